@@ -1,0 +1,581 @@
+"""CPU oracle for the recurrent memory-token + Memory-Fuser path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a plain numpy restatement of the
+reference algorithm (reference = /root/reference, 1023604540/Memory-Augmented-VLM).
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import it, and only as the checker / reported baseline.  The
+product path (``memory-augmented-vlm_amd/``) never imports anything from
+``oracle/`` and has no CPU fallback.
+
+Parity pin: the reference ships no tests and no golden vectors, so
+this restatement is pinned against outputs of the reference itself, generated in
+the build container by ``tests/golden/make_golden.py`` (imports the reference's
+own Python on CPU) and committed under ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` checks fp32 mode against them to <= 1e-5 rel-L2.
+
+Two arithmetic modes:
+
+* ``fp32``  - every op in float32 (matmuls accumulate in float32 via BLAS).
+* ``bf16`` / ``fp16`` - *operand-rounding emulation* of the HIP path: float32
+  accumulation everywhere, values rounded to the bf16/fp16 grid exactly where the
+  HIP kernels round (MFMA operands = every tensor that is stored to HBM between
+  kernels, plus the softmax probabilities fed to the P*V MFMA).  See DESIGN.md
+  "Rounding points".
+
+Each function cites the reference file:line it restates (paths relative to
+/root/reference/).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+try:  # scipy ships in the image; keep a pure-numpy erf as a guard
+    from scipy.special import erf as _erf
+except Exception:  # pragma: no cover
+    _erf = np.vectorize(math.erf, otypes=[np.float32])
+
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------- #
+# rounding helpers
+# --------------------------------------------------------------------------- #
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """Round float32 to the nearest bfloat16 (ties-to-even); returns float32."""
+    x = np.ascontiguousarray(x, dtype=F32)
+    u = x.view(np.uint32)
+    rounded = ((u + (np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))))
+               & np.uint32(0xFFFF0000))
+    out = rounded.view(F32).copy()
+    nan = np.isnan(x)
+    if nan.any():
+        out[nan] = np.nan
+    return out
+
+
+def fp16_round(x: np.ndarray) -> np.ndarray:
+    return np.asarray(x, dtype=F32).astype(np.float16).astype(F32)
+
+
+def rounder(mode: str):
+    if mode == "fp32":
+        return lambda a: np.asarray(a, dtype=F32)
+    if mode == "bf16":
+        return bf16_round
+    if mode == "fp16":
+        return fp16_round
+    raise ValueError(f"unknown mode {mode!r}")
+
+
+def bf16_bits(x: np.ndarray) -> np.ndarray:
+    """float32 (already on the bf16 grid or not) -> uint16 bf16 bit pattern (RNE)."""
+    return (bf16_round(x).view(np.uint32) >> np.uint32(16)).astype(np.uint16)
+
+
+def bits_to_f32(bits: np.ndarray) -> np.ndarray:
+    """uint16 bf16 bit pattern -> float32."""
+    return (bits.astype(np.uint32) << np.uint32(16)).view(F32)
+
+
+# --------------------------------------------------------------------------- #
+# deterministic counter-based input generator (integer hash -> float)
+# --------------------------------------------------------------------------- #
+def _mix32(x: np.ndarray) -> np.ndarray:
+    """lowbias32 integer hash on uint32 arrays (wrap-around arithmetic)."""
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    x = (x * np.uint32(0x7FEB352D)).astype(np.uint32)
+    x ^= x >> np.uint32(15)
+    x = (x * np.uint32(0x846CA68B)).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def hash_uniform(shape: Sequence[int], seed: int, lo: float = -1.0, hi: float = 1.0) -> np.ndarray:
+    """U[lo,hi) float32 tensor; element i = f(hash(i, seed)).  Reproducible anywhere."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint32)
+        h = _mix32(idx ^ _mix32(np.full(1, seed & 0xFFFFFFFF, dtype=np.uint32) + np.uint32(0x9E3779B9)))
+    u = (h >> np.uint32(8)).astype(F32) * F32(1.0 / (1 << 24))  # [0,1), 24 bits: exact in f32
+    return (F32(lo) + u * F32(hi - lo)).reshape(shape).astype(F32)
+
+
+def hash_normal_like(shape: Sequence[int], seed: int, std: float = 1.0) -> np.ndarray:
+    """Unit-variance, N(0,1)-like tensor: U(-sqrt3, sqrt3)."""
+    s = math.sqrt(3.0) * std
+    return hash_uniform(shape, seed, -s, s)
+
+
+# --------------------------------------------------------------------------- #
+# configuration and weights
+# --------------------------------------------------------------------------- #
+@dataclass
+class PathConfig:
+    """Hyper-parameters.  Defaults = the values hard-coded at llava/model/llava_arch.py:117-129
+    (H=8, P=196, M=8, depth=2, I=4D, eps=1e-12) and :146 (max_frames=600)."""
+    hidden: int = 1024
+    heads: int = 8
+    patches: int = 196
+    mem_tokens: int = 8
+    depth: int = 2
+    inter: Optional[int] = None
+    eps: float = 1e-12
+    max_frames: int = 600
+    cache_cap: int = 10
+    chunk: int = 32
+    fine_frames: int = 32
+
+    def __post_init__(self):
+        if self.inter is None:
+            self.inter = 4 * self.hidden
+        assert self.hidden % self.heads == 0
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.heads
+
+    @property
+    def mem_rows(self) -> int:
+        return self.mem_tokens * self.patches
+
+
+# Qwen2 tokenizer ids of the two hard-coded prompts, llava/model/llava_arch.py:708,714
+MEM_PROMPT_IDS = [1986, 374, 264, 1550, 11591, 12126, 315, 279, 2766, 25]
+FRAME_PROMPT_IDS = [9485, 525, 48876, 9124, 14087, 504, 279, 2766, 25]
+
+
+def attn_keys(prefix: str) -> List[str]:
+    return [f"{prefix}.{p}.{w}" for p in ("q_proj", "k_proj", "v_proj", "residual.dense", "residual.layernorm")
+            for w in ("weight", "bias")]
+
+
+def make_weights(cfg: PathConfig, seed: int = 1234, grid: str = "bf16") -> Dict[str, np.ndarray]:
+    """Synthetic weights with the reference's state-dict names and the init scales of
+    SURVEY.md §8d: nn.Linear default U(-1/sqrt(fan_in), +), LN gamma=1±0.1, beta=±0.1, xavier
+    initial_memory, N(0,1) pos-embed, N(0,0.02) type embedding.  Values snapped to ``grid``."""
+    r = rounder(grid) if grid != "fp32" else (lambda a: np.asarray(a, dtype=F32))
+    D, I, M, P = cfg.hidden, cfg.inter, cfg.mem_tokens, cfg.patches
+    w: Dict[str, np.ndarray] = {}
+    ctr = [seed * 1000]
+
+    def nxt():
+        ctr[0] += 1
+        return ctr[0]
+
+    def lin(name, out_f, in_f):
+        b = 1.0 / math.sqrt(in_f)
+        w[f"{name}.weight"] = r(hash_uniform((out_f, in_f), nxt(), -b, b))
+        w[f"{name}.bias"] = r(hash_uniform((out_f,), nxt(), -b, b))
+
+    def ln(name):
+        w[f"{name}.weight"] = r(1.0 + hash_uniform((D,), nxt(), -0.1, 0.1))
+        w[f"{name}.bias"] = r(hash_uniform((D,), nxt(), -0.1, 0.1))
+
+    def attn(prefix):
+        for p in ("q_proj", "k_proj", "v_proj"):
+            lin(f"{prefix}.{p}", D, D)
+        lin(f"{prefix}.residual.dense", D, D)
+        ln(f"{prefix}.residual.layernorm")
+
+    T = "recurrent_memory_transformer"
+    xb = math.sqrt(6.0 / (P * D + M * D))  # xavier_uniform on [M,P,D]: fan_in=P*D, fan_out=M*D
+    w[f"{T}.initial_memory"] = r(hash_uniform((M, P, D), nxt(), -xb, xb))
+    w[f"{T}.memory_pos_embed"] = r(hash_normal_like((M, 1, D), nxt()))
+    for l in range(cfg.depth):
+        attn(f"{T}.layers.{l}.memory_segment_fusion_attention")
+        lin(f"{T}.layers.{l}.mlp.0", I, D)
+        lin(f"{T}.layers.{l}.residual.dense", D, I)
+        ln(f"{T}.layers.{l}.residual.layernorm")
+    attn(f"{T}.memory_update_attention")
+    lin("memory_fuser.0", I, D)
+    lin("memory_fuser.2", D, I)
+    w["token_type_embedding.weight"] = r(hash_normal_like((2, D), nxt(), 0.02))
+    w["positional_encoding.frame_embed"] = pe_table(cfg.max_frames, D)
+    w["image_newline"] = r(hash_normal_like((D,), nxt(), 0.02))
+    return w
+
+
+# --------------------------------------------------------------------------- #
+# a1  temporal positional encoding
+# --------------------------------------------------------------------------- #
+def pe_table(max_frames: int, dim: int) -> np.ndarray:
+    """llava/model/memory_module/position_encoding.py:29-35 (sinusoidal branch), float32 math."""
+    pos = np.arange(max_frames, dtype=F32)[:, None]
+    div = np.exp(np.arange(0, dim, 2, dtype=F32) * F32(-(math.log(10000.0) / dim))).astype(F32)
+    pe = np.zeros((max_frames, dim), dtype=F32)
+    ang = (pos * div).astype(F32)
+    pe[:, 0::2] = np.sin(ang)
+    pe[:, 1::2] = np.cos(ang)
+    return pe
+
+
+def pe_add(x: np.ndarray, idx: np.ndarray, table: np.ndarray, mode: str = "fp32") -> np.ndarray:
+    """position_encoding.py:38-69,71-80: x[T,P,D] + table[idx][:,None,:]; ValueError on range."""
+    if x.ndim != 3:
+        raise ValueError(f"Expected 3D input, got {x.ndim}D.")
+    idx = np.asarray(idx, dtype=np.int64)
+    if np.any(idx >= table.shape[0]):
+        raise ValueError(f"indices exceed max_frames: max {int(idx.max())} vs limit {table.shape[0]}")
+    if np.any(idx < 0):
+        raise ValueError(f"indices contains negative values: min {int(idx.min())}")
+    r = rounder(mode)
+    pe = r(table[idx])  # .to(x.dtype), position_encoding.py:58
+    return r(r(x) + pe[:, None, :])
+
+
+# --------------------------------------------------------------------------- #
+# a2 / a3  host-side index math
+# --------------------------------------------------------------------------- #
+def torch_linspace_f32(start: float, end: float, steps: int) -> np.ndarray:
+    """float32 ``torch.linspace`` as ATen computes it (symmetric halves,
+    aten/src/ATen/native/RangeFactories: i < steps/2 ? start+step*i : end-step*(steps-1-i))."""
+    if steps == 1:
+        return np.array([start], dtype=F32)
+    s, e = F32(start), F32(end)
+    step = F32((e - s) / F32(steps - 1))
+    i = np.arange(steps)
+    lo = (s + step * i.astype(F32)).astype(F32)
+    hi = (e - step * (steps - 1 - i).astype(F32)).astype(F32)
+    return np.where(i < steps // 2, lo, hi).astype(F32)
+
+
+def subsample_count(num_frames: int) -> int:
+    """llava/model/llava_arch.py:437-445: F0<32 -> F0 ; else max(64, (F0//32)*32)."""
+    if num_frames < 32:
+        return num_frames
+    return max(64, (num_frames // 32) * 32)
+
+
+def subsample_indices(num_frames: int) -> np.ndarray:
+    """llava_arch.py:451: linspace(0, F0-1, F).long() (truncation)."""
+    return torch_linspace_f32(0, num_frames - 1, subsample_count(num_frames)).astype(np.int64)
+
+
+def fine_frame_indices(num_frames: int, want: int = 32) -> np.ndarray:
+    """llava_arch.py:513-522: round(linspace(0,T-1,min(32,T))) clamped (round-half-even)."""
+    n = min(want, num_frames)
+    v = np.rint(torch_linspace_f32(0, num_frames - 1, n)).astype(np.int64)
+    return np.clip(v, 0, num_frames - 1)
+
+
+def uniform_segment_variant(T: int, d: int = 32) -> List[int]:
+    """llava/model/memory_module/segment.py:169-192."""
+    b = [0]
+    cur = 0
+    while cur + d <= T:
+        cur += d
+        b.append(cur)
+    if cur < T:
+        b.append(T)
+    return b
+
+
+# --------------------------------------------------------------------------- #
+# a5-a7  building blocks
+# --------------------------------------------------------------------------- #
+def linear(x: np.ndarray, W: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """nn.Linear: x W^T + b, float32 accumulate (operands already on their grid)."""
+    return (x.astype(F32) @ W.astype(F32).T + b.astype(F32)).astype(F32)
+
+
+def layernorm(x: np.ndarray, g: np.ndarray, b: np.ndarray, eps: float) -> np.ndarray:
+    """nn.LayerNorm over last dim, biased variance, rsqrt(var+eps) (MemoryController.py:24,28)."""
+    x64 = x.astype(np.float64)
+    mu = x64.mean(-1, keepdims=True)
+    var = ((x64 - mu) ** 2).mean(-1, keepdims=True)
+    y = (x64 - mu) / np.sqrt(var + eps)
+    return (y * g.astype(np.float64) + b.astype(np.float64)).astype(F32)
+
+
+def gelu_erf(x: np.ndarray) -> np.ndarray:
+    """nn.GELU() default = exact erf form (llava_arch.py:134)."""
+    x = x.astype(F32)
+    return (0.5 * x * (1.0 + _erf(x / F32(math.sqrt(2.0))))).astype(F32)
+
+
+def mha(Xq: np.ndarray, Xkv: np.ndarray, w: Dict[str, np.ndarray], prefix: str, cfg: PathConfig,
+        mode: str = "fp32", want_colsum: bool = False, want_probs: bool = False,
+        kv_cached: Optional[Tuple[np.ndarray, np.ndarray]] = None):
+    """``Attention.forward`` (MemoryController.py:47-57): q/k/v Linear, H heads, softmax(qk^T/sqrt d),
+    P V, merge heads, Residual = LN(dense(ctx) + Xq).  Returns (out[R,D], colsum[Lk] | None, probs | None).
+
+    Emulation mode rounds: Q,K,V (stored), P (MFMA operand; row sum l from unrounded p),
+    ctx (stored), LN output (stored).  dense+bias+residual stays float32 into the LN.
+    """
+    r = rounder(mode)
+    H, d, D = cfg.heads, cfg.head_dim, cfg.hidden
+    Q = r(linear(Xq, w[f"{prefix}.q_proj.weight"], w[f"{prefix}.q_proj.bias"]))
+    if kv_cached is None:
+        K = r(linear(Xkv, w[f"{prefix}.k_proj.weight"], w[f"{prefix}.k_proj.bias"]))
+        V = r(linear(Xkv, w[f"{prefix}.v_proj.weight"], w[f"{prefix}.v_proj.bias"]))
+    else:
+        K, V = kv_cached
+    R, Lk = Q.shape[0], K.shape[0]
+    ctx = np.empty((R, D), dtype=F32)
+    colsum = np.zeros(Lk, dtype=np.float64) if want_colsum else None
+    probs = np.empty((H, R, Lk), dtype=F32) if want_probs else None
+    scale = F32(1.0 / math.sqrt(d))
+    for h in range(H):
+        sl = slice(h * d, (h + 1) * d)
+        s = (Q[:, sl] @ K[:, sl].T).astype(F32) * scale          # MemoryController.py:51
+        s -= s.max(axis=1, keepdims=True)
+        p = np.exp(s, dtype=F32)
+        l = p.sum(axis=1, keepdims=True, dtype=F32)
+        if want_colsum or want_probs:
+            pn = p / l                                           # :52 normalised probabilities
+            if want_colsum:
+                colsum += pn.sum(axis=0, dtype=np.float64)       # :135 sum over heads and queries
+            if want_probs:
+                probs[h] = pn
+        ctx[:, sl] = (r(p) @ V[:, sl]) / l                       # :53 (P rounded as the MFMA operand)
+    ctx = r(ctx)
+    pre = linear(ctx, w[f"{prefix}.residual.dense.weight"], w[f"{prefix}.residual.dense.bias"]) + Xq
+    out = r(layernorm(pre, w[f"{prefix}.residual.layernorm.weight"],
+                      w[f"{prefix}.residual.layernorm.bias"], cfg.eps))     # :26-29,55
+    return out, (colsum.astype(F32) if want_colsum else None), probs
+
+
+def project_kv(X: np.ndarray, w: Dict[str, np.ndarray], prefix: str, mode: str):
+    r = rounder(mode)
+    return (r(linear(X, w[f"{prefix}.k_proj.weight"], w[f"{prefix}.k_proj.bias"])),
+            r(linear(X, w[f"{prefix}.v_proj.weight"], w[f"{prefix}.v_proj.bias"])))
+
+
+def transformer_layer(m: np.ndarray, seg: np.ndarray, w: Dict[str, np.ndarray], prefix: str,
+                      cfg: PathConfig, mode: str, want_colsum: bool):
+    """``TransformerLayer.forward`` (MemoryController.py:69-72): cross-attn -> Linear(D,4D)+ReLU ->
+    Residual(4D->D)."""
+    r = rounder(mode)
+    a, colsum, _ = mha(m, seg, w, f"{prefix}.memory_segment_fusion_attention", cfg, mode, want_colsum)
+    h = r(np.maximum(linear(a, w[f"{prefix}.mlp.0.weight"], w[f"{prefix}.mlp.0.bias"]), 0))
+    pre = linear(h, w[f"{prefix}.residual.dense.weight"], w[f"{prefix}.residual.dense.bias"]) + a
+    out = r(layernorm(pre, w[f"{prefix}.residual.layernorm.weight"],
+                      w[f"{prefix}.residual.layernorm.bias"], cfg.eps))
+    return out, colsum
+
+
+# --------------------------------------------------------------------------- #
+# a8-a10  recurrent memory transformer
+# --------------------------------------------------------------------------- #
+@dataclass
+class RecurrentMemory:
+    """``TransformerProjector`` (MemoryController.py:74-158) restated.  ``memory_cache`` and
+    ``frame_attn_scores`` mirror the reference attributes (the latter is never cleared by the
+    reference either, MemoryController.py:157)."""
+    cfg: PathConfig
+    w: Dict[str, np.ndarray]
+    mode: str = "fp32"
+    prefix: str = "recurrent_memory_transformer"
+    frame_scores: bool = True
+    memory_cache: List[np.ndarray] = field(default_factory=list)
+    frame_attn_scores: List[np.ndarray] = field(default_factory=list)
+    _kv_cache: List[Tuple[np.ndarray, np.ndarray]] = field(default_factory=list)
+
+    def reset(self):
+        """llava_arch.py:532 - the caller clears memory_cache per video."""
+        self.memory_cache = []
+        self._kv_cache = []
+
+    def initial(self) -> np.ndarray:
+        r = rounder(self.mode)
+        cfg = self.cfg
+        m = r(self.w[f"{self.prefix}.initial_memory"] + self.w[f"{self.prefix}.memory_pos_embed"])  # :123-124
+        return m.reshape(cfg.mem_rows, cfg.hidden)
+
+    def evolve(self, last: np.ndarray) -> np.ndarray:
+        """``_update_memory_tokens_with_cache`` (:89-115): q = last memory, kv = cat(cache) (which
+        includes ``last``).  K/V of each cached memory are projected once and kept (row-independent,
+        exact).  The per-chunk statistics at :99-109 are dead code and are not restated."""
+        cfg = self.cfg
+        pfx = f"{self.prefix}.memory_update_attention"
+        while len(self._kv_cache) < len(self.memory_cache):
+            mem = self.memory_cache[len(self._kv_cache)].reshape(cfg.mem_rows, cfg.hidden)
+            self._kv_cache.append(project_kv(mem, self.w, pfx, self.mode))
+        K = np.concatenate([k for k, _ in self._kv_cache], axis=0)
+        V = np.concatenate([v for _, v in self._kv_cache], axis=0)
+        out, _, _ = mha(last, None, self.w, pfx, cfg, self.mode, kv_cached=(K, V))
+        return out
+
+    def step(self, seg: np.ndarray):
+        """``TransformerProjector.forward`` (:118-158).  seg: [F,P,D] (already PE-added)."""
+        cfg = self.cfg
+        F_, P, D = seg.shape
+        assert P == cfg.patches and D == cfg.hidden
+        r = rounder(self.mode)
+        if self.memory_cache:
+            m = self.evolve(self.memory_cache[-1].reshape(cfg.mem_rows, D))        # :125-127
+        else:
+            m = self.initial()
+        x = r(seg.reshape(F_ * P, D))
+        colsum = None
+        for l in range(cfg.depth):                                                   # :132-133
+            last = l == cfg.depth - 1
+            m, cs = transformer_layer(m, x, self.w, f"{self.prefix}.layers.{l}", cfg, self.mode,
+                                      want_colsum=(last and self.frame_scores))
+            if last:
+                colsum = cs
+        if colsum is not None:
+            scores = colsum.reshape(F_, P).mean(axis=1).astype(F32)                 # :135-139
+            self.frame_attn_scores.append(scores)                                    # :156-157
+        self.memory_cache.append(m.reshape(cfg.mem_tokens, P, D))                    # :152
+        if len(self.memory_cache) > cfg.cache_cap:                                   # :153-154
+            drop = len(self.memory_cache) - cfg.cache_cap
+            self.memory_cache = self.memory_cache[drop:]
+            self._kv_cache = self._kv_cache[drop:]
+        return self.memory_cache, self.frame_attn_scores
+
+
+# --------------------------------------------------------------------------- #
+# a11-a13  fuser MLP, token-type add, concat
+# --------------------------------------------------------------------------- #
+def fuser_mlp(x: np.ndarray, w: Dict[str, np.ndarray], mode: str = "fp32",
+              add: Optional[np.ndarray] = None) -> np.ndarray:
+    """``memory_fuser`` = Linear(D,4D) -> GELU(erf) -> Linear(4D,D) (llava_arch.py:132-136,546),
+    no residual, no norm; ``add`` = token_type_embedding[0] fused into the second epilogue (:548-553)."""
+    r = rounder(mode)
+    shp = x.shape
+    x2 = r(x.reshape(-1, shp[-1]))
+    u = r(gelu_erf(linear(x2, w["memory_fuser.0.weight"], w["memory_fuser.0.bias"])))
+    y = linear(u, w["memory_fuser.2.weight"], w["memory_fuser.2.bias"])
+    if add is not None:
+        y = y + add.astype(F32)
+    return r(y).reshape(shp)
+
+
+def video_tokens(x: np.ndarray, frame_idx: np.ndarray, cfg: PathConfig, w: Dict[str, np.ndarray],
+                 embed_tokens: np.ndarray, mode: str = "fp32", frame_scores: bool = True,
+                 return_parts: bool = False):
+    """The per-video memory driver, llava_arch.py:502-557 + 613-629 + 705-731:
+    PE add -> fine frames -> chunk loop -> fuser -> type add -> [mem_prompt ; memory ; newline ;
+    frame_prompt ; fine ; newline].  ``x``: pooled frame tokens [T,P,D]; ``embed_tokens``: [vocab,D]
+    table of the host LLM (only the 19 prompt ids are read)."""
+    r = rounder(mode)
+    T = x.shape[0]
+    xp = pe_add(x, frame_idx, w["positional_encoding.frame_embed"], mode)          # :510-511
+    fine = xp[fine_frame_indices(T, cfg.fine_frames)]                               # :513-524
+    rm = RecurrentMemory(cfg, w, mode, frame_scores=frame_scores)
+    rm.reset()                                                                      # :532
+    b = uniform_segment_variant(T, cfg.chunk)                                       # :528
+    for i in range(len(b) - 1):                                                     # :534-537
+        rm.step(xp[b[i]:b[i + 1]])
+    mem = np.concatenate(rm.memory_cache, axis=0)                                   # :545
+    E = r(w["token_type_embedding.weight"])
+    mem = fuser_mlp(mem, w, mode, add=E[0])                                         # :546-553
+    fine = r(fine + E[1])                                                           # :554
+    nl = r(w["image_newline"])[None]
+    et = r(embed_tokens)
+    toks = np.concatenate([et[MEM_PROMPT_IDS], mem.reshape(-1, cfg.hidden), nl,
+                           et[FRAME_PROMPT_IDS], fine.reshape(-1, cfg.hidden), nl], axis=0)  # :620-629,729-731
+    if return_parts:
+        return toks, dict(pe=xp, memory=rm.memory_cache, fused=mem, fine=fine,
+                          frame_scores=rm.frame_attn_scores)
+    return toks
+
+
+# --------------------------------------------------------------------------- #
+# a14  splice into the text sequence
+# --------------------------------------------------------------------------- #
+IGNORE_INDEX = -100          # llava/constants.py:7
+IMAGE_TOKEN_INDEX = -200     # llava/constants.py:8
+
+
+def splice(input_ids: np.ndarray, labels: Optional[np.ndarray], attention_mask: Optional[np.ndarray],
+           image_tokens: np.ndarray, embed_tokens: np.ndarray, max_len: Optional[int] = None,
+           padding_side: str = "right"):
+    """Batch-1..B splice of the per-video token block at IMAGE_TOKEN_INDEX, truncate, pad
+    (llava_arch.py:745-866).  Every sample uses ``image_tokens`` in order of appearance; the
+    reference supports batch size 1 for the memory path (:436).  Returns
+    (embeds[B,L,D], labels[B,L], mask[B,L] bool, position_ids[B,L])."""
+    B = input_ids.shape[0]
+    if attention_mask is None:
+        attention_mask = np.ones_like(input_ids, dtype=bool)
+    if labels is None:
+        labels = np.full_like(input_ids, IGNORE_INDEX)
+    outs, labs = [], []
+    for b in range(B):
+        ids = input_ids[b][attention_mask[b].astype(bool)]
+        lab = labels[b][attention_mask[b].astype(bool)]
+        pieces, lpieces = [], []
+        start = 0
+        pos = list(np.where(ids == IMAGE_TOKEN_INDEX)[0]) + [len(ids)]
+        for j, p in enumerate(pos):
+            pieces.append(embed_tokens[ids[start:p]])
+            lpieces.append(lab[start:p])
+            if j < len(pos) - 1:
+                pieces.append(image_tokens)
+                lpieces.append(np.full(image_tokens.shape[0], IGNORE_INDEX, dtype=lab.dtype))
+            start = p + 1
+        e = np.concatenate(pieces, axis=0)[:max_len]
+        l = np.concatenate(lpieces, axis=0)[:max_len]
+        outs.append(e)
+        labs.append(l)
+    L = max(e.shape[0] for e in outs)
+    D = image_tokens.shape[1]
+    emb = np.zeros((B, L, D), dtype=F32)
+    lab = np.full((B, L), IGNORE_INDEX, dtype=np.int64)
+    msk = np.zeros((B, L), dtype=bool)
+    pid = np.zeros((B, L), dtype=np.int64)
+    for b, (e, l) in enumerate(zip(outs, labs)):
+        n = e.shape[0]
+        sl = slice(L - n, L) if padding_side == "left" else slice(0, n)
+        if n:
+            emb[b, sl] = e
+            lab[b, sl] = l
+            msk[b, sl] = True
+            pid[b, sl] = np.arange(n)
+    return emb, lab, msk, pid
+
+
+# --------------------------------------------------------------------------- #
+# a16  step before the path: bilinear 2x2 pool (next-row)
+# --------------------------------------------------------------------------- #
+def bilinear_pool(x: np.ndarray, side: int = 27, stride: int = 2) -> np.ndarray:
+    """``get_2dPool`` bilinear branch (llava_arch.py:277-297): [F,side*side,D] ->
+    F.interpolate(size=ceil(side/stride), mode='bilinear', align_corners=False) -> [F,out*out,D]."""
+    Fn, N, D = x.shape
+    assert N == side * side
+    out = math.ceil(side / stride)
+    img = x.reshape(Fn, side, side, D).astype(F32)
+    scale = F32(side) / F32(out)
+
+    def src(n_out):
+        c = (np.arange(n_out, dtype=F32) + F32(0.5)) * scale - F32(0.5)
+        c = np.maximum(c, F32(0.0))
+        i0 = np.floor(c).astype(np.int64)
+        i1 = np.minimum(i0 + 1, side - 1)
+        lam = (c - i0.astype(F32)).astype(F32)
+        return i0, i1, lam
+
+    y0, y1, ly = src(out)
+    x0, x1, lx = src(out)
+    top = img[:, y0][:, :, x0] * (1 - lx)[None, None, :, None] + img[:, y0][:, :, x1] * lx[None, None, :, None]
+    bot = img[:, y1][:, :, x0] * (1 - lx)[None, None, :, None] + img[:, y1][:, :, x1] * lx[None, None, :, None]
+    res = top * (1 - ly)[None, :, None, None] + bot * ly[None, :, None, None]
+    return res.reshape(Fn, out * out, D).astype(F32)
+
+
+# --------------------------------------------------------------------------- #
+# algorithmic work - used by bench.py for the roofline line
+# --------------------------------------------------------------------------- #
+def flops_formation(R: int, S: int, D: int, L: int) -> float:
+    return L * (20.0 * R * D * D + 4.0 * S * D * D + 4.0 * R * S * D)
+
+
+def flops_evolution(R: int, C: int, D: int) -> float:
+    """K/V of cached memories projected once per memory: 4*R*D^2 (q,out) + 4*R*D^2 (new K/V) + attn."""
+    return 4.0 * R * D * D + 4.0 * R * D * D + 4.0 * R * C * D
+
+
+def flops_fuser(N: int, D: int) -> float:
+    return 16.0 * N * D * D
+
+
+def rel_l2(a: np.ndarray, b: np.ndarray) -> float:
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))

@@ -1,0 +1,339 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the *reference's own Python* on CPU.
+
+Runs ONLY in the build container (needs /root/reference, read-only).  Nothing here travels
+as code to the GPU box except this script itself; its outputs (``tests/golden/*.npz``) are data:
+inputs are regenerated from the counter-based generator in ``oracle/memory_path.py`` (seeds stored
+in the files), outputs are what the reference computed.
+
+Import recipe: single reference files are loaded in isolation with
+``importlib.util.spec_from_file_location``; the glue in ``llava/model/llava_arch.py`` is imported
+through an empty ``llava`` namespace module plus three compatibility names on
+``transformers.modeling_utils`` (the reference pins transformers 4.40-dev; the image has 5.x).
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+os.environ.setdefault("HF_HUB_OFFLINE", "1")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+from oracle import memory_path as O  # noqa: E402  (input/weight generator shared with the tests)
+
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+def load_ref_file(name):
+    path = f"{REF}/llava/model/memory_module/{name}.py"
+    spec = importlib.util.spec_from_file_location(f"ref_{name}", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+MC = load_ref_file("MemoryController")
+PEm = load_ref_file("position_encoding")
+SEG = load_ref_file("segment")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def ref_projector(cfg: O.PathConfig, w, dtype=torch.float32):
+    c = MC.Config()
+    c.mm_hidden_size = cfg.hidden
+    c.mm_intermediate_size = cfg.inter
+    c.mm_num_attention_heads = cfg.heads
+    c.num_memory_tokens = cfg.mem_tokens
+    c.patch_size = cfg.patches
+    c.depth = cfg.depth
+    c.mm_layer_norm_eps = cfg.eps
+    c.mm_dtype = torch.float32
+    m = MC.TransformerProjector(c).eval()
+    pfx = "recurrent_memory_transformer."
+    sd = {k[len(pfx):]: T(v) for k, v in w.items() if k.startswith(pfx)}
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    return m.to(dtype)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {name}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def meta(**kw):
+    kw["torch"] = torch.__version__
+    return np.frombuffer(json.dumps(kw).encode(), dtype=np.uint8)
+
+
+# --------------------------------------------------------------------------- G1 / G2
+def g1_g2():
+    cfg = O.PathConfig(hidden=128, heads=8, mem_tokens=2, depth=1)
+    w = O.make_weights(cfg, seed=11)
+    m = ref_projector(cfg, w)
+    R, S = 392, 588
+    xq = O.bf16_round(O.hash_normal_like((R, 128), 101))
+    xkv = O.bf16_round(O.hash_normal_like((S, 128), 102))
+    att = m.layers[0].memory_segment_fusion_attention
+    out, probs = att(T(xq)[None], kv_hidden_states=T(xkv)[None])
+    colsum = probs.sum(dim=1).sum(dim=1).squeeze(0)
+    lay_out, lay_probs = m.layers[0](T(xq)[None], T(xkv)[None])
+    save("g1_attention.npz", meta=meta(hidden=128, heads=8, R=R, S=S, wseed=11, qseed=101, kvseed=102, mem_tokens=2,
+                                        depth=1),
+         out=out[0].numpy(), colsum=colsum.numpy(), probs_h0_rows=probs[0, 0, :4].numpy(),
+         layer_out=lay_out[0].numpy())
+
+
+# --------------------------------------------------------------------------- G3
+def g3():
+    # NB: the reference's dead statistics code (MemoryController.py:109, reshape(8,-1,8)) raises for
+    # any num_memory_tokens that is not a multiple of 8 once the cache is non-empty -> M=8 here.
+    cfg = O.PathConfig(hidden=64, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=31)
+    m = ref_projector(cfg, w)
+    m.memory_cache = []
+    m.frame_attn_scores = []
+    outs = {}
+    F = 3
+    for t in range(4):
+        seg = O.bf16_round(O.hash_normal_like((F, 196, 64), 300 + t))
+        cache, scores = m(T(seg))
+        full = cache[-1].numpy()
+        outs[f"mem{t}"] = full.copy() if t == 3 else full[:, ::4, :].copy()
+        outs[f"mem{t}_sum"] = np.array(full.astype(np.float64).sum())
+        outs[f"score{t}"] = scores[-1].numpy().copy()
+        assert len(cache) == t + 1
+    save("g3_recurrent.npz", meta=meta(hidden=64, heads=8, mem_tokens=8, depth=2, F=F, steps=4, wseed=31, segseed0=300, rowstride_first3=4),
+         **outs)
+
+    # FIFO eviction: 12 steps, cap 10, ragged chunk sizes (1 or 2 frames)
+    cfg = O.PathConfig(hidden=32, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=32)
+    m = ref_projector(cfg, w)
+    m.memory_cache = []
+    m.frame_attn_scores = []
+    fr = [1, 2, 1, 1, 2, 1, 1, 1, 2, 1, 1, 2]
+    for t, f in enumerate(fr):
+        seg = O.bf16_round(O.hash_normal_like((f, 196, 32), 400 + t))
+        cache, scores = m(T(seg))
+    assert len(cache) == 10
+    save("g3_fifo.npz", meta=meta(hidden=32, heads=8, mem_tokens=8, depth=2, frames=fr, wseed=32, segseed0=400, rowstride=8),
+         cache=torch.stack(cache).numpy()[:, :, ::8, :].copy(),
+         cache_sums=torch.stack(cache).double().sum(dim=(1, 2, 3)).numpy(), scores_last=scores[-1].numpy(), n_scores=np.array(len(scores)))
+
+
+# --------------------------------------------------------------------------- G4
+def g4():
+    D = 64
+    pe = PEm.TemporalPositionalEncoding(max_frames=600, embed_dim=D, learnable=False)
+    table = pe.frame_embed.numpy()
+    pe1024 = PEm.TemporalPositionalEncoding(max_frames=600, embed_dim=1024, learnable=False).frame_embed.numpy()
+    x = O.hash_normal_like((7, 196, D), 41)
+    idx = np.array([0, 3, 17, 100, 333, 598, 599], dtype=np.int64)
+    y = pe(T(x), T(idx)).numpy()
+    ydef = pe(T(x)).numpy()
+    errs = {}
+    for name, bad in (("too_big", [0, 600]), ("negative", [-1, 5])):
+        try:
+            pe(T(x[:2]), T(np.array(bad, dtype=np.int64)))
+            errs[name] = "no error"
+        except ValueError as e:
+            errs[name] = str(e)
+    try:
+        pe(T(x[0]))
+        errs["rank2"] = "no error"
+    except ValueError as e:
+        errs["rank2"] = str(e)
+    save("g4_pe.npz", meta=meta(D=D, xseed=41, errors=errs), table=table, idx=idx, y=y, ydef=ydef,
+         table1024_rows=pe1024[[0, 1, 2, 299, 599]], table1024_sum=np.array(pe1024.astype(np.float64).sum()))
+
+
+# --------------------------------------------------------------------------- glue import
+def import_glue():
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+    for n in ("apply_chunking_to_forward", "find_pruneable_heads_and_indices", "prune_linear_layer"):
+        if not hasattr(mu, n):
+            if hasattr(pu, n):
+                setattr(mu, n, getattr(pu, n))
+            else:
+                def _stub(*a, _n=n, **k):
+                    raise NotImplementedError(_n)
+                setattr(mu, n, _stub)
+    pkg = types.ModuleType("llava")
+    pkg.__path__ = [f"{REF}/llava"]
+    sys.modules["llava"] = pkg
+    from llava.model.llava_arch import LlavaMetaModel, LlavaMetaForCausalLM
+    return LlavaMetaModel, LlavaMetaForCausalLM
+
+
+# --------------------------------------------------------------------------- G5 / G6
+def g5_g6():
+    LlavaMetaModel, LlavaMetaForCausalLM = import_glue()
+    import torch.nn as nn
+    D = 32
+    VOCAB = 48900
+    SIDE = 27
+
+    class Cfg:
+        hidden_size = D
+        mm_patch_merge_type = "spatial_unpad"
+        mm_newline_position = "one_token"
+        mm_spatial_pool_mode = "bilinear"
+        image_aspect_ratio = "anyres_max_9"
+        tokenizer_model_max_length = 32768
+        tokenizer_padding_side = "right"
+
+    class FakeTower(nn.Module):
+        num_patches_per_side = SIDE
+
+        def __init__(self):
+            super().__init__()
+            self.table = None
+
+        def forward(self, images):  # images [F,1,1,1] holding the original frame id
+            ids = images.reshape(-1).long()
+            return self.table[ids]
+
+    class TinyBase(nn.Module):
+        def __init__(self, config):
+            super().__init__()
+            self.embed_tokens = nn.Embedding(VOCAB, D)
+
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+        @property
+        def dtype(self):
+            return torch.float32
+
+    class TinyModel(LlavaMetaModel, TinyBase):
+        pass
+
+    class TinyLM(LlavaMetaForCausalLM, nn.Module):
+        def __init__(self):
+            nn.Module.__init__(self)
+            self.config = Cfg()
+            self.model = TinyModel(self.config)
+            self.model.vision_tower = FakeTower()
+            self.model.mm_projector = nn.Identity()
+            self.model.image_newline = nn.Parameter(torch.zeros(D))
+
+        def get_model(self):
+            return self.model
+
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+    cfg = O.PathConfig(hidden=D, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=61)
+    lm = TinyLM().eval().float()  # Config.mm_dtype=fp16 is only a creation dtype (SURVEY App.A); run in fp32
+    sd = lm.model.state_dict()
+    for k, v in w.items():
+        if k in sd:
+            sd[k].copy_(T(v))
+    # embed table: only the prompt + text ids are non-zero (kept tiny & reproducible)
+    text_ids = [151644, 8948]  # replaced below: keep ids < VOCAB
+    text_ids = [11, 22, 33, 44]
+    rows = sorted(set(O.MEM_PROMPT_IDS + O.FRAME_PROMPT_IDS + text_ids))
+    emb = np.zeros((VOCAB, D), dtype=np.float32)
+    emb[rows] = O.bf16_round(O.hash_normal_like((len(rows), D), 62, 0.02))
+    lm.model.embed_tokens.weight.copy_(T(emb))
+    lm.model.image_newline.copy_(T(w["image_newline"]))
+
+    index_cases = {}
+    for F0 in (1, 8, 31, 32, 33, 63, 64, 65, 95, 96, 100, 127, 128, 200, 330, 599):
+        n = F0 if F0 < 32 else max(64, (F0 // 32) * 32)
+        idx = torch.linspace(0, F0 - 1, steps=n).long().numpy()
+        ns = min(32, n)
+        fine = torch.clamp(torch.round(torch.linspace(0, n - 1, steps=ns)).long(), 0, n - 1).numpy()
+        bounds = np.array(SEG.uniform_segment_variant(torch.zeros(n, 1), d=32))
+        index_cases[f"idx_{F0}"] = idx
+        index_cases[f"fine_{F0}"] = fine
+        index_cases[f"bounds_{F0}"] = bounds
+
+    e2e = {}
+    for F0, rowstep in ((8, 1), (70, 13), (330, 29)):
+        feats = O.bf16_round(O.hash_normal_like((F0, SIDE * SIDE, D), 600 + F0))
+        lm.model.vision_tower.table = T(feats)
+        images = [torch.arange(F0, dtype=torch.float32).reshape(F0, 1, 1, 1)]
+        input_ids = torch.tensor([[11, 22, -200, 33, 44]])
+        labels = torch.tensor([[-100, -100, -100, 33, 44]])
+        am = torch.ones_like(input_ids)
+        lm.get_model().recurrent_memory_transformer.frame_attn_scores = []
+        out = lm.prepare_inputs_labels_for_multimodal(input_ids, None, am, None, labels, images, modalities=["video"])
+        _, pos, mask, _, embeds, labs = out
+        embeds = embeds[0].numpy()
+        e2e[f"rows_{F0}"] = np.array(embeds.shape[0])
+        e2e[f"embeds_{F0}"] = embeds[::rowstep].copy()
+        e2e[f"rowsum_{F0}"] = embeds.astype(np.float64).sum(axis=1)
+        e2e[f"labels_{F0}"] = labs[0].numpy()[-8:]
+        e2e[f"mask_all_{F0}"] = np.array(bool(mask.all()))
+        e2e[f"scores_{F0}"] = torch.stack(lm.get_model().recurrent_memory_transformer.frame_attn_scores[-1:]).numpy()
+        if F0 == 8:
+            pooled = lm.get_2dPool(T(feats[:2]))
+            e2e["pool_in_seed"] = np.array(600 + F0)
+            e2e["pooled_2"] = pooled.numpy()
+    save("g5_index.npz", meta=meta(note="torch.linspace/.long()/round index math"), **index_cases)
+    save("g6_glue.npz", meta=meta(D=D, side=SIDE, wseed=61, embseed=62, emb_rows=rows, text_ids=text_ids,
+                                   featseed0=600, rowsteps={"8": 1, "70": 13, "330": 29}), **e2e)
+
+
+# --------------------------------------------------------------------------- G7
+def g7():
+    res = {}
+    for tag, M, F, steps in (("m8f32", 8, 32, 3), ("m64f8", 64, 8, 1)):
+        cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=M, depth=2)
+        w = O.make_weights(cfg, seed=71)
+        m = ref_projector(cfg, w)
+        m.memory_cache = []
+        m.frame_attn_scores = []
+        for t in range(steps):
+            seg = O.bf16_round(O.hash_normal_like((F, 196, 1024), 700 + t))
+            cache, scores = m(T(seg))
+            mem = cache[-1].numpy().reshape(-1)
+            res[f"{tag}_s{t}_sample"] = mem[::997].copy()
+            res[f"{tag}_s{t}_norm"] = np.array(np.linalg.norm(mem.astype(np.float64)))
+            res[f"{tag}_s{t}_sum"] = np.array(mem.astype(np.float64).sum())
+            res[f"{tag}_s{t}_scores"] = scores[-1].numpy().copy()
+        # reference bf16 run of the same thing: documents the reference's own bf16-vs-fp32 envelope
+        mb = ref_projector(cfg, w, torch.bfloat16)
+        mb.memory_cache = []
+        mb.frame_attn_scores = []
+        for t in range(steps):
+            seg = O.bf16_round(O.hash_normal_like((F, 196, 1024), 700 + t))
+            cache, scores = mb(T(seg).to(torch.bfloat16))
+            mem = cache[-1].float().numpy().reshape(-1)
+            res[f"{tag}_s{t}_sample_refbf16"] = mem[::997].copy()
+    save("g7_fullsize.npz", meta=meta(hidden=1024, wseed=71, segseed0=700, stride=997), **res)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g56", "g7"]
+    if "g1" in which:
+        g1_g2()
+    if "g3" in which:
+        g3()
+    if "g4" in which:
+        g4()
+    if "g56" in which:
+        g5_g6()
+    if "g7" in which:
+        g7()
