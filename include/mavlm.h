@@ -1,0 +1,149 @@
+/* mavlm.h - C ABI of the MI355X-native recurrent memory-token + Memory-Fuser path.
+ *
+ * Drop-in boundary for the hot path that 1023604540/Memory-Augmented-VLM layers on LLaVA-OneVision.  The
+ * reference has no FFI of its own (pure Python on ATen); each entry point below names the reference interface
+ * it replaces (file:line relative to the reference root).  Plain pointers and sizes only - no torch types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked "host"; tensors are row-major and contiguous unless a
+ *     leading dimension (ld*, in elements) is passed; 16-bit tensors are bf16 (dtype 0) or fp16 (dtype 1);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises or
+ *     allocates, so every call can be captured into a hipGraph;
+ *   - return value: 0 = success, >0 = hipError_t from the runtime, <0 = MAVLM_E_* argument error.
+ *     Nothing throws.  The handle is not re-entrant (the reference module is not either: it owns the
+ *     mutable memory_cache list, MemoryController.py:85-87).
+ */
+#ifndef MAVLM_H_
+#define MAVLM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAVLM_ABI_VERSION 1
+#define MAVLM_MAX_DEPTH 8
+
+#define MAVLM_E_ARG (-1)        /* null pointer / bad size */
+#define MAVLM_E_SHAPE (-2)      /* shape not supported by the kernels */
+#define MAVLM_E_STATE (-3)      /* weights / buffers not bound, or reset missing */
+
+typedef struct mavlm_ctx mavlm_ctx;
+
+/* Hyper-parameters: `Config` (llava/model/memory_module/MemoryController.py:7-18) as overridden at
+ * llava/model/llava_arch.py:117-129, plus the FIFO cap (MemoryController.py:153-154). */
+typedef struct mavlm_config {
+  int32_t hidden;           /* D, mm_hidden_size; multiple of 128; head_dim = D/heads must be 128 */
+  int32_t heads;            /* H, mm_num_attention_heads (8) */
+  int32_t patches;          /* P, patch_size (196) */
+  int32_t mem_tokens;       /* M, num_memory_tokens (8) */
+  int32_t depth;            /* L, depth (2) */
+  int32_t inter;            /* I, mm_intermediate_size (4D) */
+  int32_t cache_cap;        /* FIFO length (10) */
+  int32_t max_chunk_frames; /* largest F passed to mavlm_step (32) */
+  int32_t dtype;            /* 0 = bf16, 1 = fp16 */
+  float eps;                /* mm_layer_norm_eps (1e-12) */
+} mavlm_config;
+
+/* One `Attention` block (MemoryController.py:31-57) minus its K/V projections.  Weights [out,in] 16-bit
+ * (nn.Linear layout), biases and LayerNorm affine parameters fp32. */
+typedef struct mavlm_attn_weights {
+  const void* wq;  const float* bq;     /* q_proj            [D,D],[D] */
+  const void* wo;  const float* bo;     /* residual.dense    [D,D],[D] */
+  const float* ln_g; const float* ln_b; /* residual.layernorm [D]      */
+} mavlm_attn_weights;
+
+/* Borrowed device pointers into the packed parameter storage (packed once by the host module from the
+ * reference state-dict names listed in SURVEY.md §8b). */
+typedef struct mavlm_weights {
+  const void* mem0;                     /* [M*P, D] 16-bit: initial_memory + memory_pos_embed (MemoryController.py:123) */
+  const void* w_kv_seg; const float* b_kv_seg; /* [2*L*D, D]: rows K_0,V_0,K_1,V_1,... of layers[l].memory_segment_fusion_attention.{k,v}_proj */
+  mavlm_attn_weights layer_attn[MAVLM_MAX_DEPTH];
+  const void* w_up[MAVLM_MAX_DEPTH];   const float* b_up[MAVLM_MAX_DEPTH];   /* layers[l].mlp.0          [I,D] */
+  const void* w_down[MAVLM_MAX_DEPTH]; const float* b_down[MAVLM_MAX_DEPTH]; /* layers[l].residual.dense [D,I] */
+  const float* ln2_g[MAVLM_MAX_DEPTH]; const float* ln2_b[MAVLM_MAX_DEPTH];  /* layers[l].residual.layernorm */
+  mavlm_attn_weights evo;               /* memory_update_attention */
+  const void* w_kv_evo; const float* b_kv_evo; /* [2D, D]: rows K,V of memory_update_attention.{k,v}_proj */
+  const void* w_f1; const float* b_f1;  /* memory_fuser.0 [I,D]  (llava_arch.py:132-136) */
+  const void* w_f2; const float* b_f2_type0; /* memory_fuser.2 [D,I]; bias + token_type_embedding[0] (llava_arch.py:548-553) */
+  const void* type1;                    /* [D] 16-bit token_type_embedding[1] (llava_arch.py:554) */
+} mavlm_weights;
+
+/* Caller-allocated state and scratch (the module owns them as torch tensors). */
+typedef struct mavlm_buffers {
+  void* mem_ring;       /* [cache_cap, M*P, D]  16-bit  memory_cache entries, slot = step % cache_cap */
+  void* evo_kv_ring;    /* [cache_cap, M*P, 2D] 16-bit  K|V projections of each cached memory (projected once) */
+  void* workspace;      /* mavlm_workspace_bytes() bytes, 256-B aligned */
+  size_t workspace_bytes;
+} mavlm_buffers;
+
+/* --- lifecycle -------------------------------------------------------------------------------------- */
+int mavlm_abi_version(void);
+/* replaces TransformerProjector.__init__ (MemoryController.py:74-87) - host-side handle only */
+int mavlm_create(const mavlm_config* cfg, mavlm_ctx** out);
+void mavlm_destroy(mavlm_ctx* ctx);
+size_t mavlm_workspace_bytes(const mavlm_config* cfg);
+/* byte offsets of the 10 workspace regions {kv_seg, q, ctx, a, h, pre(fp32), mA, mB, lse2, colsum_part}: lets the
+ * parity tests read the intermediates of the last sub-layer after a step (stage-wise checks) */
+int mavlm_workspace_layout(const mavlm_config* cfg, size_t* offsets, int32_t n);
+int mavlm_bind_weights(mavlm_ctx* ctx, const mavlm_weights* w);
+int mavlm_bind_buffers(mavlm_ctx* ctx, const mavlm_buffers* b);
+
+/* --- per-video protocol ------------------------------------------------------------------------------ */
+/* replaces `recurrent_model.memory_cache = []` (llava_arch.py:532) */
+int mavlm_reset(mavlm_ctx* ctx);
+/* number of valid cache entries = min(steps, cache_cap); slot of the newest entry; steps since reset */
+int mavlm_cache_len(const mavlm_ctx* ctx);
+int mavlm_newest_slot(const mavlm_ctx* ctx);
+int mavlm_steps(const mavlm_ctx* ctx);
+
+/* replaces TemporalPositionalEncoding.forward (position_encoding.py:38-69): out[t] = x[t] + table[idx[t]].
+ * Index range checking (ValueError, :73-76) is done by the host wrapper on the host copy of idx. */
+int mavlm_pe_add(const void* x, const int64_t* idx, const void* table, void* out, int32_t T, int32_t P, int32_t D,
+                 int32_t dtype, void* stream);
+
+/* replaces TransformerProjector.forward (MemoryController.py:118-158) for one chunk seg[F,P,D]:
+ * memory evolution over the FIFO (t>0, :89-115), L formation layers (:59-72,132-133), append to the ring.
+ * frame_scores: null, or [F] (fp32 if scores_f32 else 16-bit) = probs.sum(heads).sum(queries).view(F,P).mean(1)
+ * of the last layer (:135-139). */
+int mavlm_step(mavlm_ctx* ctx, const void* seg, int32_t F, void* frame_scores, int32_t scores_f32, void* stream);
+
+/* replaces memory_fuser(cat(memory_cache)) + token_type add + fine-frame gather/add + prompt/newline concat
+ * (llava_arch.py:513-524,545-554,620-629,708-731).  Writes
+ *   out = [mem_prompt(10) ; fused memory (n*M*P rows, oldest first) ; newline ; frame_prompt(9) ; fine (n_fine*P) ; newline]
+ * x_pe: [T,P,D] PE-added frames; fine_idx: [n_fine] int64 frame indices into x_pe.  Returns rows written via *rows (host). */
+int mavlm_fuse_emit(mavlm_ctx* ctx, const void* x_pe, const int64_t* fine_idx, int32_t n_fine, const void* mem_prompt,
+                    int32_t n_mem_prompt, const void* frame_prompt, int32_t n_frame_prompt, const void* newline,
+                    int32_t with_frames, void* out, int64_t out_capacity_rows, int64_t* rows, void* stream);
+
+/* --- operator-level entry points (used by the parity tests; same kernels the step uses) --------------- */
+/* C = epi(A[M,K] . W[N,K]^T + bias); epilogue: 0 bias, 1 bias+ReLU, 2 bias+GELU(erf),
+ * 3 bias+residual -> fp32 C.   nn.Linear call sites: MemoryController.py:23,37-39,63-67; llava_arch.py:132-136 */
+int mavlm_linear(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const void* res, int32_t ldr,
+                 void* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t dtype, void* stream);
+/* ctx[R,H*128] = softmax(Q K^T / sqrt(128)) V per head; lse2 [H,R] fp32 optional.  MemoryController.py:51-54 */
+int mavlm_attention(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
+                    int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream);
+/* part[H,S] fp32 = column sums over queries of the normalised probabilities.  MemoryController.py:135 */
+int mavlm_attention_colsum(const void* Q, int32_t ldq, const void* K, int32_t ldk, const float* lse2, float* part,
+                           int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream);
+/* out = LayerNorm(x fp32 [rows,D]) * gamma + beta -> 16-bit.  MemoryController.py:24,28 */
+int mavlm_layernorm(const float* x, const float* gamma, const float* beta, void* out, int32_t rows, int32_t D, float eps,
+                    int32_t dtype, void* stream);
+/* out[t,p,:] = x[src[t],p,:] + table[idx[t],:] (src/idx may be null).  position_encoding.py:64; llava_arch.py:524,554 */
+int mavlm_row_add(const void* x, const int64_t* src, const void* table, const int64_t* idx, void* out, int32_t T,
+                  int32_t P, int32_t D, int32_t dtype, void* stream);
+
+/* --- measurement hooks (bench.py only; new - the reference has no profiling) ------------- */
+/* When enabled, every kernel launch is bracketed by HIP events on its own stream.  Kinds: 0 GEMM, 1 attention
+ * forward, 2 attention column-sum, 3 LayerNorm, 4 row-add, 5 misc.  Not re-entrant, not graph-capturable. */
+int mavlm_prof_enable(int32_t on);
+/* host arrays of length nkinds >= 6: total milliseconds, launches, algorithmic flops, algorithmic bytes per kind */
+int mavlm_prof_read(double* ms, int64_t* launches, double* flops, double* bytes, int32_t nkinds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAVLM_H_ */

@@ -1,0 +1,114 @@
+"""Operator-level wrappers over the C ABI (device pointers + current HIP stream).  PyTorch is used only to
+own device memory and the stream.  Every function raises if the tensors are not on a GPU: there is no CPU path."""
+import math
+
+import torch
+
+from . import _capi as capi
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.bfloat16:
+        return capi.BF16
+    if dt == torch.float16:
+        return capi.F16
+    raise capi.MavlmError(f"dtype {dt} is not supported by the gfx950 kernels (bf16 / fp16 only); "
+                          "the reference runs this path in the model dtype (bf16 in training, fp16/bf16 in eval)")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise capi.MavlmError("tensor is not on a GPU: the memory path has no CPU fallback")
+
+
+def _rows(x):
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise capi.MavlmError("expected a 2-D tensor with unit inner stride")
+    return x.shape[0], x.shape[1], x.stride(0)
+
+
+def linear(x, weight, bias_f32, epilogue=capi.EPI_BIAS, residual=None, out=None):
+    """out = epi(x @ weight.T + bias).  x [M,K], weight [N,K] (nn.Linear layout) 16-bit; bias fp32 [N].
+    epilogue EPI_RES_F32 adds ``residual`` [M,N] and returns fp32."""
+    _need_gpu(x, weight, bias_f32, residual, out)
+    M, K, lda = _rows(x)
+    N, K2, ldw = _rows(weight)
+    if K2 != K or weight.dtype != x.dtype or bias_f32.dtype != torch.float32 or bias_f32.numel() != N:
+        raise capi.MavlmError("linear: operand mismatch")
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32 if epilogue == capi.EPI_RES_F32 else x.dtype)
+    _, _, ldc = _rows(out)
+    rp, ldr = (0, 0)
+    if epilogue == capi.EPI_RES_F32:
+        if residual is None or residual.dtype != x.dtype:
+            raise capi.MavlmError("linear: residual required")
+        _, _, ldr = _rows(residual)
+        rp = residual.data_ptr()
+    capi.check(capi.lib().mavlm_linear(x.data_ptr(), lda, weight.data_ptr(), ldw, bias_f32.data_ptr(), rp, ldr,
+                                       out.data_ptr(), ldc, M, N, K, epilogue, dtype_code(x.dtype), stream_ptr()),
+               "mavlm_linear")
+    return out
+
+
+def attention(q, k, v, heads, want_lse=False, out=None):
+    """ctx = softmax(q k^T / sqrt(128)) v per head (head_dim 128).  q [R,>=H*128], k/v [S,...] may be column
+    slices of wider buffers.  Returns (ctx [R,H*128], lse2 [H,R] fp32 | None)."""
+    _need_gpu(q, k, v)
+    R, _, ldq = _rows(q)
+    S, _, ldk = _rows(k)
+    S2, _, ldv = _rows(v)
+    if S2 != S or q.shape[1] < heads * 128 or k.shape[1] < heads * 128 or v.shape[1] < heads * 128:
+        raise capi.MavlmError("attention: operand mismatch (head_dim must be 128)")
+    if out is None:
+        out = torch.empty((R, heads * 128), device=q.device, dtype=q.dtype)
+    lse = torch.empty((heads, R), device=q.device, dtype=torch.float32) if want_lse else None
+    capi.check(capi.lib().mavlm_attention(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(),
+                                          out.stride(0), lse.data_ptr() if want_lse else 0, R, S, heads,
+                                          1.0 / math.sqrt(128.0), dtype_code(q.dtype), stream_ptr()), "mavlm_attention")
+    return out, lse
+
+
+def attention_colsum(q, k, lse2, heads):
+    """part[h,s] = sum_q softmax probability of key s for head h (fp32)."""
+    _need_gpu(q, k, lse2)
+    R, _, ldq = _rows(q)
+    S, _, ldk = _rows(k)
+    part = torch.empty((heads, S), device=q.device, dtype=torch.float32)
+    capi.check(capi.lib().mavlm_attention_colsum(q.data_ptr(), ldq, k.data_ptr(), ldk, lse2.data_ptr(), part.data_ptr(),
+                                                 R, S, heads, 1.0 / math.sqrt(128.0), dtype_code(q.dtype), stream_ptr()),
+               "mavlm_attention_colsum")
+    return part
+
+
+def layernorm(x_f32, gamma_f32, beta_f32, eps, out_dtype, out=None):
+    _need_gpu(x_f32, gamma_f32, beta_f32)
+    if x_f32.dtype != torch.float32 or not x_f32.is_contiguous():
+        raise capi.MavlmError("layernorm: fp32 contiguous input expected")
+    rows, D = x_f32.shape
+    if out is None:
+        out = torch.empty((rows, D), device=x_f32.device, dtype=out_dtype)
+    capi.check(capi.lib().mavlm_layernorm(x_f32.data_ptr(), gamma_f32.data_ptr(), beta_f32.data_ptr(), out.data_ptr(),
+                                          rows, D, float(eps), dtype_code(out_dtype), stream_ptr()), "mavlm_layernorm")
+    return out
+
+
+def row_add(x, table, idx=None, src=None, out=None):
+    """out[t,p,:] = x[src[t],p,:] + table[idx[t],:]  (x [T0,P,D]; idx/src int64 device tensors or None)."""
+    _need_gpu(x, table, idx, src, out)
+    if x.dim() != 3 or not x.is_contiguous() or not table.is_contiguous() or table.dtype != x.dtype:
+        raise capi.MavlmError("row_add: operand mismatch")
+    T = x.shape[0] if src is None else src.numel()
+    if idx is not None and idx.numel() != T:
+        raise capi.MavlmError("row_add: index length mismatch")
+    P, D = x.shape[1], x.shape[2]
+    if out is None:
+        out = torch.empty((T, P, D), device=x.device, dtype=x.dtype)
+    capi.check(capi.lib().mavlm_row_add(x.data_ptr(), src.data_ptr() if src is not None else 0, table.data_ptr(),
+                                        idx.data_ptr() if idx is not None else 0, out.data_ptr(), T, P, D,
+                                        dtype_code(x.dtype), stream_ptr()), "mavlm_row_add")
+    return out

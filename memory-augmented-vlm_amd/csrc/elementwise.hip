@@ -1,0 +1,130 @@
+// Row-wise kernels of the memory path (HBM-bound; 16-byte vector accesses, wave-level reductions).
+//
+//   layernorm_kernel  Residual's LayerNorm (llava/model/memory_module/MemoryController.py:24,28): fp32 row in
+//                     (dense + bias + residual, written by the GEMM epilogue), 16-bit row out.
+//   row_add_kernel    out[t,p,:] = x[src[t],p,:] + table[idx[t],:]  - temporal positional-encoding add
+//                     (position_encoding.py:58,64), fine-frame gather + token-type add (llava_arch.py:513-524,554).
+#include "mavlm_common.h"
+#include "mavlm_kernels.h"
+
+namespace {
+
+// one wave per row, NV float4 per lane (D <= 256*NV)
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, uint16_t* __restrict__ out,
+                                                        int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nvec = D >> 2;
+  const f32x4* xr = (const f32x4*)(x + (size_t)row * D);
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = i * 64 + lane;
+    if (j < nvec) {
+      v[i] = xr[j];
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    } else {
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = i * 64 + lane;
+    if (j < nvec) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        ss += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+  uint16_t* orow = out + (size_t)row * D;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = i * 64 + lane;
+    if (j < nvec) {
+      const f32x4 g = ((const f32x4*)gamma)[j];
+      const f32x4 b = ((const f32x4*)beta)[j];
+      *(u32x2*)(orow + 4 * j) = pack4<T>((v[i][0] - mean) * rstd * g[0] + b[0], (v[i][1] - mean) * rstd * g[1] + b[1],
+                                         (v[i][2] - mean) * rstd * g[2] + b[2], (v[i][3] - mean) * rstd * g[3] + b[3]);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void row_add_kernel(const uint16_t* __restrict__ x, const int64_t* __restrict__ src,
+                                                      const uint16_t* __restrict__ table,
+                                                      const int64_t* __restrict__ idx, uint16_t* __restrict__ out,
+                                                      int T_, int P, int D) {
+  // one thread = 8 elements; grid-stride over T*P*D/8 vectors
+  const int dv = D >> 3;
+  const size_t total = (size_t)T_ * P * dv;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % dv);
+    const size_t rowi = i / dv;
+    const int t = (int)(rowi / P);
+    const int p = (int)(rowi % P);
+    const int64_t st = src ? src[t] : t;
+    const int64_t it = idx ? idx[t] : 0;
+    const u16x8 a = *(const u16x8*)(x + ((size_t)st * P + p) * D + 8 * c);
+    const u16x8 b = *(const u16x8*)(table + (size_t)it * D + 8 * c);
+    u16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = T::from_f32(T::to_f32(a[e]) + T::to_f32(b[e]));
+    *(u16x8*)(out + rowi * D + 8 * c) = o;
+  }
+}
+
+template <typename T, int NV>
+void ln_launch(const float* x, const float* g, const float* b, void* out, int rows, int D, float eps, hipStream_t s) {
+  hipLaunchKernelGGL((layernorm_kernel<T, NV>), dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, (uint16_t*)out, rows, D,
+                     eps);
+}
+
+template <typename T>
+hipError_t ln_dispatch(const float* x, const float* g, const float* b, void* out, int rows, int D, float eps,
+                       hipStream_t s) {
+  const int nv = (D / 4 + 63) / 64;
+  if (nv <= 1) ln_launch<T, 1>(x, g, b, out, rows, D, eps, s);
+  else if (nv <= 2) ln_launch<T, 2>(x, g, b, out, rows, D, eps, s);
+  else if (nv <= 4) ln_launch<T, 4>(x, g, b, out, rows, D, eps, s);
+  else if (nv <= 8) ln_launch<T, 8>(x, g, b, out, rows, D, eps, s);
+  else if (nv <= 16) ln_launch<T, 16>(x, g, b, out, rows, D, eps, s);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t mavlm_launch_layernorm(const float* x, const float* gamma, const float* beta, void* out, int rows, int D,
+                                  float eps, int dtype, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (!x || !gamma || !beta || !out || D <= 0 || (D & 3)) return hipErrorInvalidValue;
+  mavlm_prof_scope prof(MAVLM_K_LN, 0.0, 6.0 * rows * (double)D, s);
+  return dtype == MAVLM_F16 ? ln_dispatch<F16>(x, gamma, beta, out, rows, D, eps, s)
+                            : ln_dispatch<BF16>(x, gamma, beta, out, rows, D, eps, s);
+}
+
+hipError_t mavlm_launch_row_add(const void* x, const int64_t* src, const void* table, const int64_t* idx, void* out,
+                                int T_, int P, int D, int dtype, hipStream_t s) {
+  if (T_ <= 0) return hipSuccess;
+  if (!x || !table || !out || P <= 0 || D <= 0 || (D & 7)) return hipErrorInvalidValue;
+  const size_t total = (size_t)T_ * P * (D >> 3);
+  mavlm_prof_scope prof(MAVLM_K_ROWADD, 0.0, 4.0 * T_ * (double)P * D, s);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == MAVLM_F16)
+    hipLaunchKernelGGL(row_add_kernel<F16>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)x, src,
+                       (const uint16_t*)table, idx, (uint16_t*)out, T_, P, D);
+  else
+    hipLaunchKernelGGL(row_add_kernel<BF16>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)x, src,
+                       (const uint16_t*)table, idx, (uint16_t*)out, T_, P, D);
+  return hipGetLastError();
+}

@@ -1,0 +1,177 @@
+// C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias)  -- nn.Linear layout (weight [out,in]), bf16/fp16 operands,
+// fp32 accumulation on the gfx950 matrix cores (v_mfma_f32_16x16x32_{bf16,f16}).
+//
+// Replaces the ATen addmm call sites of the reference memory path (nn.Linear q/k/v/dense/mlp/fuser:
+// llava/model/memory_module/MemoryController.py:23,37-39,48-50,63-67; llava/model/llava_arch.py:132-136).
+//
+// Structure (v1): 128x128x64 block tile, 4 waves (2x2) each owning a 64x64 sub-tile = 4x4 MFMA tiles,
+// operands staged HBM -> LDS with 16-byte global_load_lds into an XOR-swizzled image (the swizzle is applied
+// to the per-lane SOURCE address, the LDS destination stays lane-linear), two LDS stages, one barrier per
+// K-tile.  The MFMA is issued as D' = W_tile . A_tile^T so every lane ends up with 4 CONSECUTIVE output
+// columns of one row -> 8-byte (16-bit out) / 16-byte (fp32 out) epilogue stores.
+//
+// Ragged M is allowed (row loads are clamped to M-1, stores masked); N % 128 == 0 and K % 64 == 0 required
+// (checked on the host in mavlm_api.hip).
+#include "mavlm_common.h"
+#include "mavlm_kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A then B
+constexpr int GEMM_LDS = 2 * STAGE_BYTES;      // 64 KiB
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
+                                                         const uint16_t* __restrict__ W, int ldw,
+                                                         const float* __restrict__ bias,
+                                                         const uint16_t* __restrict__ res, int ldr,
+                                                         void* __restrict__ Cout, int ldc, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int ntn = N / BN;
+  const int ntm = (M + BM - 1) / BM;
+  const int wg = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (wg / ntn) * BM;
+  const int n0 = (wg % ntn) * BN;
+
+  // ---- staging: wave w issues instructions inst = 4w..4w+3 per operand; one instruction = 8 rows x 128 B.
+  const int srow = lane >> 3;                 // row inside the 8-row group
+  const int sp = lane & 7;                    // physical 16-B chunk in the row
+  const uint16_t* gA[4];
+  const uint16_t* gB[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 8 + srow;
+    const int c = sp ^ ((row >> 1) & 7);      // logical chunk that lives at physical chunk sp
+    int ar = m0 + row;
+    ar = ar < M ? ar : M - 1;
+    gA[j] = A + (size_t)ar * lda + c * 8;
+    gB[j] = W + (size_t)(n0 + row) * ldw + c * 8;
+  }
+
+  // ---- fragment read offsets (bytes inside an operand tile)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = (lane >> 1) & 7;             // ((row>>1)&7) for row = 16*i + fr
+  const int offA = (wm * 64 + fr) * 128;
+  const int offB = (wn * 64 + fr) * 128;
+  const int ck0 = ((fq ^ sw) << 4);           // k-step 0 : chunk fq
+  const int ck1 = (((4 + fq) ^ sw) << 4);     // k-step 1 : chunk 4+fq
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int buf, int kt) {
+    char* sA = smem + buf * STAGE_BYTES + wave * 4096;
+    char* sB = sA + TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)(gA[j] + kt * BK), (MAVLM_LDS void*)(sA + j * 1024), 16,
+                                       0, 0);
+      __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)(gB[j] + kt * BK), (MAVLM_LDS void*)(sB + j * 1024), 16,
+                                       0, 0);
+    }
+  };
+
+  const int nk = K / BK;
+  stage(0, 0);
+  __syncthreads();   // drains vmcnt(0): tile 0 resident
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* sA = smem + cur * STAGE_BYTES;
+    const char* sB = sA + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ck = ks ? ck1 : ck0;
+      typename T::vec8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = *(const typename T::vec8*)(sA + offA + i * 2048 + ck);
+        b[i] = *(const typename T::vec8*)(sB + offB + i * 2048 + ck);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma16(b[j], a[i], acc[i][j]);   // D'[n][m]
+    }
+    __syncthreads();   // next tile landed (vmcnt(0)) and everyone is done reading buf[cur]
+  }
+
+  // ---- epilogue: lane holds C[m][n..n+3], m = m0+wm*64+16i+fr, n = n0+wn*64+16j+4fq
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fq * 4;
+      const f32x4 bv = *(const f32x4*)(bias + n);
+      float v0 = acc[i][j][0] + bv[0], v1 = acc[i][j][1] + bv[1], v2 = acc[i][j][2] + bv[2],
+            v3 = acc[i][j][3] + bv[3];
+      if (EPI == MAVLM_EPI_RELU) {
+        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+      } else if (EPI == MAVLM_EPI_GELU) {
+        v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+      }
+      if (EPI == MAVLM_EPI_RES_F32) {
+        const u16x4 rv = *(const u16x4*)(res + (size_t)m * ldr + n);
+        f32x4 o;
+        o[0] = v0 + T::to_f32(rv[0]); o[1] = v1 + T::to_f32(rv[1]);
+        o[2] = v2 + T::to_f32(rv[2]); o[3] = v3 + T::to_f32(rv[3]);
+        *(f32x4*)((float*)Cout + (size_t)m * ldc + n) = o;
+      } else {
+        *(u32x2*)((uint16_t*)Cout + (size_t)m * ldc + n) = pack4<T>(v0, v1, v2, v3);
+      }
+    }
+  }
+}
+
+template <typename T, int EPI>
+hipError_t launch(const mavlm_gemm_args& g, hipStream_t s) {
+  auto kern = gemm_tn_kernel<T, EPI>;
+  static bool attr_done = false;   // per instantiation
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int ntm = (g.M + BM - 1) / BM, ntn = g.N / BN;
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(256), GEMM_LDS, s, (const uint16_t*)g.A, g.lda, (const uint16_t*)g.W,
+                     g.ldw, g.bias, (const uint16_t*)g.res, g.ldr, g.C, g.ldc, g.M, g.N, g.K);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_epi(const mavlm_gemm_args& g, hipStream_t s) {
+  switch (g.epilogue) {
+    case MAVLM_EPI_BIAS: return launch<T, MAVLM_EPI_BIAS>(g, s);
+    case MAVLM_EPI_RELU: return launch<T, MAVLM_EPI_RELU>(g, s);
+    case MAVLM_EPI_GELU: return launch<T, MAVLM_EPI_GELU>(g, s);
+    case MAVLM_EPI_RES_F32: return launch<T, MAVLM_EPI_RES_F32>(g, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s) {
+  if (g.M <= 0) return hipSuccess;
+  if (g.N % BN != 0 || g.K % BK != 0 || g.K <= 0 || (g.lda & 7) || (g.ldw & 7) || (g.ldc & 3)) return hipErrorInvalidValue;
+  if (g.epilogue == MAVLM_EPI_RES_F32 && (g.res == nullptr || (g.ldr & 3))) return hipErrorInvalidValue;
+  const double osz = g.epilogue == MAVLM_EPI_RES_F32 ? 6.0 : 2.0;   // fp32 out + 16-bit residual in
+  mavlm_prof_scope prof(MAVLM_K_GEMM, 2.0 * g.M * (double)g.N * g.K,
+                        2.0 * ((double)g.M * g.K + (double)g.N * g.K) + osz * g.M * (double)g.N, s);
+  return dtype == MAVLM_F16 ? launch_epi<F16>(g, s) : launch_epi<BF16>(g, s);
+}

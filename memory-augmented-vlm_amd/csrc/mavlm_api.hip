@@ -1,0 +1,306 @@
+// C-ABI layer (include/mavlm.h): host-side handle, workspace carving and the per-chunk launch sequence.
+// No allocation, no synchronisation: every entry point only enqueues kernels on the caller's stream.
+#include "../../include/mavlm.h"
+
+#include <new>
+
+#include "mavlm_kernels.h"
+
+struct mavlm_ctx {
+  mavlm_config cfg;
+  mavlm_weights w;
+  mavlm_buffers b;
+  bool has_w = false, has_b = false;
+  int steps = 0;
+  // workspace carve (byte offsets)
+  size_t o_kv, o_q, o_ctx, o_a, o_h, o_pre, o_mA, o_mB, o_lse, o_part, total;
+};
+
+namespace {
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+bool cfg_ok(const mavlm_config* c) {
+  if (!c) return false;
+  if (c->hidden <= 0 || c->heads <= 0 || c->patches <= 0 || c->mem_tokens <= 0 || c->depth <= 0 ||
+      c->depth > MAVLM_MAX_DEPTH || c->inter <= 0 || c->cache_cap <= 0 || c->max_chunk_frames <= 0)
+    return false;
+  if (c->dtype != 0 && c->dtype != 1) return false;
+  return true;
+}
+
+// shapes the gfx950 kernels implement (DESIGN.md "Supported shapes")
+bool shape_ok(const mavlm_config* c) {
+  return c->hidden % 128 == 0 && c->hidden == c->heads * 128 && c->inter % 128 == 0;
+}
+
+void carve(mavlm_ctx* x) {
+  const mavlm_config& c = x->cfg;
+  const size_t R = (size_t)c.mem_tokens * c.patches, S = (size_t)c.max_chunk_frames * c.patches, D = c.hidden,
+               I = c.inter, L = c.depth, H = c.heads;
+  size_t o = 0;
+  x->o_kv = o;   o += al(S * 2 * L * D * 2);
+  x->o_q = o;    o += al(R * D * 2);
+  x->o_ctx = o;  o += al(R * D * 2);
+  x->o_a = o;    o += al(R * D * 2);
+  x->o_h = o;    o += al(R * I * 2);
+  x->o_pre = o;  o += al(R * D * 4);
+  x->o_mA = o;   o += al(R * D * 2);
+  x->o_mB = o;   o += al(R * D * 2);
+  x->o_lse = o;  o += al(H * R * 4);
+  x->o_part = o; o += al(H * S * 4);
+  x->total = o;
+}
+
+inline char* ws(mavlm_ctx* x, size_t off) { return (char*)x->b.workspace + off; }
+
+#define MAVLM_TRY(expr)                       \
+  do {                                        \
+    hipError_t _e = (expr);                   \
+    if (_e != hipSuccess) return (int)_e;     \
+  } while (0)
+
+hipError_t gemm(int dtype, hipStream_t s, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+                int M, int N, int K, int epi, const void* res = nullptr, int ldr = 0) {
+  mavlm_gemm_args g;
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.res = res; g.ldr = ldr; g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K; g.epilogue = epi;
+  return mavlm_launch_gemm(g, dtype, s);
+}
+
+// One `Attention` block given projected K/V:  out = LN(dense(attn(q_proj(xq), K, V)) + xq)
+int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const void* xq, const void* K, int ldk,
+               const void* V, int ldv, int S, void* out, float* lse2) {
+  const mavlm_config& c = x->cfg;
+  const int R = c.mem_tokens * c.patches, D = c.hidden, H = c.heads, dt = c.dtype;
+  MAVLM_TRY(gemm(dt, s, xq, D, aw.wq, D, aw.bq, ws(x, x->o_q), D, R, D, D, MAVLM_EPI_BIAS));
+  mavlm_attn_args a;
+  a.Q = ws(x, x->o_q); a.ldq = D; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = ws(x, x->o_ctx); a.ldo = D;
+  a.lse2 = lse2; a.R = R; a.S = S; a.H = H; a.scale = 0.08838834764831845f;   // 1/sqrt(128)
+  MAVLM_TRY(mavlm_launch_attention(a, dt, s));
+  MAVLM_TRY(gemm(dt, s, ws(x, x->o_ctx), D, aw.wo, D, aw.bo, ws(x, x->o_pre), D, R, D, D, MAVLM_EPI_RES_F32, xq, D));
+  MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), aw.ln_g, aw.ln_b, out, R, D, c.eps, dt, s));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mavlm_abi_version(void) { return MAVLM_ABI_VERSION; }
+
+size_t mavlm_workspace_bytes(const mavlm_config* cfg) {
+  if (!cfg_ok(cfg)) return 0;
+  mavlm_ctx t;
+  t.cfg = *cfg;
+  carve(&t);
+  return t.total;
+}
+
+int mavlm_workspace_layout(const mavlm_config* cfg, size_t* offsets, int32_t n) {
+  if (!cfg_ok(cfg) || !offsets || n < 10) return MAVLM_E_ARG;
+  mavlm_ctx t;
+  t.cfg = *cfg;
+  carve(&t);
+  const size_t o[10] = {t.o_kv, t.o_q, t.o_ctx, t.o_a, t.o_h, t.o_pre, t.o_mA, t.o_mB, t.o_lse, t.o_part};
+  for (int i = 0; i < 10; ++i) offsets[i] = o[i];
+  return 0;
+}
+
+int mavlm_create(const mavlm_config* cfg, mavlm_ctx** out) {
+  if (!out || !cfg_ok(cfg)) return MAVLM_E_ARG;
+  if (!shape_ok(cfg)) return MAVLM_E_SHAPE;
+  mavlm_ctx* x = new (std::nothrow) mavlm_ctx();
+  if (!x) return MAVLM_E_ARG;
+  x->cfg = *cfg;
+  carve(x);
+  *out = x;
+  return 0;
+}
+
+void mavlm_destroy(mavlm_ctx* ctx) { delete ctx; }
+
+int mavlm_bind_weights(mavlm_ctx* x, const mavlm_weights* w) {
+  if (!x || !w) return MAVLM_E_ARG;
+  if (!w->mem0 || !w->w_kv_seg || !w->b_kv_seg || !w->w_kv_evo || !w->b_kv_evo) return MAVLM_E_ARG;
+  // the fuser / token-type weights live outside TransformerProjector (llava_arch.py:132-150): optional here,
+  // required by mavlm_fuse_emit
+  const mavlm_attn_weights* e = &w->evo;
+  if (!e->wq || !e->bq || !e->wo || !e->bo || !e->ln_g || !e->ln_b) return MAVLM_E_ARG;
+  for (int l = 0; l < x->cfg.depth; ++l) {
+    const mavlm_attn_weights* a = &w->layer_attn[l];
+    if (!a->wq || !a->bq || !a->wo || !a->bo || !a->ln_g || !a->ln_b || !w->w_up[l] || !w->b_up[l] || !w->w_down[l] ||
+        !w->b_down[l] || !w->ln2_g[l] || !w->ln2_b[l])
+      return MAVLM_E_ARG;
+  }
+  x->w = *w;
+  x->has_w = true;
+  return 0;
+}
+
+int mavlm_bind_buffers(mavlm_ctx* x, const mavlm_buffers* b) {
+  if (!x || !b || !b->mem_ring || !b->evo_kv_ring || !b->workspace) return MAVLM_E_ARG;
+  if (b->workspace_bytes < x->total || ((uintptr_t)b->workspace & 255)) return MAVLM_E_ARG;
+  x->b = *b;
+  x->has_b = true;
+  return 0;
+}
+
+int mavlm_reset(mavlm_ctx* x) {
+  if (!x) return MAVLM_E_ARG;
+  x->steps = 0;
+  return 0;
+}
+
+int mavlm_cache_len(const mavlm_ctx* x) { return x ? (x->steps < x->cfg.cache_cap ? x->steps : x->cfg.cache_cap) : MAVLM_E_ARG; }
+int mavlm_newest_slot(const mavlm_ctx* x) { return x ? (x->steps ? (x->steps - 1) % x->cfg.cache_cap : -1) : MAVLM_E_ARG; }
+int mavlm_steps(const mavlm_ctx* x) { return x ? x->steps : MAVLM_E_ARG; }
+
+int mavlm_pe_add(const void* xin, const int64_t* idx, const void* table, void* out, int32_t T, int32_t P, int32_t D,
+                 int32_t dtype, void* stream) {
+  if (!xin || !idx || !table || !out || T < 0) return MAVLM_E_ARG;
+  return (int)mavlm_launch_row_add(xin, nullptr, table, idx, out, T, P, D, dtype, (hipStream_t)stream);
+}
+
+int mavlm_step(mavlm_ctx* x, const void* seg, int32_t F, void* frame_scores, int32_t scores_f32, void* stream) {
+  if (!x || !seg) return MAVLM_E_ARG;
+  if (!x->has_w || !x->has_b) return MAVLM_E_STATE;
+  const mavlm_config& c = x->cfg;
+  if (F <= 0 || F > c.max_chunk_frames) return MAVLM_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int R = c.mem_tokens * c.patches, D = c.hidden, I = c.inter, L = c.depth, H = c.heads, dt = c.dtype;
+  const int S = F * c.patches;
+  const size_t mem_bytes = (size_t)R * D * 2, kv_bytes = (size_t)R * 2 * D * 2;
+  const int cap = c.cache_cap;
+  const int n = x->steps < cap ? x->steps : cap;
+
+  const void* cur = x->w.mem0;
+  if (x->steps > 0) {
+    // ---- memory evolution (MemoryController.py:89-97): q = newest memory, kv = every cached memory.
+    const int newest = (x->steps - 1) % cap;
+    const char* mem_new = (const char*)x->b.mem_ring + (size_t)newest * mem_bytes;
+    char* kv_new = (char*)x->b.evo_kv_ring + (size_t)newest * kv_bytes;
+    // K/V of a cached memory are row-independent -> project each memory once, when it becomes the newest
+    MAVLM_TRY(gemm(dt, s, mem_new, D, x->w.w_kv_evo, D, x->w.b_kv_evo, kv_new, 2 * D, R, 2 * D, D, MAVLM_EPI_BIAS));
+    const char* kv = (const char*)x->b.evo_kv_ring;
+    int rc = attn_block(x, s, x->w.evo, mem_new, kv, 2 * D, kv + (size_t)D * 2, 2 * D, n * R, ws(x, x->o_mA), nullptr);
+    if (rc) return rc;
+    cur = ws(x, x->o_mA);
+  }
+
+  // ---- memory formation (MemoryController.py:132-133): K/V of the chunk for all L layers in one GEMM
+  char* kvs = ws(x, x->o_kv);
+  const int ldkv = 2 * L * D;
+  MAVLM_TRY(gemm(dt, s, seg, D, x->w.w_kv_seg, D, x->w.b_kv_seg, kvs, ldkv, S, ldkv, D, MAVLM_EPI_BIAS));
+  for (int l = 0; l < L; ++l) {
+    const bool last = l == L - 1;
+    const bool want_scores = last && frame_scores != nullptr;
+    const char* Kl = kvs + (size_t)(2 * l) * D * 2;
+    const char* Vl = Kl + (size_t)D * 2;
+    float* lse = want_scores ? (float*)ws(x, x->o_lse) : nullptr;
+    int rc = attn_block(x, s, x->w.layer_attn[l], cur, Kl, ldkv, Vl, ldkv, S, ws(x, x->o_a), lse);
+    if (rc) return rc;
+    if (want_scores) {
+      mavlm_colsum_args ca;
+      ca.Q = ws(x, x->o_q); ca.ldq = D; ca.K = Kl; ca.ldk = ldkv; ca.lse2 = lse; ca.part = (float*)ws(x, x->o_part);
+      ca.R = R; ca.S = S; ca.H = H; ca.scale = 0.08838834764831845f;
+      MAVLM_TRY(mavlm_launch_colsum(ca, dt, s));
+      MAVLM_TRY(mavlm_launch_frame_scores(ca.part, H, S, F, c.patches, frame_scores, scores_f32, dt, s));
+    }
+    // MLP: Linear(D,I)+ReLU -> Residual(I->D)  (MemoryController.py:63-67,71)
+    MAVLM_TRY(gemm(dt, s, ws(x, x->o_a), D, x->w.w_up[l], D, x->w.b_up[l], ws(x, x->o_h), I, R, I, D, MAVLM_EPI_RELU));
+    MAVLM_TRY(gemm(dt, s, ws(x, x->o_h), I, x->w.w_down[l], I, x->w.b_down[l], ws(x, x->o_pre), D, R, D, I,
+                   MAVLM_EPI_RES_F32, ws(x, x->o_a), D));
+    void* dst = last ? (void*)((char*)x->b.mem_ring + (size_t)(x->steps % cap) * mem_bytes)
+                     : (void*)ws(x, (l & 1) ? x->o_mA : x->o_mB);
+    MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), x->w.ln2_g[l], x->w.ln2_b[l], dst, R, D, c.eps, dt, s));
+    cur = dst;
+  }
+  x->steps += 1;   // append; the slot written above evicts the oldest entry once the ring is full (:152-154)
+  return 0;
+}
+
+int mavlm_fuse_emit(mavlm_ctx* x, const void* x_pe, const int64_t* fine_idx, int32_t n_fine, const void* mem_prompt,
+                    int32_t n_mem_prompt, const void* frame_prompt, int32_t n_frame_prompt, const void* newline,
+                    int32_t with_frames, void* out, int64_t cap_rows, int64_t* rows, void* stream) {
+  if (!x || !out || !newline || !rows) return MAVLM_E_ARG;
+  if (!x->has_w || !x->has_b) return MAVLM_E_STATE;
+  if (!x->w.w_f1 || !x->w.b_f1 || !x->w.w_f2 || !x->w.b_f2_type0 || (with_frames && !x->w.type1)) return MAVLM_E_STATE;
+  if (n_mem_prompt < 0 || n_frame_prompt < 0 || n_fine < 0 || (n_mem_prompt && !mem_prompt) ||
+      (with_frames && ((n_frame_prompt && !frame_prompt) || (n_fine && (!x_pe || !fine_idx)))))
+    return MAVLM_E_ARG;
+  const mavlm_config& c = x->cfg;
+  hipStream_t s = (hipStream_t)stream;
+  const int R = c.mem_tokens * c.patches, D = c.hidden, I = c.inter, dt = c.dtype, cap = c.cache_cap;
+  const int n = x->steps < cap ? x->steps : cap;
+  if (n == 0) return MAVLM_E_STATE;
+  int64_t need = (int64_t)n_mem_prompt + (int64_t)n * R + 1;
+  if (with_frames) need += (int64_t)n_frame_prompt + (int64_t)n_fine * c.patches + 1;
+  if (cap_rows < need) return MAVLM_E_ARG;
+  const size_t rowb = (size_t)D * 2;
+  char* o = (char*)out;
+  int64_t row = 0;
+  if (n_mem_prompt) MAVLM_TRY(hipMemcpyAsync(o, mem_prompt, rowb * n_mem_prompt, hipMemcpyDeviceToDevice, s));
+  row += n_mem_prompt;
+  const int oldest = x->steps <= cap ? 0 : x->steps % cap;
+  for (int i = 0; i < n; ++i) {   // torch.cat(memory_cache) order = oldest first (llava_arch.py:545)
+    const int slot = (oldest + i) % cap;
+    const char* mem = (const char*)x->b.mem_ring + (size_t)slot * R * rowb;
+    MAVLM_TRY(gemm(dt, s, mem, D, x->w.w_f1, D, x->w.b_f1, ws(x, x->o_h), I, R, I, D, MAVLM_EPI_GELU));
+    MAVLM_TRY(gemm(dt, s, ws(x, x->o_h), I, x->w.w_f2, I, x->w.b_f2_type0, o + (size_t)row * rowb, D, R, D, I,
+                   MAVLM_EPI_BIAS));
+    row += R;
+  }
+  MAVLM_TRY(hipMemcpyAsync(o + (size_t)row * rowb, newline, rowb, hipMemcpyDeviceToDevice, s));
+  row += 1;
+  if (with_frames) {
+    if (n_frame_prompt)
+      MAVLM_TRY(hipMemcpyAsync(o + (size_t)row * rowb, frame_prompt, rowb * n_frame_prompt, hipMemcpyDeviceToDevice, s));
+    row += n_frame_prompt;
+    MAVLM_TRY(mavlm_launch_row_add(x_pe, fine_idx, x->w.type1, nullptr, o + (size_t)row * rowb, n_fine, c.patches, D, dt, s));
+    row += (int64_t)n_fine * c.patches;
+    MAVLM_TRY(hipMemcpyAsync(o + (size_t)row * rowb, newline, rowb, hipMemcpyDeviceToDevice, s));
+    row += 1;
+  }
+  *rows = row;
+  return 0;
+}
+
+int mavlm_linear(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const void* res, int32_t ldr,
+                 void* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t dtype, void* stream) {
+  if (!A || !W || !bias || !C || M < 0) return MAVLM_E_ARG;
+  if (N % 128 || K % 64 || N <= 0 || K <= 0) return MAVLM_E_SHAPE;
+  hipError_t e = gemm(dtype, (hipStream_t)stream, A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, res, ldr);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int mavlm_attention(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
+                    int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream) {
+  mavlm_attn_args a;
+  a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.lse2 = lse2;
+  a.R = R; a.S = S; a.H = H; a.scale = scale;
+  hipError_t e = mavlm_launch_attention(a, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int mavlm_attention_colsum(const void* Q, int32_t ldq, const void* K, int32_t ldk, const float* lse2, float* part,
+                           int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream) {
+  mavlm_colsum_args a;
+  a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.lse2 = lse2; a.part = part; a.R = R; a.S = S; a.H = H; a.scale = scale;
+  hipError_t e = mavlm_launch_colsum(a, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int mavlm_layernorm(const float* xin, const float* gamma, const float* beta, void* out, int32_t rows, int32_t D, float eps,
+                    int32_t dtype, void* stream) {
+  hipError_t e = mavlm_launch_layernorm(xin, gamma, beta, out, rows, D, eps, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int mavlm_row_add(const void* xin, const int64_t* src, const void* table, const int64_t* idx, void* out, int32_t T,
+                  int32_t P, int32_t D, int32_t dtype, void* stream) {
+  hipError_t e = mavlm_launch_row_add(xin, src, table, idx, out, T, P, D, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+}  // extern "C"

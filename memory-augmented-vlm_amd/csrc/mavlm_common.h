@@ -1,0 +1,85 @@
+// Common device helpers for the MI355X (gfx950 / CDNA4) memory-path kernels.
+// Wave = 64 lanes everywhere; MFMA fragment maps per cdna_hip_programming.md §3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+
+#define MAVLM_LDS __attribute__((address_space(3)))
+#define MAVLM_GLOBAL __attribute__((address_space(1)))
+
+enum { MAVLM_BF16 = 0, MAVLM_F16 = 1 };
+
+// 16-bit element traits: storage is always uint16_t; arithmetic is fp32.
+struct BF16 {
+  using vec8 = bf16x8;
+  using vec4 = bf16x4;
+  static __device__ __forceinline__ float to_f32(uint16_t u) {
+    return __builtin_bit_cast(float, (unsigned)u << 16);
+  }
+  static __device__ __forceinline__ uint16_t from_f32(float f) {   // RNE, v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint16_t, (__bf16)f);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ vec4 ds_read_tr(unsigned lds_byte_off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MAVLM_LDS vec4*)(uintptr_t)lds_byte_off);
+  }
+};
+
+struct F16 {
+  using vec8 = f16x8;
+  using vec4 = f16x4;
+  static __device__ __forceinline__ float to_f32(uint16_t u) {
+    return (float)__builtin_bit_cast(_Float16, u);
+  }
+  static __device__ __forceinline__ uint16_t from_f32(float f) {
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ vec4 ds_read_tr(unsigned lds_byte_off) {
+    typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 h4;
+    return __builtin_bit_cast(vec4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((MAVLM_LDS h4*)(uintptr_t)lds_byte_off));
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
+  u32x2 r;
+  r[0] = (unsigned)T::from_f32(a) | ((unsigned)T::from_f32(b) << 16);
+  r[1] = (unsigned)T::from_f32(c) | ((unsigned)T::from_f32(d) << 16);
+  return r;
+}
+
+// Bijective XCD-aware remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch), so
+// give each XCD a contiguous range of logical tiles (cdna_hip_programming.md T1).  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (bid >> 3);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}

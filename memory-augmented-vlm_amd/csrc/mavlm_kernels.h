@@ -1,0 +1,62 @@
+// Internal launch interface between the C-ABI layer (mavlm_api.hip) and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+enum { MAVLM_EPI_BIAS = 0, MAVLM_EPI_RELU = 1, MAVLM_EPI_GELU = 2, MAVLM_EPI_RES_F32 = 3 };
+
+struct mavlm_gemm_args {
+  const void* A; int lda;        // [M,K] 16-bit, row stride lda elements
+  const void* W; int ldw;        // [N,K] 16-bit (nn.Linear weight layout)
+  const float* bias;             // [N] fp32
+  const void* res; int ldr;      // [M,N] 16-bit residual (EPI_RES_F32 only)
+  void* C; int ldc;              // [M,N] 16-bit, or fp32 for EPI_RES_F32
+  int M, N, K;
+  int epilogue;
+};
+hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s);
+
+struct mavlm_attn_args {
+  const void* Q; int ldq;        // [R, >=H*128] 16-bit; head h at column h*128
+  const void* K; int ldk;        // [S, ...]
+  const void* V; int ldv;        // [S, ...]
+  void* O; int ldo;              // [R, H*128] 16-bit
+  float* lse2;                   // [H, R] fp32 (log2-domain log-sum-exp) or null
+  int R, S, H;
+  float scale;                   // 1/sqrt(head_dim)
+};
+hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream_t s);
+
+// column sums of the normalised probabilities: part[h][k] = sum_q exp2(s*c - lse2[h][q])
+struct mavlm_colsum_args {
+  const void* Q; int ldq;
+  const void* K; int ldk;
+  const float* lse2;             // [H, R]
+  float* part;                   // [H, S]
+  int R, S, H;
+  float scale;
+};
+hipError_t mavlm_launch_colsum(const mavlm_colsum_args& a, int dtype, hipStream_t s);
+
+// frame_scores[f] = (1/P) * sum_{p<P} sum_h part[h][f*P+p]     (MemoryController.py:135-139)
+hipError_t mavlm_launch_frame_scores(const float* part, int H, int S, int F, int P, void* out, int out_f32, int dtype,
+                                     hipStream_t s);
+
+// out[r,:] = LayerNorm(x[r,:]) * gamma + beta   (x fp32 [rows, D]; biased variance; rsqrt(var+eps))
+hipError_t mavlm_launch_layernorm(const float* x, const float* gamma, const float* beta, void* out, int rows, int D,
+                                  float eps, int dtype, hipStream_t s);
+
+// out[t,p,:] = x[src[t],p,:] + table[idx[t],:]   (src null = identity, idx null = row 0)
+hipError_t mavlm_launch_row_add(const void* x, const int64_t* src, const void* table, const int64_t* idx, void* out,
+                                int T, int P, int D, int dtype, hipStream_t s);
+
+// ---- optional per-kernel HIP-event profiling (bench.py roofline line); off by default, zero cost when off.
+enum { MAVLM_K_GEMM = 0, MAVLM_K_ATTN = 1, MAVLM_K_COLSUM = 2, MAVLM_K_LN = 3, MAVLM_K_ROWADD = 4, MAVLM_K_MISC = 5,
+       MAVLM_K_COUNT = 6 };
+struct mavlm_prof_scope {
+  int slot;
+  hipStream_t s;
+  mavlm_prof_scope(int kind, double flops, double bytes, hipStream_t stream);
+  ~mavlm_prof_scope();
+};

@@ -1,0 +1,304 @@
+"""Multimodal glue of the memory path on the MI355X HIP engine.
+
+Mirrors the memory-specific parts of the reference's llava/model/llava_arch.py so the HF/LLaVA backbone
+(vision tower, mm_projector, Qwen2 LLM - all unchanged PyTorch-ROCm modules) keeps working:
+
+  LlavaMetaModel            builds `recurrent_memory_transformer`, `memory_fuser`, `positional_encoding`,
+                            `token_type_embedding` with the reference's names and hard-coded hyper-parameters
+                            (llava_arch.py:117-150) - same state-dict keys, so checkpoints load unchanged.
+  LlavaMetaForCausalLM      `prepare_inputs_labels_for_multimodal` (8 in / 6 out, llava_arch.py:388-878) for the
+                            video path, `get_2dPool`, `encode_images`, `get_synced_dropout_decision`.
+  video_memory_tokens       the per-video driver (llava_arch.py:502-557,613-629,705-731) as HIP launches only:
+                            PE add -> chunk loop (mavlm_step) -> fuser MLP + type add + prompts/newlines concat
+                            (mavlm_fuse_emit) written straight into one token block.
+
+Out of scope here (stay with the backbone / next rows of SURVEY.md §8f): building the vision tower and projector,
+the image (non-video) merge modes, anyres unpadding.  Those branches raise NotImplementedError.
+"""
+import math
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .. import _capi as capi
+from .. import _ops as ops
+from .memory_module.MemoryController import Config, TransformerProjector
+from .memory_module.position_encoding import TemporalPositionalEncoding
+from .memory_module.segment import uniform_segment_variant
+
+IGNORE_INDEX = -100          # llava/constants.py:7
+IMAGE_TOKEN_INDEX = -200     # llava/constants.py:8
+
+# Qwen2-tokenizer ids of the two fixed prompts (llava_arch.py:708,714):
+# "This is a high-level summary of the video:" / "These are sampled visual frames from the video:"
+MEMORY_PROMPT_IDS = (1986, 374, 264, 1550, 11591, 12126, 315, 279, 2766, 25)
+FRAME_PROMPT_IDS = (9485, 525, 48876, 9124, 14087, 504, 279, 2766, 25)
+
+
+class MemoryFuserMLP(nn.Sequential):
+    """`memory_fuser` = Linear(D,4D) -> GELU(erf) -> Linear(4D,D) (llava_arch.py:132-136); state-dict keys
+    `0.weight, 0.bias, 2.weight, 2.bias` as the reference's nn.Sequential.  forward = two MFMA GEMMs with the
+    GELU fused into the first epilogue."""
+
+    def __init__(self, hidden):
+        super().__init__(nn.Linear(hidden, hidden * 4), nn.GELU(), nn.Linear(hidden * 4, hidden))
+
+    def forward(self, x):
+        x2 = x.reshape(-1, x.shape[-1])
+        u = ops.linear(x2, self[0].weight, self[0].bias.float(), capi.EPI_GELU)
+        y = ops.linear(u, self[2].weight, self[2].bias.float(), capi.EPI_BIAS)
+        return y.reshape(x.shape)
+
+
+def sample_frame_count(num_frames: int) -> int:
+    """F0 -> F  (llava_arch.py:437-445): all frames below 32, else a multiple of 32 and at least 64."""
+    if num_frames < 32:
+        return num_frames
+    return max(64, (num_frames // 32) * 32)
+
+
+def sample_frame_indices(num_frames: int) -> torch.Tensor:
+    """llava_arch.py:451 - same call the reference makes (CPU float32 linspace, truncation)."""
+    return torch.linspace(0, num_frames - 1, steps=sample_frame_count(num_frames)).long()
+
+
+def fine_frame_indices(num_frames: int, want: int = 32) -> torch.Tensor:
+    """llava_arch.py:513-522 - rounded, clamped linspace over the sampled frames."""
+    n = min(want, num_frames)
+    idx = torch.round(torch.linspace(0, num_frames - 1, steps=n)).long()
+    return torch.clamp(idx, 0, num_frames - 1)
+
+
+class LlavaMetaModel:
+    """Mixin for the inner model (the class that owns `embed_tokens`).  Vision modules are the backbone's: attach
+    `vision_tower`, `mm_projector`, `image_newline` as the host model does."""
+
+    def __init__(self, config):
+        super(LlavaMetaModel, self).__init__(config)
+        hidden = getattr(config, "hidden_size", 896)
+        c = Config()
+        c.mm_hidden_size = hidden
+        c.mm_hidden_act = "relu"
+        c.mm_num_attention_heads = 8
+        c.patch_size = 196
+        c.mm_attention_probs_dropout_prob = 0.1
+        c.mm_layer_norm_eps = 1e-12
+        c.mm_hidden_dropout_prob = 0.1
+        c.mm_intermediate_size = 4 * hidden
+        c.num_memory_tokens = getattr(config, "num_memory_tokens", 8)     # reference constant: 8
+        c.depth = 2
+        c.mm_dtype = torch.float16
+        c.cache_cap = getattr(config, "memory_cache_cap", 10)
+        self.recurrent_memory_transformer = TransformerProjector(c)
+        self.memory_fuser = MemoryFuserMLP(hidden)
+        self.positional_encoding = TemporalPositionalEncoding(
+            max_frames=getattr(config, "memory_max_frames", 600), embed_dim=hidden, learnable=False)
+        self.token_type_embedding = nn.Embedding(2, hidden)
+        self.recurrent_memory_transformer.bind_fuser(self.memory_fuser, self.token_type_embedding)
+
+    def get_vision_tower(self):
+        vt = getattr(self, "vision_tower", None)
+        return vt[0] if type(vt) is list else vt
+
+
+_INDEX_CACHE = {}
+
+
+def _device_indices(idx_cpu: torch.Tensor, device) -> torch.Tensor:
+    """int64 index vectors are tiny and repeat across videos of the same length: cache the device copy so the
+    steady state has no H2D copy (a pageable copy would wait for the stream to drain)."""
+    key = (str(device), idx_cpu.numel(), idx_cpu.numpy().tobytes())
+    t = _INDEX_CACHE.get(key)
+    if t is None:
+        if len(_INDEX_CACHE) > 256:
+            _INDEX_CACHE.clear()
+        t = idx_cpu.to(device=device, dtype=torch.int64)
+        _INDEX_CACHE[key] = t
+    return t
+
+
+@torch.no_grad()
+def video_memory_tokens(model, image: torch.Tensor, frame_idx_cpu: torch.Tensor, memory_prompt_embeds: torch.Tensor,
+                        frame_prompt_embeds: torch.Tensor, image_newline: torch.Tensor, with_frames: bool = True,
+                        chunk: int = 32, fine_frames: int = 32):
+    """Per-video memory path.  `model` owns the four memory sub-modules; `image` = pooled frame tokens [T,196,D]
+    on the GPU; `frame_idx_cpu` = original frame indices [T] (host).  Returns (tokens [rows,D], info dict).
+
+    tokens = [mem_prompt ; fused memory (oldest first) ; newline ; frame_prompt ; fine frames ; newline]
+    (llava_arch.py:620-629,729-731); with_frames=False reproduces the frame-dropout branch (:720-725)."""
+    if not image.is_cuda:
+        raise capi.MavlmError("video_memory_tokens: frame tokens are not on a GPU (no CPU fallback)")
+    pe: TemporalPositionalEncoding = model.positional_encoding
+    rm: TransformerProjector = model.recurrent_memory_transformer
+    T, P, D = image.shape
+    pe.check_indices(frame_idx_cpu)                                                       # ValueError, :73-76
+    x = pe(image, _device_indices(frame_idx_cpu, image.device), indices_checked=True)     # :510-511
+    fine_cpu = fine_frame_indices(T, fine_frames)                                         # :513-522
+    bounds = uniform_segment_variant(T, chunk)                                            # :528
+    rm.memory_cache = []                                                                  # :532
+    for i in range(len(bounds) - 1):                                                      # :534-537
+        rm(x[bounds[i]:bounds[i + 1]])
+    eng = rm.engine(image.device, image.dtype)
+    n = len(rm.memory_cache)
+    R = rm.num_memory_tokens * P
+    n_fine = fine_cpu.numel()
+    rows = memory_prompt_embeds.shape[0] + n * R + 1
+    if with_frames:
+        rows += frame_prompt_embeds.shape[0] + n_fine * P + 1
+    out = torch.empty((rows, D), device=image.device, dtype=image.dtype)
+    mp = memory_prompt_embeds.to(image.dtype).contiguous()
+    fp = frame_prompt_embeds.to(image.dtype).contiguous()
+    nl = image_newline.to(device=image.device, dtype=image.dtype).contiguous()
+    import ctypes
+    written = ctypes.c_int64(0)
+    capi.check(capi.lib().mavlm_fuse_emit(eng.ctx, x.data_ptr(), _device_indices(fine_cpu, image.device).data_ptr(), n_fine,
+                                          mp.data_ptr(), mp.shape[0], fp.data_ptr(), fp.shape[0], nl.data_ptr(),
+                                          1 if with_frames else 0, out.data_ptr(), rows, ctypes.byref(written),
+                                          ops.stream_ptr()), "mavlm_fuse_emit")
+    assert written.value == rows
+    info = {"num_memories": n, "pe_frames": x, "fine_idx": fine_cpu, "memory_rows": (mp.shape[0], mp.shape[0] + n * R)}
+    return out, info
+
+
+class LlavaMetaForCausalLM:
+    """Mixin for the *ForCausalLM wrapper: needs `get_model()`, `.config`, `.device`."""
+
+    def get_model(self):
+        raise NotImplementedError
+
+    def get_vision_tower(self):
+        return self.get_model().get_vision_tower()
+
+    def get_2dPool(self, image_feature, stride=2):
+        """[F, side*side, D] -> [F, ceil(side/stride)^2, D]  (llava_arch.py:277-297).  Step before the path
+        (SURVEY.md §8f rank 1): stays a backbone op on PyTorch-ROCm in this round."""
+        side = self.get_vision_tower().num_patches_per_side
+        nf, _, nd = image_feature.shape
+        x = image_feature.view(nf, side, side, -1).permute(0, 3, 1, 2).contiguous()
+        mode = self.config.mm_spatial_pool_mode
+        if mode == "average":
+            x = nn.functional.avg_pool2d(x, stride)
+        elif mode == "max":
+            x = nn.functional.max_pool2d(x, stride)
+        elif mode == "bilinear":
+            size = [math.ceil(side / stride), math.ceil(side / stride)]
+            x = nn.functional.interpolate(x, size=size, mode="bilinear")
+        else:
+            raise ValueError(f"Unexpected mm_spatial_pool_mode: {mode}")
+        return x.permute(0, 2, 3, 1).reshape(nf, -1, nd)
+
+    def encode_images(self, images):
+        feats = self.get_model().get_vision_tower()(images)
+        return self.get_model().mm_projector(feats).detach()      # llava_arch.py:299-304
+
+    def get_synced_dropout_decision(self, prob: float = 0.5):
+        """Shared Bernoulli(prob) across ranks (llava_arch.py:378-386): rank-0 draw, 1-element broadcast."""
+        if not dist.is_initialized():
+            return torch.rand(1).item() < prob
+        flag = torch.zeros(1, device=self.device)
+        if dist.get_rank() == 0:
+            flag.fill_(1.0 if torch.rand(1).item() < prob else 0.0)
+        dist.broadcast(flag, src=0)
+        return bool(flag.item())
+
+    def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels,
+                                             images, modalities=["image"], image_sizes=None):
+        vision_tower = self.get_vision_tower()
+        if vision_tower is None or images is None or input_ids.shape[1] == 1:
+            return input_ids, position_ids, attention_mask, past_key_values, None, labels        # :392-394
+        if isinstance(modalities, str):
+            modalities = [modalities]
+        if not (type(images) is list or images.ndim == 5):
+            raise NotImplementedError("plain image batches bypass the memory path (llava_arch.py:703): backbone-only")
+        images = [x.unsqueeze(0) if x.ndim == 3 else x for x in images] if type(images) is list else list(images)
+        if len(images) != 1 or modalities[0] != "video":
+            raise NotImplementedError("the memory path supports one video per forward (llava_arch.py:436)")
+        if getattr(self.config, "mm_newline_position", "one_token") != "one_token" or \
+                "unpad" not in getattr(self.config, "mm_patch_merge_type", "flat"):
+            raise NotImplementedError("memory path: mm_newline_position='one_token' with an *_unpad merge type only")
+        model = self.get_model()
+        video = images[0]
+        idx_cpu = sample_frame_indices(video.shape[0])                                          # :437-451
+        feats = self.encode_images(video[idx_cpu.to(video.device)])                             # :457-481
+        pooled = self.get_2dPool(feats)                                                         # :495
+        dev = pooled.device
+        mem_prompt = model.embed_tokens(torch.tensor([MEMORY_PROMPT_IDS], device=dev)).squeeze(0)   # :708-709
+        frame_prompt = model.embed_tokens(torch.tensor([FRAME_PROMPT_IDS], device=dev)).squeeze(0)  # :714-715
+        training = bool(getattr(self, "training", False))
+        dropout_frames = getattr(self.config, "dropout_frames", False)
+        if training and dropout_frames:
+            drop = self.get_synced_dropout_decision(prob=0.5)                                    # :719
+        else:
+            torch.rand(1)   # keep the reference's per-forward RNG draw; the broadcast cannot change the result here
+            drop = False
+        tokens, _ = video_memory_tokens(model, pooled, idx_cpu, mem_prompt, frame_prompt, model.image_newline,
+                                        with_frames=not drop)
+        return splice_into_text(self, model, [tokens], input_ids, position_ids, attention_mask, past_key_values, labels)
+
+
+def splice_into_text(lm, model, image_features: List[torch.Tensor], input_ids, position_ids, attention_mask,
+                     past_key_values, labels):
+    """Insert the visual token blocks at IMAGE_TOKEN_INDEX, truncate to tokenizer_model_max_length, pad, and build
+    labels / mask / position ids (llava_arch.py:745-878).  Host-side orchestration of device copies."""
+    _labels, _position_ids, _attention_mask = labels, position_ids, attention_mask
+    if attention_mask is None:
+        attention_mask = torch.ones_like(input_ids, dtype=torch.bool)
+    else:
+        attention_mask = attention_mask.bool()
+    if position_ids is None:
+        position_ids = torch.arange(0, input_ids.shape[1], dtype=torch.long, device=input_ids.device)
+    if labels is None:
+        labels = torch.full_like(input_ids, IGNORE_INDEX)
+    ids_list = [i[m] for i, m in zip(input_ids, attention_mask)]
+    lab_list = [l[m] for l, m in zip(labels, attention_mask)]
+
+    new_embeds, new_labels = [], []
+    img_i = 0
+    for ids, lab in zip(ids_list, lab_list):
+        img_pos = torch.where(ids == IMAGE_TOKEN_INDEX)[0].tolist()
+        if not img_pos:
+            new_embeds.append(model.embed_tokens(ids))
+            new_labels.append(lab)
+            img_i += 1
+            continue
+        cuts = [-1] + img_pos + [ids.shape[0]]
+        text_ids = [ids[cuts[i] + 1:cuts[i + 1]] for i in range(len(cuts) - 1)]
+        text_lab = [lab[cuts[i] + 1:cuts[i + 1]] for i in range(len(cuts) - 1)]
+        text_emb = torch.split(model.embed_tokens(torch.cat(text_ids)), [t.shape[0] for t in text_ids], dim=0)
+        pe, pl = [], []
+        for i in range(len(img_pos) + 1):
+            pe.append(text_emb[i])
+            pl.append(text_lab[i])
+            if i < len(img_pos):
+                f = image_features[min(img_i, len(image_features) - 1)]
+                img_i += 1
+                pe.append(f.to(text_emb[i].dtype))
+                pl.append(torch.full((f.shape[0],), IGNORE_INDEX, device=lab.device, dtype=lab.dtype))
+        new_embeds.append(torch.cat(pe))
+        new_labels.append(torch.cat(pl))
+
+    max_tok = getattr(lm.config, "tokenizer_model_max_length", None)
+    new_embeds = [x[:max_tok] for x in new_embeds]
+    new_labels = [x[:max_tok] for x in new_labels]
+    max_len = max(x.shape[0] for x in new_embeds)
+    B = len(new_embeds)
+    left = getattr(lm.config, "tokenizer_padding_side", "right") == "left"
+    emb = torch.zeros((B, max_len, new_embeds[0].shape[1]), dtype=new_embeds[0].dtype, device=new_embeds[0].device)
+    lab_pad = torch.full((B, max_len), IGNORE_INDEX, dtype=new_labels[0].dtype, device=new_labels[0].device)
+    mask = torch.zeros((B, max_len), dtype=attention_mask.dtype, device=attention_mask.device)
+    pos = torch.zeros((B, max_len), dtype=position_ids.dtype, device=position_ids.device)
+    for i, (e, l) in enumerate(zip(new_embeds, new_labels)):
+        n = e.shape[0]
+        if n == 0:
+            continue
+        sl = slice(max_len - n, max_len) if left else slice(0, n)
+        emb[i, sl] = e
+        lab_pad[i, sl] = l
+        mask[i, sl] = True
+        pos[i, sl] = torch.arange(0, n, dtype=pos.dtype, device=pos.device)
+    out_labels = None if _labels is None else lab_pad
+    out_mask = None if _attention_mask is None else mask.to(dtype=_attention_mask.dtype)
+    out_pos = None if _position_ids is None else pos
+    return None, out_pos, out_mask, past_key_values, emb, out_labels

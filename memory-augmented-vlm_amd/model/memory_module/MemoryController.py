@@ -1,0 +1,338 @@
+"""Recurrent memory transformer on the MI355X HIP path.
+
+Drop-in for llava/model/memory_module/MemoryController.py of the reference: same class names, constructor
+arguments, parameter / state-dict names and the same call protocol
+
+    recurrent_model.memory_cache = []                      # per video   (llava_arch.py:532)
+    memory_cache, attn_stats = recurrent_model(segment)    # per chunk   (llava_arch.py:536-537)
+
+but ``TransformerProjector.forward`` runs as one fused launch sequence of hand-written gfx950 kernels behind the
+C ABI (include/mavlm.h: mavlm_step) - MFMA GEMMs with fused bias/ReLU/residual epilogues, flash-style
+cross-attention that never materialises the [H,R,S] probabilities, a second column-sum pass for the frame scores,
+wave-reduce LayerNorm.  The sub-modules keep their parameters (so checkpoints load unchanged) and each has a working
+``forward`` built from the operator-level entry points; none of them has a CPU path.
+
+Deliberate deviations from the reference (documented in DESIGN.md):
+  * `Attention.forward` returns a `FusedAttentionStats` (column sums + log-sum-exp) instead of the
+    materialised probability tensor (MemoryController.py:52,57) - the only consumer reads column sums (:135).
+  * the dead per-chunk statistics of the evolution step (:99-109) are not computed, so the reference's implicit
+    `num_memory_tokens % 8 == 0` / `heads == 8` requirement (reshape(8,-1,8), :109) does not apply.
+  * tensors in the returned `memory_cache` are views into a ring buffer owned by the module: an entry is
+    overwritten once it has been evicted from the FIFO (the reference drops the evicted tensor, :153-154).
+  * forward only (inference).  Calling it in training mode with autograd enabled raises.
+"""
+import math
+from typing import List
+
+import torch
+from torch import nn
+
+from ... import _capi as capi
+from ... import _ops as ops
+
+
+class Config:
+    """Hyper-parameters; same attribute names and defaults as the reference `Config` (:7-18) plus the two
+    constants the reference hard-codes in code (FIFO cap :153, chunk size llava_arch.py:528)."""
+    mm_hidden_size = 896
+    mm_hidden_act = "relu"
+    mm_num_attention_heads = 8
+    patch_size = 196
+    mm_attention_probs_dropout_prob = 0.1   # defined, never applied (as in the reference)
+    mm_layer_norm_eps = 1e-12
+    mm_hidden_dropout_prob = 0.1            # defined, never applied
+    mm_intermediate_size = 4 * mm_hidden_size
+    num_memory_tokens = 8
+    depth = 1
+    mm_dtype = torch.float16                # creation dtype of the parameters only
+    cache_cap = 10
+    max_chunk_frames = 32
+
+
+class FusedAttentionStats:
+    """What the fused kernel keeps of the attention probabilities: per-(head,query) log2-sum-exp and, on demand,
+    the per-key column sums  sum_h sum_q p[h,q,k]  (all the reference ever reads, MemoryController.py:135)."""
+
+    def __init__(self, q, k, lse2, heads):
+        self._q, self._k, self.lse2, self.heads = q, k, lse2, heads
+
+    def column_sums_per_head(self) -> torch.Tensor:
+        return ops.attention_colsum(self._q, self._k, self.lse2, self.heads)
+
+    def column_sums(self) -> torch.Tensor:
+        return self.column_sums_per_head().sum(dim=0)
+
+
+class Residual(nn.Module):
+    """LayerNorm(dense(h) + x)  (:20-29): GEMM with fused bias+residual epilogue (fp32 out) -> row LayerNorm."""
+
+    def __init__(self, input_size, output_size, config):
+        super().__init__()
+        self.dense = nn.Linear(input_size, output_size, dtype=config.mm_dtype)
+        self.layernorm = nn.LayerNorm(output_size, eps=config.mm_layer_norm_eps, dtype=config.mm_dtype)
+
+    def forward(self, hidden_states: torch.Tensor, input_tensor: torch.Tensor):
+        shp = input_tensor.shape
+        h2 = hidden_states.reshape(-1, hidden_states.shape[-1])
+        x2 = input_tensor.reshape(-1, shp[-1])
+        pre = ops.linear(h2, self.dense.weight, self.dense.bias.float(), capi.EPI_RES_F32, residual=x2)
+        out = ops.layernorm(pre, self.layernorm.weight.float(), self.layernorm.bias.float(), self.layernorm.eps, x2.dtype)
+        return out.reshape(shp)
+
+
+class Attention(nn.Module):
+    """Multi-head attention block (:31-57), head_dim 128 on the HIP path."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.hidden_size = config.mm_hidden_size
+        self.num_attention_heads = config.mm_num_attention_heads
+        self.attention_head_size = self.hidden_size // self.num_attention_heads
+        self.k_proj = nn.Linear(self.hidden_size, self.hidden_size, dtype=config.mm_dtype)
+        self.v_proj = nn.Linear(self.hidden_size, self.hidden_size, dtype=config.mm_dtype)
+        self.q_proj = nn.Linear(self.hidden_size, self.hidden_size, dtype=config.mm_dtype)
+        self.residual = Residual(self.hidden_size, self.hidden_size, config)
+
+    def forward(self, hidden_states, kv_hidden_states=None, output_attentions=True):
+        if hidden_states.dim() != 3 or hidden_states.shape[0] != 1:
+            raise capi.MavlmError("Attention.forward: batch size 1 only (as the reference, MemoryController.py:121)")
+        kv = hidden_states if kv_hidden_states is None else kv_hidden_states
+        xq, xkv = hidden_states[0], kv[0]
+        q = ops.linear(xq, self.q_proj.weight, self.q_proj.bias.float())
+        k = ops.linear(xkv, self.k_proj.weight, self.k_proj.bias.float())
+        v = ops.linear(xkv, self.v_proj.weight, self.v_proj.bias.float())
+        ctx, lse2 = ops.attention(q, k, v, self.num_attention_heads, want_lse=output_attentions)
+        out = self.residual(ctx[None], hidden_states)
+        stats = FusedAttentionStats(q, k, lse2, self.num_attention_heads) if output_attentions else None
+        return out, stats
+
+
+class TransformerLayer(nn.Module):
+    """Cross-attention + ReLU MLP with post-LN residuals (:59-72)."""
+
+    def __init__(self, config):
+        super().__init__()
+        if config.mm_hidden_act != "relu":
+            raise capi.MavlmError("only mm_hidden_act='relu' (the value the reference uses) is implemented")
+        self.memory_segment_fusion_attention = Attention(config)
+        self.mlp = nn.Sequential(
+            nn.Linear(config.mm_hidden_size, config.mm_intermediate_size, dtype=config.mm_dtype),
+            nn.ReLU(),
+        )
+        self.residual = Residual(config.mm_intermediate_size, config.mm_hidden_size, config)
+
+    def forward(self, query_states, kv_states):
+        a, stats = self.memory_segment_fusion_attention(query_states, kv_hidden_states=kv_states, output_attentions=True)
+        h = ops.linear(a[0], self.mlp[0].weight, self.mlp[0].bias.float(), capi.EPI_RELU)
+        return self.residual(h[None], a), stats
+
+
+class _Engine:
+    """Owns the C handle, the packed parameter views and the device buffers of one TransformerProjector."""
+
+    def __init__(self, proj: "TransformerProjector", device, dtype, max_chunk_frames):
+        cfg = proj.config
+        self.device, self.dtype = device, dtype
+        self.c = capi.Config(hidden=cfg.mm_hidden_size, heads=cfg.mm_num_attention_heads, patches=cfg.patch_size,
+                             mem_tokens=cfg.num_memory_tokens, depth=cfg.depth, inter=cfg.mm_intermediate_size,
+                             cache_cap=getattr(cfg, "cache_cap", 10), max_chunk_frames=max_chunk_frames,
+                             dtype=ops.dtype_code(dtype), eps=cfg.mm_layer_norm_eps)
+        lib = capi.lib()
+        h = capi.vp()
+        capi.check(lib.mavlm_create(self.c, h), "mavlm_create")
+        self.ctx = h
+        R, D = self.c.mem_tokens * self.c.patches, self.c.hidden
+        self.mem_ring = torch.empty((self.c.cache_cap, self.c.mem_tokens, self.c.patches, D), device=device, dtype=dtype)
+        self.evo_kv = torch.empty((self.c.cache_cap, R, 2 * D), device=device, dtype=dtype)
+        nbytes = lib.mavlm_workspace_bytes(self.c)
+        self.workspace = torch.empty(nbytes + 256, device=device, dtype=torch.uint8)
+        base = (self.workspace.data_ptr() + 255) & ~255
+        self.workspace_base_offset = base - self.workspace.data_ptr()
+        b = capi.Buffers(mem_ring=self.mem_ring.data_ptr(), evo_kv_ring=self.evo_kv.data_ptr(), workspace=base,
+                         workspace_bytes=nbytes)
+        capi.check(lib.mavlm_bind_buffers(self.ctx, b), "mavlm_bind_buffers")
+        self.keep = {}
+        self.version = None
+
+    def __del__(self):
+        try:
+            if self.ctx:
+                capi.lib().mavlm_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # -- parameter packing -------------------------------------------------------------------------------
+    def pack(self, proj, fuser=None, type_emb=None):
+        dev, dt = self.device, self.dtype
+        keep = {}
+
+        def w16(name, t):
+            keep[name] = t.detach().to(device=dev, dtype=dt).contiguous()
+            return keep[name].data_ptr()
+
+        def f32(name, t):
+            keep[name] = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            return keep[name].data_ptr()
+
+        def attn(prefix, a: Attention):
+            return capi.AttnWeights(wq=w16(prefix + "wq", a.q_proj.weight), bq=f32(prefix + "bq", a.q_proj.bias),
+                                    wo=w16(prefix + "wo", a.residual.dense.weight), bo=f32(prefix + "bo", a.residual.dense.bias),
+                                    ln_g=f32(prefix + "g", a.residual.layernorm.weight),
+                                    ln_b=f32(prefix + "b", a.residual.layernorm.bias))
+
+        W = capi.Weights()
+        R, D = self.c.mem_tokens * self.c.patches, self.c.hidden
+        # initial_memory + memory_pos_embed in the parameter dtype, then cast (MemoryController.py:123-124)
+        W.mem0 = w16("mem0", (proj.initial_memory + proj.memory_pos_embed).reshape(R, D))
+        ats = [l.memory_segment_fusion_attention for l in proj.layers]
+        W.w_kv_seg = w16("wkv", torch.cat([t for a in ats for t in (a.k_proj.weight, a.v_proj.weight)], dim=0))
+        W.b_kv_seg = f32("bkv", torch.cat([t for a in ats for t in (a.k_proj.bias, a.v_proj.bias)], dim=0))
+        for l, layer in enumerate(proj.layers):
+            W.layer_attn[l] = attn(f"l{l}.", ats[l])
+            W.w_up[l] = w16(f"l{l}.up", layer.mlp[0].weight)
+            W.b_up[l] = f32(f"l{l}.bup", layer.mlp[0].bias)
+            W.w_down[l] = w16(f"l{l}.down", layer.residual.dense.weight)
+            W.b_down[l] = f32(f"l{l}.bdown", layer.residual.dense.bias)
+            W.ln2_g[l] = f32(f"l{l}.g2", layer.residual.layernorm.weight)
+            W.ln2_b[l] = f32(f"l{l}.b2", layer.residual.layernorm.bias)
+        e = proj.memory_update_attention
+        W.evo = attn("evo.", e)
+        W.w_kv_evo = w16("evo.wkv", torch.cat([e.k_proj.weight, e.v_proj.weight], dim=0))
+        W.b_kv_evo = f32("evo.bkv", torch.cat([e.k_proj.bias, e.v_proj.bias], dim=0))
+        if fuser is not None and type_emb is not None:
+            te = type_emb.weight.detach().to(device=dev, dtype=dt)
+            W.w_f1 = w16("f1", fuser[0].weight)
+            W.b_f1 = f32("bf1", fuser[0].bias)
+            W.w_f2 = w16("f2", fuser[2].weight)
+            # bias + token_type_embedding[0] folded into the second epilogue (llava_arch.py:548-553)
+            W.b_f2_type0 = f32("bf2", fuser[2].bias.detach().to(dev).float() + te[0].float())
+            W.type1 = w16("type1", te[1])
+        capi.check(capi.lib().mavlm_bind_weights(self.ctx, W), "mavlm_bind_weights")
+        self.keep = keep          # keeps the packed tensors (and the Weights struct's targets) alive
+        self._W = W
+
+    @property
+    def steps(self) -> int:
+        return capi.lib().mavlm_steps(self.ctx)
+
+    def workspace_views(self):
+        """Typed views of the workspace regions (contents = intermediates of the most recent sub-layer).  For the
+        stage-wise parity tests; not used by the product path."""
+        import ctypes
+        offs = (ctypes.c_size_t * 10)()
+        capi.check(capi.lib().mavlm_workspace_layout(self.c, offs, 10), "mavlm_workspace_layout")
+        c = self.c
+        R, S, D, I, L, H = c.mem_tokens * c.patches, c.max_chunk_frames * c.patches, c.hidden, c.inter, c.depth, c.heads
+        names = ("kv_seg", "q", "ctx", "a", "h", "pre", "mA", "mB", "lse2", "part")
+        shapes = ((S, 2 * L * D), (R, D), (R, D), (R, D), (R, I), (R, D), (R, D), (R, D), (H, R), (H, S))
+        dts = (self.dtype,) * 5 + (torch.float32, self.dtype, self.dtype, torch.float32, torch.float32)
+        out = {}
+        for n_, o, shp, dt in zip(names, offs, shapes, dts):
+            nbytes = shp[0] * shp[1] * (4 if dt == torch.float32 else 2)
+            b0 = self.workspace_base_offset + o
+            out[n_] = self.workspace[b0:b0 + nbytes].view(dt).view(shp)
+        return out
+
+
+class TransformerProjector(nn.Module):
+    """The recurrent memory transformer (:74-158)."""
+
+    def __init__(self, config=None):
+        super().__init__()
+        self.config = config or Config()
+        if self.config.depth > capi.MAX_DEPTH:
+            raise capi.MavlmError(f"depth > {capi.MAX_DEPTH} not supported")
+        self.layers = nn.ModuleList([TransformerLayer(self.config) for _ in range(self.config.depth)])
+        self.num_memory_tokens = self.config.num_memory_tokens
+        self.hidden_size = self.config.mm_hidden_size
+        self.patch_size = self.config.patch_size
+        self.initial_memory = nn.Parameter(torch.empty(self.num_memory_tokens, self.patch_size, self.hidden_size))
+        self.memory_pos_embed = nn.Parameter(torch.randn(self.num_memory_tokens, 1, self.hidden_size))
+        nn.init.xavier_uniform_(self.initial_memory)
+        self.memory_update_attention = Attention(self.config)
+        self.frame_attn_scores: List[torch.Tensor] = []
+        self.compute_frame_scores = True      # API parity default; False skips the column-sum pass
+        self._memory_cache: List[torch.Tensor] = []
+        self._engine = None
+        self._fuser_refs = None               # (memory_fuser, token_type_embedding) bound by the glue
+
+    # -- the reference's reset protocol: `module.memory_cache = []` ----------------------------------------
+    @property
+    def memory_cache(self) -> List[torch.Tensor]:
+        return self._memory_cache
+
+    @memory_cache.setter
+    def memory_cache(self, value):
+        value = list(value)
+        if value:
+            raise capi.MavlmError("memory_cache can only be reset to [] from outside (llava_arch.py:532); "
+                                  "its entries are views into the module's ring buffer")
+        self._memory_cache = value
+        if self._engine is not None:
+            capi.check(capi.lib().mavlm_reset(self._engine.ctx), "mavlm_reset")
+
+    # -- engine management -------------------------------------------------------------------------------
+    def bind_fuser(self, memory_fuser, token_type_embedding):
+        """Give the engine the Memory-Fuser MLP and the token-type embedding (llava_arch.py:132-136,150) so that
+        mavlm_fuse_emit can run fuser + type add + concat in one sequence."""
+        self._fuser_refs = (memory_fuser, token_type_embedding)
+        if self._engine is not None:
+            self._engine.version = None
+
+    def _param_version(self):
+        ps = list(self.parameters())
+        if self._fuser_refs is not None:
+            ps += list(self._fuser_refs[0].parameters()) + list(self._fuser_refs[1].parameters())
+        return tuple((p._version, p.data_ptr()) for p in ps)
+
+    def refresh_weights(self):
+        if self._engine is not None:
+            self._engine.version = None
+
+    def engine(self, device, dtype, frames=None) -> _Engine:
+        need = max(int(getattr(self.config, "max_chunk_frames", 32)), int(frames or 0))
+        e = self._engine
+        if e is None or e.device != device or e.dtype != dtype or e.c.max_chunk_frames < need:
+            if e is not None and e.steps:
+                raise capi.MavlmError("device / dtype / chunk size changed in the middle of a video")
+            e = self._engine = _Engine(self, device, dtype, need)
+            self._memory_cache = []
+        v = self._param_version()
+        if e.version != v:
+            fuser, temb = self._fuser_refs if self._fuser_refs is not None else (None, None)
+            e.pack(self, fuser, temb)
+            e.version = v
+        return e
+
+    def _apply(self, fn, *a, **k):   # .to() / .cuda() / .half(): parameters move, packed views are stale
+        out = super()._apply(fn, *a, **k)
+        if getattr(self, "_engine", None) is not None and not self._engine.steps:
+            self._engine = None
+        return out
+
+    # -- forward -----------------------------------------------------------------------------------------
+    def forward(self, image_features: torch.Tensor):
+        if image_features.dim() != 3:
+            raise capi.MavlmError("TransformerProjector expects [F, P, D]")
+        if not image_features.is_cuda:
+            raise capi.MavlmError("TransformerProjector: input is not on a GPU; the HIP path has no CPU fallback")
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("the HIP memory path is forward-only (SURVEY.md §8f rank 3: backward is a "
+                                      "later row); call it under torch.no_grad() / in eval mode")
+        F, P, D = image_features.shape
+        if P != self.patch_size or D != self.hidden_size:
+            raise capi.MavlmError(f"expected [F,{self.patch_size},{self.hidden_size}], got {tuple(image_features.shape)}")
+        eng = self.engine(image_features.device, image_features.dtype, F)
+        x = image_features.contiguous()
+        scores = torch.empty(F, device=x.device, dtype=x.dtype) if self.compute_frame_scores else None
+        lib = capi.lib()
+        capi.check(lib.mavlm_step(eng.ctx, x.data_ptr(), F, scores.data_ptr() if scores is not None else 0, 0,
+                                  ops.stream_ptr()), "mavlm_step")
+        self._memory_cache.append(eng.mem_ring[lib.mavlm_newest_slot(eng.ctx)])      # :152
+        cap = eng.c.cache_cap
+        if len(self._memory_cache) > cap:                                            # :153-154
+            self._memory_cache = self._memory_cache[-cap:]
+        if scores is not None:
+            self.frame_attn_scores.append(scores)                                    # :156-157
+        return self._memory_cache, self.frame_attn_scores

@@ -40,6 +40,32 @@ except Exception:  # pragma: no cover
 
 F32 = np.float32
 
+# Accumulation width of every contraction.  float32 is the restatement proper; float64 is used by the tests to
+# measure the *noise floor* of a 16-bit chain: two correct implementations that differ only in summation order
+# decorrelate at every storage rounding (a perturbation d << ulp becomes ~sqrt(d*ulp) after rounding).
+_ACC = [np.float32]
+
+
+class accumulate_in:
+    """Context manager: run the oracle with float64 (or float32) accumulation in all matmuls."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev = _ACC[0]
+        _ACC[0] = self.dtype
+
+    def __exit__(self, *a):
+        _ACC[0] = self.prev
+
+
+def _mm(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    acc = _ACC[0]
+    if acc is np.float32:
+        return (a.astype(F32) @ b.astype(F32)).astype(F32)
+    return (a.astype(acc) @ b.astype(acc)).astype(F32)
+
 
 # --------------------------------------------------------------------------- #
 # rounding helpers
@@ -280,7 +306,7 @@ def uniform_segment_variant(T: int, d: int = 32) -> List[int]:
 # --------------------------------------------------------------------------- #
 def linear(x: np.ndarray, W: np.ndarray, b: np.ndarray) -> np.ndarray:
     """nn.Linear: x W^T + b, float32 accumulate (operands already on their grid)."""
-    return (x.astype(F32) @ W.astype(F32).T + b.astype(F32)).astype(F32)
+    return (_mm(x, W.T) + b.astype(F32)).astype(F32)
 
 
 def layernorm(x: np.ndarray, g: np.ndarray, b: np.ndarray, eps: float) -> np.ndarray:
@@ -298,46 +324,81 @@ def gelu_erf(x: np.ndarray) -> np.ndarray:
     return (0.5 * x * (1.0 + _erf(x / F32(math.sqrt(2.0))))).astype(F32)
 
 
+KV_TILE = 64   # keys per tile of the HIP flash-attention kernel (csrc/attention.hip)
+
+
+def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mode: str = "fp32",
+                    want_colsum: bool = False, want_probs: bool = False, kv_tile: int = KV_TILE):
+    """softmax(Q K^T / sqrt(d)) V per head (MemoryController.py:51-54).  Returns
+    (ctx [R,H*d] unrounded float32, lse2 [H,R] log2-domain log-sum-exp, colsum [H,Lk] | None, probs | None).
+
+    fp32 mode: plain softmax.  Emulation modes follow the kernel's rounding points exactly: keys are consumed in
+    tiles of ``kv_tile`` with a running row maximum; the probabilities of a tile are rounded to 16 bits
+    *relative to the running maximum at that tile* before the P.V product, while the row sum uses the unrounded
+    values; earlier partial sums are rescaled in float32 when the maximum grows."""
+    r = rounder(mode)
+    R, Lk = Q.shape[0], K.shape[0]
+    d = Q.shape[1] // heads
+    scale = F32(1.0 / math.sqrt(d))
+    ctx = np.empty((R, heads * d), dtype=F32)
+    lse2 = np.empty((heads, R), dtype=F32)
+    colsum = np.zeros((heads, Lk), dtype=np.float64) if want_colsum else None
+    probs = np.empty((heads, R, Lk), dtype=F32) if want_probs else None
+    for h in range(heads):
+        sl = slice(h * d, (h + 1) * d)
+        s = _mm(Q[:, sl], K[:, sl].T) * scale                                # :51
+        if mode == "fp32":
+            m = s.max(axis=1, keepdims=True)
+            p = np.exp(s - m, dtype=F32)
+            l = p.sum(axis=1, keepdims=True, dtype=F32)
+            acc = _mm(p, V[:, sl])
+        else:
+            m = np.full((R, 1), -1e30, dtype=F32)
+            l = np.zeros((R, 1), dtype=F32)
+            acc = np.zeros((R, d), dtype=F32)
+            for k0 in range(0, Lk, kv_tile):
+                st = s[:, k0:k0 + kv_tile]
+                m_new = np.maximum(m, st.max(axis=1, keepdims=True))
+                alpha = np.exp(m - m_new, dtype=F32)
+                pt = np.exp(st - m_new, dtype=F32)
+                l = l * alpha + pt.sum(axis=1, keepdims=True, dtype=F32)
+                acc = acc * alpha + _mm(r(pt), V[k0:k0 + kv_tile, sl])       # P rounded as the MFMA operand
+                m = m_new
+        ctx[:, sl] = acc / l                                                 # :53
+        lse = m + np.log(l)
+        lse2[h] = (lse / F32(math.log(2.0))).reshape(-1)
+        if want_colsum or want_probs:
+            pn = np.exp(s - lse, dtype=F32)                                  # :52 normalised probabilities
+            if want_colsum:
+                colsum[h] = pn.sum(axis=0, dtype=np.float64)
+            if want_probs:
+                probs[h] = pn
+    return ctx, lse2, (colsum.astype(F32) if want_colsum else None), probs
+
+
 def mha(Xq: np.ndarray, Xkv: np.ndarray, w: Dict[str, np.ndarray], prefix: str, cfg: PathConfig,
         mode: str = "fp32", want_colsum: bool = False, want_probs: bool = False,
         kv_cached: Optional[Tuple[np.ndarray, np.ndarray]] = None):
     """``Attention.forward`` (MemoryController.py:47-57): q/k/v Linear, H heads, softmax(qk^T/sqrt d),
     P V, merge heads, Residual = LN(dense(ctx) + Xq).  Returns (out[R,D], colsum[Lk] | None, probs | None).
 
-    Emulation mode rounds: Q,K,V (stored), P (MFMA operand; row sum l from unrounded p),
-    ctx (stored), LN output (stored).  dense+bias+residual stays float32 into the LN.
+    Emulation mode rounds: Q,K,V (stored), P (MFMA operand, see attention_heads), ctx (stored), LN output
+    (stored).  dense+bias+residual stays float32 into the LN.
     """
     r = rounder(mode)
-    H, d, D = cfg.heads, cfg.head_dim, cfg.hidden
     Q = r(linear(Xq, w[f"{prefix}.q_proj.weight"], w[f"{prefix}.q_proj.bias"]))
     if kv_cached is None:
         K = r(linear(Xkv, w[f"{prefix}.k_proj.weight"], w[f"{prefix}.k_proj.bias"]))
         V = r(linear(Xkv, w[f"{prefix}.v_proj.weight"], w[f"{prefix}.v_proj.bias"]))
     else:
         K, V = kv_cached
-    R, Lk = Q.shape[0], K.shape[0]
-    ctx = np.empty((R, D), dtype=F32)
-    colsum = np.zeros(Lk, dtype=np.float64) if want_colsum else None
-    probs = np.empty((H, R, Lk), dtype=F32) if want_probs else None
-    scale = F32(1.0 / math.sqrt(d))
-    for h in range(H):
-        sl = slice(h * d, (h + 1) * d)
-        s = (Q[:, sl] @ K[:, sl].T).astype(F32) * scale          # MemoryController.py:51
-        s -= s.max(axis=1, keepdims=True)
-        p = np.exp(s, dtype=F32)
-        l = p.sum(axis=1, keepdims=True, dtype=F32)
-        if want_colsum or want_probs:
-            pn = p / l                                           # :52 normalised probabilities
-            if want_colsum:
-                colsum += pn.sum(axis=0, dtype=np.float64)       # :135 sum over heads and queries
-            if want_probs:
-                probs[h] = pn
-        ctx[:, sl] = (r(p) @ V[:, sl]) / l                       # :53 (P rounded as the MFMA operand)
+    ctx, _, colsum_h, probs = attention_heads(Q, K, V, cfg.heads, mode, want_colsum, want_probs)
+    colsum = colsum_h.astype(np.float64).sum(axis=0).astype(F32) if want_colsum else None   # :135 sum over heads
     ctx = r(ctx)
     pre = linear(ctx, w[f"{prefix}.residual.dense.weight"], w[f"{prefix}.residual.dense.bias"]) + Xq
     out = r(layernorm(pre, w[f"{prefix}.residual.layernorm.weight"],
                       w[f"{prefix}.residual.layernorm.bias"], cfg.eps))     # :26-29,55
-    return out, (colsum.astype(F32) if want_colsum else None), probs
+    return out, colsum, probs
 
 
 def project_kv(X: np.ndarray, w: Dict[str, np.ndarray], prefix: str, mode: str):

@@ -291,6 +291,12 @@ def g5_g6():
             pooled = lm.get_2dPool(T(feats[:2]))
             e2e["pool_in_seed"] = np.array(600 + F0)
             e2e["pooled_2"] = pooled.numpy()
+    # state-dict contract of the memory modules (names, shapes) as the reference builds them
+    sd_names = {k: list(v.shape) for k, v in lm.model.state_dict().items()
+                if k.split(".")[0] in ("recurrent_memory_transformer", "memory_fuser", "positional_encoding",
+                                       "token_type_embedding")}
+    with open(os.path.join(HERE, "g6_statedict.json"), "w") as f:
+        json.dump({"hidden": D, "keys": sd_names}, f, indent=0, sort_keys=True)
     save("g5_index.npz", meta=meta(note="torch.linspace/.long()/round index math"), **index_cases)
     save("g6_glue.npz", meta=meta(D=D, side=SIDE, wseed=61, embseed=62, emb_rows=rows, text_ids=text_ids,
                                    featseed0=600, rowsteps={"8": 1, "70": 13, "330": 29}), **e2e)

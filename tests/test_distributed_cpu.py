@@ -1,0 +1,68 @@
+"""World-size-2 gloo test of the multi-GPU host logic (video sharding + all-gather of the final memory state)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from memory_augmented_vlm_amd import distributed as D
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_videos, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, w, _ = D.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    mine = list(D.shard_range(n_videos, r, w))
+    # stand-in for the final memory state of the last video this rank processed: [M,P,D] filled with its video id
+    state = torch.full((2, 3, 4), float(mine[-1] if mine else -1))
+    out, work = D.all_gather_memory_state(state, async_op=True)
+    work.wait()
+    flag = torch.zeros(1)
+    if r == 0:
+        flag.fill_(1.0)
+    dist.broadcast(flag, src=0)          # the reference's only hot-path collective (llava_arch.py:378-386)
+    q.put((rank, mine, out[:, 0, 0, 0].tolist(), float(flag)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_videos", [5, 2])
+def test_shard_and_allgather_world2(n_videos):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_videos, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    all_ids = res[0][1] + res[1][1]
+    assert all_ids == list(range(n_videos))                      # disjoint, complete, ordered
+    expect = [float(res[0][1][-1]), float(res[1][1][-1])]
+    assert res[0][2] == expect and res[1][2] == expect           # both ranks see both states
+    assert res[0][3] == res[1][3] == 1.0
+
+
+def test_shard_range_properties():
+    for n in range(0, 20):
+        for w in (1, 2, 3, 8):
+            parts = [list(D.shard_range(n, r, w)) for r in range(w)]
+            assert sum(parts, []) == list(range(n))
+            assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def test_single_process_gather_is_identity():
+    s = torch.arange(24.).reshape(2, 3, 4)
+    out, work = D.all_gather_memory_state(s)
+    assert work is None and torch.equal(out[0], s)

@@ -1,0 +1,153 @@
+"""-m gpu: operator-level parity of the HIP kernels (through the C ABI) against the CPU oracle.
+
+Gates: exact for integer-valued data (fp32 accumulation of small integers is exact);
+rel-L2 <= 1e-3 against the oracle in operand-rounding-emulation mode for random data."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import memory_augmented_vlm_amd  # noqa: F401
+from memory_augmented_vlm_amd import _capi as capi
+from memory_augmented_vlm_amd import _ops as ops
+from oracle import memory_path as O
+from gpu_util import to_dev, to_np, f32_dev
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _int_mat(shape, seed, lo=-4, hi=4):
+    return np.floor(O.hash_uniform(shape, seed, lo, hi + 0.999)).astype(np.float32)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K", [(16, 128, 64), (200, 256, 192), (129, 128, 1024), (1, 384, 64)])
+def test_linear_integer_exact(mode, M, N, K):
+    """A = I-like / asymmetric integer data: catches any row/col swap in the fragment or C maps exactly."""
+    A = _int_mat((M, K), 1)
+    W = _int_mat((N, K), 2)
+    W[:, 0] += np.arange(N) % 5          # asymmetric
+    b = _int_mat((N,), 3).astype(np.float32)
+    ref = A @ W.T + b
+    res = _int_mat((M, N), 4)
+    out = ops.linear(to_dev(A, mode), to_dev(W, mode), f32_dev(b), capi.EPI_RES_F32, residual=to_dev(res, mode))
+    np.testing.assert_array_equal(to_np(out), ref + res)
+    out_relu = ops.linear(to_dev(A, mode), to_dev(W, mode), f32_dev(b), capi.EPI_RELU)
+    r = O.rounder(mode)
+    np.testing.assert_array_equal(to_np(out_relu), r(np.maximum(ref, 0)))
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(1568, 1024, 1024, "bias"), (588, 4096, 1024, "bias"), (777, 512, 4096, "gelu"),
+                                       (300, 4096, 1024, "relu")])
+def test_linear_random_vs_oracle(M, N, K, epi):
+    r = O.bf16_round
+    A = r(O.hash_normal_like((M, K), 11))
+    W = r(O.hash_uniform((N, K), 12, -1 / math.sqrt(K), 1 / math.sqrt(K)))
+    b = r(O.hash_uniform((N,), 13, -0.1, 0.1))
+    y = O.linear(A, W, b)
+    code = {"bias": capi.EPI_BIAS, "relu": capi.EPI_RELU, "gelu": capi.EPI_GELU}[epi]
+    if epi == "relu":
+        y = np.maximum(y, 0)
+    elif epi == "gelu":
+        y = O.gelu_erf(y)
+    got = to_np(ops.linear(to_dev(A), to_dev(W), f32_dev(b), code))
+    assert O.rel_l2(got, r(y)) < TOL
+
+
+def _attn_oracle(q, k, v, H, mode="bf16"):
+    """ctx (rounded to the 16-bit grid), lse2 [H,R], per-head column sums [H,S] from the oracle's emulation of the
+    kernel (64-key tiles, running maximum, P rounded per tile)."""
+    ctx, lse2, col, _ = O.attention_heads(q, k, v, H, mode, want_colsum=True)
+    return O.rounder(mode)(ctx), lse2, col
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("R,S,H", [(32, 64, 1), (200, 300, 2), (128, 64 * 5 + 1, 1), (392, 588, 8), (1, 1, 1)])
+def test_attention_vs_oracle(mode, R, S, H):
+    r = O.rounder(mode)
+    q = r(O.hash_normal_like((R, H * 128), 21))
+    k = r(O.hash_normal_like((S, H * 128), 22))
+    v = r(O.hash_normal_like((S, H * 128), 23))
+    ctx, lse2, col = _attn_oracle(q, k, v, H, mode)
+    got, lse = ops.attention(to_dev(q, mode), to_dev(k, mode), to_dev(v, mode), H, want_lse=True)
+    assert O.rel_l2(to_np(got), ctx) < TOL
+    np.testing.assert_allclose(to_np(lse), lse2, rtol=0, atol=2e-3)
+    part = ops.attention_colsum(to_dev(q, mode), to_dev(k, mode), lse, H)
+    assert O.rel_l2(to_np(part), col) < TOL
+    # size-independent property: every softmax row sums to one -> all column sums add up to H*R
+    assert abs(float(part.sum()) - H * R) < 1e-3 * H * R
+
+
+def test_attention_strided_kv_and_identity_v():
+    """K/V as column slices of a wider [S, 4D] buffer (how the step lays them out) and V = one-hot columns:
+    ctx then equals the probabilities themselves - catches any key/column permutation error in the P.V MFMA."""
+    R, S, H = 64, 128, 2
+    r = O.bf16_round
+    q = r(O.hash_normal_like((R, H * 128), 31))
+    kvbuf = np.zeros((S, 4 * H * 128), np.float32)
+    k = r(O.hash_normal_like((S, H * 128), 32))
+    v = np.zeros((S, H * 128), np.float32)
+    for h in range(H):
+        v[np.arange(S), h * 128 + (np.arange(S) * 7 + 3 * h) % 128] = 1.0      # asymmetric one-hot
+    kvbuf[:, :H * 128] = k
+    kvbuf[:, 2 * H * 128:3 * H * 128] = v
+    t = to_dev(kvbuf)
+    got, _ = ops.attention(to_dev(q), t[:, :H * 128], t[:, 2 * H * 128:3 * H * 128], H)
+    ctx, _, _ = _attn_oracle(q, k, v, H)
+    assert O.rel_l2(to_np(got), ctx) < TOL
+
+
+def test_attention_forced_rescale():
+    """Rule 26: force the online-softmax rescale branch - one key in a LATE tile dominates one query row."""
+    R, S, H = 64, 64 * 6, 1
+    r = O.bf16_round
+    q = r(O.hash_normal_like((R, 128), 41))
+    k = r(O.hash_normal_like((S, 128), 42))
+    v = r(O.hash_normal_like((S, 128), 43))
+    k[64 * 4 + 17] = r(q[5] * 4.0)      # spike in tile 4 for query 5
+    k[64 * 5 + 63] = r(q[40] * 6.0)     # spike in the last tile for query 40
+    ctx, lse2, _ = _attn_oracle(q, k, v, H)
+    got, lse = ops.attention(to_dev(q), to_dev(k), to_dev(v), H, want_lse=True)
+    assert O.rel_l2(to_np(got), ctx) < TOL
+    assert np.abs(to_np(got)[[5, 40]] - ctx[[5, 40]]).max() < 2e-2
+    np.testing.assert_allclose(to_np(lse), lse2, rtol=0, atol=5e-3)
+
+
+@pytest.mark.parametrize("D", [128, 256, 896, 1024, 3584])
+def test_layernorm_vs_oracle(D):
+    rows = 37
+    x = O.hash_normal_like((rows, D), 51) * 3.0 + 0.5
+    g = 1.0 + O.hash_uniform((D,), 52, -0.1, 0.1)
+    b = O.hash_uniform((D,), 53, -0.1, 0.1)
+    ref = O.bf16_round(O.layernorm(x, g, b, 1e-12))
+    got = to_np(ops.layernorm(f32_dev(x), f32_dev(g), f32_dev(b), 1e-12, torch.bfloat16))
+    assert O.rel_l2(got, ref) < 2e-4
+    # constant rows: var = 0 -> rsqrt(0 + 1e-12) finite, output = beta
+    xc = np.full((4, D), 2.5, np.float32)
+    gc = to_np(ops.layernorm(f32_dev(xc), f32_dev(g), f32_dev(b), 1e-12, torch.bfloat16))
+    np.testing.assert_array_equal(gc, O.bf16_round(np.broadcast_to(b, (4, D))))
+
+
+def test_row_add_exact():
+    T, P, D = 9, 196, 256
+    x = O.bf16_round(O.hash_normal_like((T, P, D), 61))
+    table = O.bf16_round(O.hash_normal_like((50, D), 62))
+    idx = np.array([0, 49, 7, 7, 13, 2, 48, 1, 30])
+    ref = O.bf16_round(x + table[idx][:, None, :])
+    got = ops.row_add(to_dev(x), to_dev(table), idx=torch.from_numpy(idx).cuda())
+    np.testing.assert_array_equal(to_np(got), ref)
+    src = np.array([8, 0, 3])
+    got2 = ops.row_add(to_dev(x), to_dev(table[5:6]), src=torch.from_numpy(src).cuda())
+    np.testing.assert_array_equal(to_np(got2), O.bf16_round(x[src] + table[5][None, None, :]))
+    assert ops.row_add(to_dev(x[:0]), to_dev(table), idx=torch.zeros(0, dtype=torch.int64).cuda()).shape[0] == 0
+
+
+def test_bad_arguments_fail_loudly():
+    a = to_dev(np.zeros((4, 64), np.float32))
+    w = to_dev(np.zeros((100, 64), np.float32))     # N not a multiple of 128
+    with pytest.raises(capi.MavlmError):
+        ops.linear(a, w, f32_dev(np.zeros(100, np.float32)))
+    with pytest.raises(capi.MavlmError):
+        ops.linear(a.cpu(), w.cpu(), torch.zeros(100))

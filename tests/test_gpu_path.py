@@ -1,0 +1,355 @@
+"""-m gpu: parity of the fused recurrent-memory path (mavlm_step / mavlm_fuse_emit through the reference-shaped
+modules) against the CPU oracle in emulation mode, against golden vectors of the reference itself (G7), and
+size-independent properties at the BASELINE sizes."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import memory_augmented_vlm_amd  # noqa: F401
+from memory_augmented_vlm_amd import _capi as capi
+from memory_augmented_vlm_amd.model.memory_module.MemoryController import Config, TransformerProjector
+from memory_augmented_vlm_amd.model.memory_module.position_encoding import TemporalPositionalEncoding
+from memory_augmented_vlm_amd.model import llava_arch as arch
+from oracle import memory_path as O
+from conftest import load_golden
+from gpu_util import to_dev, to_np, load_oracle_weights, DT
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3            # GPU vs oracle in operand-rounding-emulation mode (primary gate)
+TOL_REF_FP32 = 1.2e-2  # GPU bf16 vs the reference's own fp32 run; the reference's bf16 run sits at 4.8e-3..8.4e-3
+
+
+def chain_tol(floor):
+    """Tolerance for a CHAIN of 16-bit-rounded stages.  Single stages match the oracle to ~1e-4 (see
+    test_gpu_ops.py and test_step_stagewise_teacher_forced); along a chain two correct implementations
+    decorrelate at every storage rounding (a perturbation d << ulp becomes ~sqrt(d*ulp)), so the gate is the larger
+    of 1e-3 and twice the measured noise floor = the oracle against itself with float64 accumulation."""
+    return max(TOL, 2.0 * floor)
+
+
+def run_oracle_steps(cfg, w, mode, segs, acc, cap=None):
+    with O.accumulate_in(acc):
+        rm = O.RecurrentMemory(cfg, w, mode)
+        rm.reset()
+        outs = []
+        for seg in segs:
+            cache, scores = rm.step(seg)
+            outs.append(([c.copy() for c in cache], scores[-1].copy()))
+    return outs
+
+
+def make_projector(cfg: O.PathConfig, w, mode="bf16", cache_cap=10):
+    c = Config()
+    c.mm_hidden_size = cfg.hidden
+    c.mm_intermediate_size = cfg.inter
+    c.mm_num_attention_heads = cfg.heads
+    c.num_memory_tokens = cfg.mem_tokens
+    c.patch_size = cfg.patches
+    c.depth = cfg.depth
+    c.mm_layer_norm_eps = cfg.eps
+    c.mm_dtype = torch.float32
+    c.cache_cap = cache_cap
+    m = TransformerProjector(c).eval()
+    pfx = "recurrent_memory_transformer."
+    n = load_oracle_weights(m, {k[len(pfx):]: v for k, v in w.items() if k.startswith(pfx)})
+    assert n == len(m.state_dict())
+    return m.to("cuda").to(DT[mode])
+
+
+@pytest.mark.parametrize("mode,H,M,frames", [("bf16", 8, 8, [3, 2, 3, 1]), ("fp16", 2, 4, [2, 1, 2]), ("bf16", 1, 3, [1, 1])])
+def test_recurrent_steps_vs_oracle(mode, H, M, frames):
+    cfg = O.PathConfig(hidden=128 * H, heads=H, mem_tokens=M, depth=2)
+    w = O.make_weights(cfg, seed=5, grid=mode)
+    proj = make_projector(cfg, w, mode)
+    r = O.rounder(mode)
+    segs = [r(O.hash_normal_like((f, 196, cfg.hidden), 900 + t)) for t, f in enumerate(frames)]
+    ref = run_oracle_steps(cfg, w, mode, segs, np.float32)
+    alt = run_oracle_steps(cfg, w, mode, segs, np.float64)
+    proj.memory_cache = []
+    with torch.no_grad():
+        for t, seg in enumerate(segs):
+            cache, scores = proj(to_dev(seg, mode))
+            ocache, oscores = ref[t]
+            assert len(cache) == len(ocache) == t + 1
+            floor = O.rel_l2(alt[t][0][-1], ocache[-1])
+            err = O.rel_l2(to_np(cache[-1]), ocache[-1])
+            print(f"{mode} H={H} step {t}: HIP vs oracle {err:.2e}, oracle f64-acc vs f32-acc (floor) {floor:.2e}")
+            assert err < chain_tol(floor), (t, err, floor)
+            if mode == "fp16":
+                assert err < TOL        # the finer grid keeps the whole chain under the flat 1e-3 gate
+            for i in range(len(cache) - 1):       # older entries are untouched views of the ring
+                assert O.rel_l2(to_np(cache[i]), ref[i][0][-1]) < chain_tol(O.rel_l2(alt[i][0][-1], ref[i][0][-1]))
+            assert tuple(cache[-1].shape) == (M, 196, cfg.hidden)
+            assert O.rel_l2(to_np(scores[-1]), oscores) < 5e-3   # scores are stored in the 16-bit model dtype
+            # property (MemoryController.py:135-139): sum_f score_f = H * R / P
+            assert abs(float(scores[-1].float().sum()) - H * M) < 2e-2 * H * M
+
+
+def test_step_stagewise_teacher_forced():
+    """Every stage INSIDE the fused mavlm_step against the oracle fed with the GPU's own inputs to that stage
+    (read back from the workspace after the step).  Tight gate: <= 1e-3 per stage, expected ~1e-4."""
+    H, M, mode = 8, 8, "bf16"
+    cfg = O.PathConfig(hidden=1024, heads=H, mem_tokens=M, depth=2)
+    D, R = cfg.hidden, cfg.mem_rows
+    w = O.make_weights(cfg, seed=12)
+    proj = make_projector(cfg, w, mode)
+    r = O.bf16_round
+    segs = [r(O.hash_normal_like((f, 196, D), 1200 + t)) for t, f in enumerate((3, 2))]
+    proj.memory_cache = []
+    with torch.no_grad():
+        for seg in segs:
+            cache, scores = proj(to_dev(seg))
+    torch.cuda.synchronize()
+    eng = proj.engine(torch.device("cuda", 0), torch.bfloat16)
+    ws = {k: to_np(v) if v.dtype != torch.float32 else v.cpu().numpy() for k, v in eng.workspace_views().items()}
+    S = 2 * 196
+    x = segs[1].reshape(S, D)
+    T = "recurrent_memory_transformer"
+    errs = {}
+
+    def lin(xin, name):
+        return O.linear(xin, w[f"{name}.weight"], w[f"{name}.bias"])
+
+    # chunk K/V for both layers (one GEMM on the GPU)
+    kv = ws["kv_seg"][:S]
+    for l in range(2):
+        a_ = f"{T}.layers.{l}.memory_segment_fusion_attention"
+        errs[f"K{l}"] = O.rel_l2(kv[:, (2 * l) * D:(2 * l + 1) * D], r(lin(x, a_ + ".k_proj")))
+        errs[f"V{l}"] = O.rel_l2(kv[:, (2 * l + 1) * D:(2 * l + 2) * D], r(lin(x, a_ + ".v_proj")))
+    # evolution (t=1): newest = cache[0]; its K|V projection sits in ring slot 0; output = mA
+    newest = to_np(cache[0]).reshape(R, D)
+    evo = f"{T}.memory_update_attention"
+    ekv = to_np(eng.evo_kv[0])
+    errs["evoK"] = O.rel_l2(ekv[:, :D], r(lin(newest, evo + ".k_proj")))
+    errs["evoV"] = O.rel_l2(ekv[:, D:], r(lin(newest, evo + ".v_proj")))
+    mA, _, _ = O.mha(newest, None, w, evo, cfg, mode, kv_cached=(ekv[:, :D], ekv[:, D:]))
+    errs["evolved(q,attn,dense,LN)"] = O.rel_l2(ws["mA"], mA)
+    # last formation layer (l=1): its input is mB (layer-0 output)
+    cur = ws["mB"]
+    a1 = f"{T}.layers.1.memory_segment_fusion_attention"
+    errs["q"] = O.rel_l2(ws["q"], r(lin(cur, a1 + ".q_proj")))
+    K1, V1 = kv[:, 2 * D:3 * D], kv[:, 3 * D:4 * D]
+    ctx, lse2, col, _ = O.attention_heads(ws["q"], K1, V1, H, mode, want_colsum=True)
+    errs["ctx"] = O.rel_l2(ws["ctx"], r(ctx))
+    errs["lse2"] = float(np.abs(ws["lse2"] - lse2).max())
+    pre_a = lin(ws["ctx"], a1 + ".residual.dense") + cur
+    errs["a(LN)"] = O.rel_l2(ws["a"], r(O.layernorm(pre_a, w[a1 + ".residual.layernorm.weight"],
+                                                  w[a1 + ".residual.layernorm.bias"], cfg.eps)))
+    errs["h(relu)"] = O.rel_l2(ws["h"], r(np.maximum(lin(ws["a"], f"{T}.layers.1.mlp.0"), 0)))
+    errs["pre(fp32)"] = O.rel_l2(ws["pre"], lin(ws["h"], f"{T}.layers.1.residual.dense") + ws["a"])
+    errs["m_out(LN)"] = O.rel_l2(to_np(cache[-1]).reshape(R, D),
+                                 r(O.layernorm(ws["pre"], w[f"{T}.layers.1.residual.layernorm.weight"],
+                                               w[f"{T}.layers.1.residual.layernorm.bias"], cfg.eps)))
+    part = eng.workspace_views()["part"].reshape(-1)[:H * S].view(H, S).cpu().numpy()
+    errs["colsum"] = O.rel_l2(part, col)
+    errs["scores"] = O.rel_l2(to_np(scores[-1]), r(col.sum(0).reshape(2, 196).mean(1)))
+    print({k: f"{v:.1e}" for k, v in errs.items()})
+    for k, v in errs.items():
+        lim = {"pre(fp32)": 1e-5, "lse2": 1e-4, "scores": 4e-3}.get(k, TOL)
+        assert v < lim, (k, v)
+    # layer 0 as a whole (7 rounded stages): calibrated chain gate
+    with O.accumulate_in(np.float32):
+        l0, _ = O.transformer_layer(ws["mA"], x, w, f"{T}.layers.0", cfg, mode, False)
+    with O.accumulate_in(np.float64):
+        l0b, _ = O.transformer_layer(ws["mA"], x, w, f"{T}.layers.0", cfg, mode, False)
+    assert O.rel_l2(cur, l0) < chain_tol(O.rel_l2(l0b, l0))
+
+
+def test_fifo_eviction_vs_oracle():
+    H, M, cap = 1, 2, 3
+    cfg = O.PathConfig(hidden=128, heads=H, mem_tokens=M, depth=2, cache_cap=cap)
+    w = O.make_weights(cfg, seed=6)
+    proj = make_projector(cfg, w, cache_cap=cap)
+    segs = [O.bf16_round(O.hash_normal_like((1 + t % 2, 196, 128), 950 + t)) for t in range(6)]
+    ref = run_oracle_steps(cfg, w, "bf16", segs, np.float32)
+    alt = run_oracle_steps(cfg, w, "bf16", segs, np.float64)
+    proj.memory_cache = []
+    with torch.no_grad():
+        for t, seg in enumerate(segs):
+            cache, _ = proj(to_dev(seg))
+            ocache = ref[t][0]
+            assert len(cache) == len(ocache) == min(t + 1, cap)
+            for i in range(len(cache)):      # age order, oldest first
+                floor = O.rel_l2(alt[t][0][i], ocache[i])
+                assert O.rel_l2(to_np(cache[i]), ocache[i]) < chain_tol(floor), (t, i)
+    # reset protocol: assigning [] restarts from the initial memory
+    proj.memory_cache = []
+    rm = O.RecurrentMemory(cfg, w, "bf16")
+    rm.reset()
+    with torch.no_grad():
+        seg = O.bf16_round(O.hash_normal_like((2, 196, 128), 999))
+        cache, _ = proj(to_dev(seg))
+        ocache, _ = rm.step(seg)
+    assert len(cache) == 1 and O.rel_l2(to_np(cache[0]), ocache[0]) < chain_tol(0.0) * 1.5
+    with pytest.raises(capi.MavlmError):
+        proj.memory_cache = [cache[0]]
+
+
+@pytest.mark.parametrize("tag,M,F,steps", [("m8f32", 8, 32, 3), ("m64f8", 64, 8, 1)])
+def test_golden_g7_reference_fullsize(tag, M, F, steps):
+    """Against outputs of the reference itself (fp32 CPU run, D=1024): strided samples, norms, frame scores."""
+    z, m = load_golden("g7_fullsize.npz")
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=M, depth=2)
+    w = O.make_weights(cfg, seed=m["wseed"])
+    proj = make_projector(cfg, w)
+    proj.memory_cache = []
+    with torch.no_grad():
+        for t in range(steps):
+            seg = O.bf16_round(O.hash_normal_like((F, 196, 1024), m["segseed0"] + t))
+            cache, scores = proj(to_dev(seg))
+            mem = to_np(cache[-1]).reshape(-1)
+            ref = z[f"{tag}_s{t}_sample"]
+            err = O.rel_l2(mem[::m["stride"]], ref)
+            err_refbf16 = O.rel_l2(z[f"{tag}_s{t}_sample_refbf16"], ref)
+            print(f"{tag} step {t}: HIP-bf16 vs ref-fp32 {err:.2e}; reference-bf16 vs ref-fp32 {err_refbf16:.2e}")
+            assert err < TOL_REF_FP32
+            assert err < 1.5 * err_refbf16 + 1e-3        # inside the reference's own bf16 envelope
+            assert abs(np.linalg.norm(mem.astype(np.float64)) / float(z[f"{tag}_s{t}_norm"]) - 1) < 5e-3
+            assert O.rel_l2(to_np(scores[-1]), z[f"{tag}_s{t}_scores"]) < 1e-2
+
+
+def _tiny_host(cfg: O.PathConfig, w, mode="bf16", vocab=48900):
+    # LlavaMetaModel calls super().__init__(config): give it a base that accepts it
+    class Base(torch.nn.Module):
+        def __init__(self, config):
+            super().__init__()
+            self.embed_tokens = torch.nn.Embedding(vocab, config.hidden_size)
+
+    class Model(arch.LlavaMetaModel, Base):
+        pass
+
+    hf = types.SimpleNamespace(hidden_size=cfg.hidden, num_memory_tokens=cfg.mem_tokens, mm_patch_merge_type="spatial_unpad",
+                               mm_newline_position="one_token", mm_spatial_pool_mode="bilinear",
+                               tokenizer_model_max_length=32768, tokenizer_padding_side="right")
+    model = Model(hf).eval()
+    model.image_newline = torch.nn.Parameter(torch.zeros(cfg.hidden))
+    load_oracle_weights(model, w)
+    return model.to("cuda").to(DT[mode]), hf
+
+
+def test_video_tokens_vs_oracle():
+    """PE add -> 2 chunks (32 + 8 frames, evolution) -> fuser + type add + concat, whole block vs the oracle."""
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=8)
+    model, _ = _tiny_host(cfg, w)
+    rows = sorted(set(O.MEM_PROMPT_IDS + O.FRAME_PROMPT_IDS))
+    emb = np.zeros((48900, 1024), np.float32)
+    emb[rows] = O.bf16_round(O.hash_normal_like((len(rows), 1024), 81, 0.02))
+    with torch.no_grad():
+        model.embed_tokens.weight.copy_(to_dev(emb))
+    T = 40
+    x = O.bf16_round(O.hash_normal_like((T, 196, 1024), 82))
+    idx = O.subsample_indices(45)[:T]
+    toks, parts = O.video_tokens(x, idx, cfg, w, emb, "bf16", return_parts=True)
+    with O.accumulate_in(np.float64):
+        toks64 = O.video_tokens(x, idx, cfg, w, emb, "bf16")
+    dev = "cuda"
+    mp = model.embed_tokens(torch.tensor(O.MEM_PROMPT_IDS, device=dev))
+    fp = model.embed_tokens(torch.tensor(O.FRAME_PROMPT_IDS, device=dev))
+    got, info = arch.video_memory_tokens(model, to_dev(x), torch.from_numpy(idx), mp, fp, model.image_newline)
+    assert got.shape[0] == toks.shape[0] == 10 + 2 * 1568 + 1 + 9 + 32 * 196 + 1
+    g = to_np(got)
+    assert O.rel_l2(to_np(info["pe_frames"]), parts["pe"]) < 1e-6
+    a, b = info["memory_rows"]
+    floor = O.rel_l2(toks64[a:b], toks[a:b])
+    err = O.rel_l2(g[a:b], toks[a:b])
+    print(f"fused memory tokens: HIP vs oracle {err:.2e}, noise floor {floor:.2e}")
+    assert err < chain_tol(floor)
+    np.testing.assert_array_equal(g[:a], toks[:a])                         # prompt rows are copies
+    assert O.rel_l2(g[b:], toks[b:]) < 1e-6                                # newline, prompt, fine frames (+E1)
+    # frame-dropout branch: memory half only
+    got2, _ = arch.video_memory_tokens(model, to_dev(x), torch.from_numpy(idx), mp, fp, model.image_newline,
+                                       with_frames=False)
+    assert got2.shape[0] == b + 1 and torch.equal(got2, got[:b + 1])       # deterministic + same prefix
+    with pytest.raises(ValueError, match="exceed max_frames"):
+        arch.video_memory_tokens(model, to_dev(x[:2]), torch.tensor([0, 600]), mp, fp, model.image_newline)
+
+
+def test_prepare_inputs_end_to_end_vs_oracle():
+    """The reference-shaped outer API on a toy host: fake vision tower -> 2x2 bilinear pool -> memory path ->
+    splice into the text sequence; compared against the oracle pipeline fed the same features."""
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=9)
+    model, hf = _tiny_host(cfg, w)
+    side, F0, D = 27, 40, 1024
+    rows = sorted(set(O.MEM_PROMPT_IDS + O.FRAME_PROMPT_IDS + [11, 22, 33, 44]))
+    emb = np.zeros((48900, D), np.float32)
+    emb[rows] = O.bf16_round(O.hash_normal_like((len(rows), D), 91, 0.02))
+    feats = O.bf16_round(O.hash_normal_like((F0, side * side, D), 92))
+    with torch.no_grad():
+        model.embed_tokens.weight.copy_(to_dev(emb))
+    table = to_dev(feats)
+
+    class Tower(torch.nn.Module):
+        num_patches_per_side = side
+
+        def forward(self, images):
+            return table[images.reshape(-1).long()]
+
+    model.vision_tower = Tower()
+    model.mm_projector = torch.nn.Identity()
+
+    class LM(arch.LlavaMetaForCausalLM, torch.nn.Module):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.config = hf
+            self.model = model
+
+        def get_model(self):
+            return self.model
+
+        @property
+        def device(self):
+            return torch.device("cuda")
+
+    lm = LM().eval()
+    ids = torch.tensor([[11, 22, arch.IMAGE_TOKEN_INDEX, 33, 44]], device="cuda")
+    labels = torch.tensor([[-100, -100, -100, 33, 44]], device="cuda")
+    am = torch.ones_like(ids)
+    images = [torch.arange(F0, dtype=torch.float32, device="cuda").reshape(F0, 1, 1, 1)]
+    with torch.no_grad():
+        out = lm.prepare_inputs_labels_for_multimodal(ids, None, am, None, labels, images, modalities=["video"])
+    none_ids, pos, mask, pkv, embeds, labs = out
+    assert none_ids is None and pos is None and pkv is None
+    # oracle pipeline (bf16 emulation); the pooled features come from the GPU pool so that only the path is compared
+    idx = O.subsample_indices(F0)
+    assert len(idx) == 64
+    pooled = to_np(lm.get_2dPool(table[torch.from_numpy(idx).cuda()]))
+    assert O.rel_l2(pooled, O.bf16_round(O.bilinear_pool(feats[idx], side))) < 3e-3     # torch bf16 interpolate
+    toks = O.video_tokens(pooled, idx, cfg, w, emb, "bf16")
+    with O.accumulate_in(np.float64):
+        toks64 = O.video_tokens(pooled, idx, cfg, w, emb, "bf16")
+    e, lab, msk, pid = O.splice(to_np(ids).astype(np.int64), to_np(labels).astype(np.int64), np.ones((1, 5)), toks,
+                                O.bf16_round(emb), max_len=32768)
+    assert tuple(embeds.shape) == e.shape
+    assert O.rel_l2(to_np(embeds)[0, 2:-2], e[0, 2:-2]) < chain_tol(O.rel_l2(toks64, toks))
+    np.testing.assert_array_equal(labs.cpu().numpy(), lab)
+    assert bool(mask.all())
+
+
+def test_baseline_size_properties():
+    """BASELINE config 2 sizes (64 frames, 64 memory tokens, D=1024): properties that need no CPU oracle run."""
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=64, depth=2)
+    w = O.make_weights(cfg, seed=10)
+    model, _ = _tiny_host(cfg, w)
+    x = to_dev(O.bf16_round(O.hash_normal_like((64, 196, 1024), 101)))
+    idx = torch.arange(64)
+    mp = torch.zeros((10, 1024), device="cuda", dtype=torch.bfloat16)
+    fp = torch.ones((9, 1024), device="cuda", dtype=torch.bfloat16)
+    a, info = arch.video_memory_tokens(model, x, idx, mp, fp, model.image_newline)
+    b, _ = arch.video_memory_tokens(model, x, idx, mp, fp, model.image_newline)
+    assert torch.equal(a, b)                                   # idempotent / deterministic, state fully reset
+    R = 64 * 196
+    assert a.shape[0] == 10 + 2 * R + 1 + 9 + 32 * 196 + 1
+    assert torch.isfinite(a.float()).all()
+    rm = model.recurrent_memory_transformer
+    for s in rm.frame_attn_scores[-2:]:
+        assert abs(float(s.float().sum()) - 8 * 64) < 0.02 * 8 * 64          # sum_f score_f = H*R/P
+    mem = torch.stack(list(rm.memory_cache)).float()           # LayerNorm output: per-row mean/var of (y-beta)/gamma
+    g = rm.layers[1].residual.layernorm.weight.float()
+    bb = rm.layers[1].residual.layernorm.bias.float()
+    z = (mem - bb) / g
+    assert float(z.mean(-1).abs().max().detach()) < 2e-2
+    assert float((z.var(-1, unbiased=False) - 1).abs().max().detach()) < 5e-2
