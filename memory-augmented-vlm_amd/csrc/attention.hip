@@ -32,6 +32,7 @@ constexpr int KT = 64;              // keys per tile
 constexpr int TILE = KT * HD * 2;   // 16 KiB
 constexpr int ATTN_LDS = 4 * TILE;  // 2 stages x (K,V)
 constexpr int CS_LDS = 2 * TILE;    // 2 stages x Q
+constexpr float RESCALE_LOG2 = 8.0f;   // deferred-rescale threshold in log2 units (mirrored by the oracle)
 
 __device__ __forceinline__ int img_x(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
@@ -40,13 +41,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
                                                           const uint16_t* __restrict__ K, int ldk,
                                                           const uint16_t* __restrict__ V, int ldv,
                                                           uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
-                                                          int R, int S, float c /* scale*log2(e) */) {
+                                                          int R, int S, int H, float c /* scale*log2(e) */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // 1-D grid: head = bid % H.  Blocks b and b+8 share an XCD (round-robin dispatch), so with H = 8 every XCD's L2
+  // serves the K/V of ONE head (3.2 MB at S = 6272) instead of all of them.  Speed only.
+  const int h = blockIdx.x % H;
+  const int q0 = (blockIdx.x / H) * 128 + wave * 32;
   const int r = lane & 31, hh = lane >> 5;
 
   // ---- Q fragments: B operand, lane holds Q[q0+r][h*128 + 16ks + 8hh + 0..7]
@@ -102,11 +105,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
   const int nt = (S + KT - 1) / KT;
   load_tile(0);
   store_tile(0);
+  // Pin the loop-invariant Q fragments in registers BEFORE the loop: left alone, hipcc sinks their loads to the
+  // loop entry and then carries counted vmcnt waits for them into the QK^T chain, where (vmcnt counts in issue
+  // order) they end up waiting for the NEXT tile's loads on every iteration.
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
   __syncthreads();
 
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
-    if (t + 1 < nt) load_tile(t + 1);
+    if (t + 1 < nt) load_tile(t + 1);     // lands during this tile's compute; written to LDS at the end
     const char* kb = smem + cur * 2 * TILE;
     const unsigned vb = (unsigned)(uintptr_t)(MAVLM_LDS const char*)(kb + TILE);   // LDS byte address of the V image
 
@@ -140,11 +148,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[b][i]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = xhalf_max(mx);
+    // Deferred rescale (cdna_hip_programming.md T13): the running reference m_run only moves when some query of this
+    // wave saw its maximum grow by more than 2^RESCALE_LOG2; otherwise P stays relative to the old reference
+    // (p <= 2^RESCALE_LOG2, harmless in 16-bit floating point) and the O / l rescale is skipped.  The decision is
+    // wave-uniform and taken BEFORE this tile's P is exponentiated, so everything is scaled exactly once.
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
-    m_run = m_new;
+    if (__any((m_new - m_run) * c > RESCALE_LOG2)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ot[d][i] *= alpha;
+    }
+    const float mc = m_run * c;
     float psum = 0.f;
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -154,11 +173,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
         st[b][i] = p;
         psum += p;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) ot[d][i] *= alpha;
+    l_run += psum;
 
     // ---- P^T fragments (B operand): registers 8s..8s+7 of key block b
     typename T::vec8 pf[2][2];
@@ -168,8 +183,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
       for (int s = 0; s < 2; ++s) {
         u32x4 w;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          w[j] = (unsigned)T::from_f32(st[b][8 * s + 2 * j]) | ((unsigned)T::from_f32(st[b][8 * s + 2 * j + 1]) << 16);
+        for (int j = 0; j < 4; ++j) w[j] = pack2<T>(st[b][8 * s + 2 * j], st[b][8 * s + 2 * j + 1]);
         pf[b][s] = __builtin_bit_cast(typename T::vec8, w);
       }
 
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
   }
 
   // ---- epilogue: O[q][h*128 + 32db + 8g + 4hh + 0..3] = O^T / l
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float l_tot = xhalf_sum(l_run);
   const float inv = 1.0f / l_tot;
   const int q = q0 + r;
   if (q < R) {
@@ -217,13 +231,13 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_colsum_kernel(const uint16_t* __restrict__ Q, int ldq,
                                                              const uint16_t* __restrict__ K, int ldk,
                                                              const float* __restrict__ lse2, float* __restrict__ part,
-                                                             int R, int S, float c) {
+                                                             int R, int S, int H, float c) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = blockIdx.y;
-  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int h = blockIdx.x % H;
+  const int k0 = (blockIdx.x / H) * 128 + wave * 32;
   const int r = lane & 31, hh = lane >> 5;
 
   typename T::vec8 kf[8];
@@ -263,6 +277,8 @@ __global__ __launch_bounds__(256, 2) void attn_colsum_kernel(const uint16_t* __r
   const int nt = (R + KT - 1) / KT;
   load_tile(0);
   store_tile(0);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(kf[ks]));   // K fragments resident (see attn_fwd_kernel)
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
@@ -338,18 +354,18 @@ hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream
   if (!attn_args_ok(a.Q, a.ldq, a.K, a.ldk, a.R, a.S, a.H) || !a.V || !a.O || (a.ldv & 7) || (a.ldo & 3))
     return hipErrorInvalidValue;
   const float c = a.scale * 1.44269504088896340736f;
-  dim3 grid((a.R + 127) / 128, a.H);
+  dim3 grid(((a.R + 127) / 128) * a.H);
   mavlm_prof_scope prof(MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD,
                         2.0 * HD * a.H * (2.0 * a.R + 2.0 * a.S), s);
   static bool done[2] = {false, false};
   if (dtype == MAVLM_F16) {
     if (!done[1]) { hipError_t e = set_lds(attn_fwd_kernel<F16>, ATTN_LDS); if (e != hipSuccess) return e; done[1] = true; }
     hipLaunchKernelGGL(attn_fwd_kernel<F16>, grid, dim3(256), ATTN_LDS, s, (const uint16_t*)a.Q, a.ldq,
-                       (const uint16_t*)a.K, a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, c);
+                       (const uint16_t*)a.K, a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c);
   } else {
     if (!done[0]) { hipError_t e = set_lds(attn_fwd_kernel<BF16>, ATTN_LDS); if (e != hipSuccess) return e; done[0] = true; }
     hipLaunchKernelGGL(attn_fwd_kernel<BF16>, grid, dim3(256), ATTN_LDS, s, (const uint16_t*)a.Q, a.ldq,
-                       (const uint16_t*)a.K, a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, c);
+                       (const uint16_t*)a.K, a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c);
   }
   return hipGetLastError();
 }
@@ -357,14 +373,14 @@ hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream
 hipError_t mavlm_launch_colsum(const mavlm_colsum_args& a, int dtype, hipStream_t s) {
   if (!attn_args_ok(a.Q, a.ldq, a.K, a.ldk, a.R, a.S, a.H) || !a.lse2 || !a.part) return hipErrorInvalidValue;
   const float c = a.scale * 1.44269504088896340736f;
-  dim3 grid((a.S + 127) / 128, a.H);
+  dim3 grid(((a.S + 127) / 128) * a.H);
   mavlm_prof_scope prof(MAVLM_K_COLSUM, 2.0 * a.R * (double)a.S * a.H * HD, 2.0 * HD * a.H * ((double)a.R + a.S), s);
   if (dtype == MAVLM_F16)
     hipLaunchKernelGGL(attn_colsum_kernel<F16>, grid, dim3(256), CS_LDS, s, (const uint16_t*)a.Q, a.ldq,
-                       (const uint16_t*)a.K, a.ldk, a.lse2, a.part, a.R, a.S, c);
+                       (const uint16_t*)a.K, a.ldk, a.lse2, a.part, a.R, a.S, a.H, c);
   else
     hipLaunchKernelGGL(attn_colsum_kernel<BF16>, grid, dim3(256), CS_LDS, s, (const uint16_t*)a.Q, a.ldq,
-                       (const uint16_t*)a.K, a.ldk, a.lse2, a.part, a.R, a.S, c);
+                       (const uint16_t*)a.K, a.ldk, a.lse2, a.part, a.R, a.S, a.H, c);
   return hipGetLastError();
 }
 

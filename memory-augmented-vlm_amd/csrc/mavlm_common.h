@@ -62,12 +62,49 @@ struct F16 {
   }
 };
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+// two fp32 -> one dword of two 16-bit values (lo = a), one v_cvt_pk_* instruction
+template <typename T>
+__device__ __forceinline__ unsigned pack2(float a, float b);
+template <>
+__device__ __forceinline__ unsigned pack2<BF16>(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+template <>
+__device__ __forceinline__ unsigned pack2<F16>(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, f16x2));
+}
+
 template <typename T>
 __device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
   u32x2 r;
-  r[0] = (unsigned)T::from_f32(a) | ((unsigned)T::from_f32(b) << 16);
-  r[1] = (unsigned)T::from_f32(c) | ((unsigned)T::from_f32(d) << 16);
+  r[0] = pack2<T>(a, b);
+  r[1] = pack2<T>(c, d);
   return r;
+}
+
+// max / sum of a value across the two 32-lane halves of a wave (lane l <-> lane l^32), no LDS round trip
+// v_permlane32_swap vdst, src: lanes 32-63 of vdst <-> lanes 0-31 of src.  Fed two copies of v it leaves
+// {own | other-half} in one register and {other-half | own} in the other, so max / sum of the two is the cross-half
+// reduction on every lane (no LDS round trip, unlike __shfl_xor(v, 32) = ds_bpermute).
+// Inline asm on purpose: with __builtin_amdgcn_permlane32_swap, hipcc (ROCm 7.2, -O3) folds the SECOND result into
+// the first (InstCombine; correct at -O0) - measured as wrong softmax row sums.  The 2 wait states the ISA wants
+// between a VALU write of an operand and the swap are inside the string (hipcc pads nothing inside asm).
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float xhalf_max(float v) {
+  float a = v, b = v;
+  permlane32_swap(a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  float a = v, b = v;
+  permlane32_swap(a, b);
+  return a + b;
 }
 
 // Bijective XCD-aware remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch), so

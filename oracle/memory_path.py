@@ -324,7 +324,9 @@ def gelu_erf(x: np.ndarray) -> np.ndarray:
     return (0.5 * x * (1.0 + _erf(x / F32(math.sqrt(2.0))))).astype(F32)
 
 
-KV_TILE = 64   # keys per tile of the HIP flash-attention kernel (csrc/attention.hip)
+KV_TILE = 64          # keys per tile of the HIP flash-attention kernel (csrc/attention.hip)
+RESCALE_LOG2 = 8.0    # deferred-rescale threshold of the kernel, log2 units (attention.hip RESCALE_LOG2)
+WAVE_ROWS = 32        # queries per wave: the rescale decision is wave-uniform (any lane over threshold)
 
 
 def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mode: str = "fp32",
@@ -333,9 +335,10 @@ def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mod
     (ctx [R,H*d] unrounded float32, lse2 [H,R] log2-domain log-sum-exp, colsum [H,Lk] | None, probs | None).
 
     fp32 mode: plain softmax.  Emulation modes follow the kernel's rounding points exactly: keys are consumed in
-    tiles of ``kv_tile`` with a running row maximum; the probabilities of a tile are rounded to 16 bits
-    *relative to the running maximum at that tile* before the P.V product, while the row sum uses the unrounded
-    values; earlier partial sums are rescaled in float32 when the maximum grows."""
+    tiles of ``kv_tile``; the probabilities of a tile are rounded to 16 bits *relative to the running reference
+    value m at that tile* before the P.V product, while the row sum uses the unrounded values.  The reference m of a
+    32-query wave moves to the running maximum only when some query of the wave saw its maximum grow by more than
+    2^RESCALE_LOG2 (deferred rescale); earlier partial sums are then rescaled in float32."""
     r = rounder(mode)
     R, Lk = Q.shape[0], K.shape[0]
     d = Q.shape[1] // heads
@@ -358,7 +361,12 @@ def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mod
             acc = np.zeros((R, d), dtype=F32)
             for k0 in range(0, Lk, kv_tile):
                 st = s[:, k0:k0 + kv_tile]
-                m_new = np.maximum(m, st.max(axis=1, keepdims=True))
+                cand = np.maximum(m, st.max(axis=1, keepdims=True))
+                need = ((cand - m) * F32(1.4426950408889634) > F32(RESCALE_LOG2)).reshape(-1)
+                pad = (-R) % WAVE_ROWS
+                grp = np.concatenate([need, np.zeros(pad, bool)]).reshape(-1, WAVE_ROWS).any(axis=1)
+                move = np.repeat(grp, WAVE_ROWS)[:R].reshape(R, 1)
+                m_new = np.where(move, cand, m).astype(F32)
                 alpha = np.exp(m - m_new, dtype=F32)
                 pt = np.exp(st - m_new, dtype=F32)
                 l = l * alpha + pt.sum(axis=1, keepdims=True, dtype=F32)
