@@ -9,7 +9,8 @@ HEADERS = ["mavlm_common.h", "mavlm_kernels.h", os.path.join("..", "..", "includ
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "lib", "libmavlm.so")
+    # MAVLM_LIB: diagnostics only (A/B builds of the same sources with different -D flags)
+    return os.environ.get("MAVLM_LIB") or os.path.join(_HERE, "lib", "libmavlm.so")
 
 
 def _stale(out: str) -> bool:

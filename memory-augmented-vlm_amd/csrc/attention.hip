@@ -36,6 +36,19 @@ constexpr float RESCALE_LOG2 = 8.0f;   // deferred-rescale threshold in log2 uni
 
 __device__ __forceinline__ int img_x(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
+// Diagnostic build only (-DMAVLM_ATTN_STAMPS): per-phase cycle sums of every wave, read back with
+// mavlm_debug_read_stamps().  No stamp executes in the product build.
+#ifdef MAVLM_ATTN_STAMPS
+__device__ unsigned long long g_attn_stamps[8 * 4096];
+#define STAMP(var)                                                                  \
+  unsigned long long var;                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                                \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");        \
+  __builtin_amdgcn_sched_barrier(0);
+#else
+#define STAMP(var)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ Q, int ldq,
                                                           const uint16_t* __restrict__ K, int ldk,
@@ -103,6 +116,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
   float m_run = -1e30f, l_run = 0.f;
 
   const int nt = (S + KT - 1) / KT;
+#ifdef MAVLM_ATTN_STAGGER
+  // experiment: de-phase the two waves that share a SIMD (they come from two co-resident workgroups running the
+  // same program and otherwise fall into lockstep: both in the MFMA phase, then both in the VALU phase)
+  if (__builtin_amdgcn_s_getreg(0x1804) & 1) __builtin_amdgcn_s_sleep(MAVLM_ATTN_STAGGER);   // HW_ID.wave_id bit 0
+#endif
   load_tile(0);
   store_tile(0);
   // Pin the loop-invariant Q fragments in registers BEFORE the loop: left alone, hipcc sinks their loads to the
@@ -112,25 +130,42 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
   for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
   __syncthreads();
 
+#ifdef MAVLM_ATTN_STAMPS
+  unsigned long long acc_qk = 0, acc_sm = 0, acc_pv = 0, acc_st = 0, acc_bar = 0;
+#endif
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
+    STAMP(t0)
     if (t + 1 < nt) load_tile(t + 1);     // lands during this tile's compute; written to LDS at the end
     const char* kb = smem + cur * 2 * TILE;
     const unsigned vb = (unsigned)(uintptr_t)(MAVLM_LDS const char*)(kb + TILE);   // LDS byte address of the V image
 
-    // ---- S^T = K . Q^T  (2 key blocks x 8 k-steps)
+    // ---- S^T = K . Q^T  (2 key blocks x 8 k-steps).  Step i = (ks = i>>1, b = i&1): consecutive MFMAs hit different
+    // accumulators, and the K fragments are read KPF steps ahead so that several ds_read_b128 are in flight
+    // (one read in flight exposes the LDS latency on every MFMA).
     f32x16 st[2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) st[b][i] = 0.f;
+    {
+      constexpr int KPF = 4;
+      typename T::vec8 kfr[16];
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const typename T::vec8 kf = *(const typename T::vec8*)(kb + k_rd + 8192 * b + 16 * ((2 * ks + hh) ^ xr));
-        st[b] = T::mfma32(kf, qf[ks], st[b]);
+      for (int i = 0; i < KPF; ++i)
+        kfr[i] = *(const typename T::vec8*)(kb + k_rd + 8192 * (i & 1) + 16 * ((2 * (i >> 1) + hh) ^ xr));
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i + KPF < 16) {
+          const int j = i + KPF;
+          kfr[j] = *(const typename T::vec8*)(kb + k_rd + 8192 * (j & 1) + 16 * ((2 * (j >> 1) + hh) ^ xr));
+        }
+        st[i & 1] = T::mfma32(kfr[i], qf[i >> 1], st[i & 1]);
+        __builtin_amdgcn_sched_barrier(0);   // keep the read-ahead distance: hipcc otherwise sinks the reads to their use
       }
     }
 
+    STAMP(t1)
     // ---- mask the ragged tail of the last tile: key = 64t + 32b + (i&3) + 8(i>>2) + 4hh
     if (t == nt - 1 && (S & (KT - 1))) {
 #pragma unroll
@@ -187,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
         pf[b][s] = __builtin_bit_cast(typename T::vec8, w);
       }
 
+    STAMP(t2)
     // ---- O^T += V^T . P^T
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
@@ -203,9 +239,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
         }
     }
 
+    STAMP(t3)
     if (t + 1 < nt) store_tile(cur ^ 1);
+    STAMP(t4)
     __syncthreads();
+#ifdef MAVLM_ATTN_STAMPS
+    STAMP(t5)
+    acc_qk += t1 - t0; acc_sm += t2 - t1; acc_pv += t3 - t2; acc_st += t4 - t3; acc_bar += t5 - t4;
+#endif
   }
+#ifdef MAVLM_ATTN_STAMPS
+  if (lane == 0) {
+    const int wid = (blockIdx.x * 4 + wave) & 4095;
+    unsigned long long* d = g_attn_stamps + 8 * wid;
+    d[0] = acc_qk; d[1] = acc_sm; d[2] = acc_pv; d[3] = acc_st; d[4] = acc_bar; d[5] = nt;
+    d[6] = __builtin_amdgcn_s_getreg(0x1804) | (__builtin_amdgcn_s_getreg((5 << 11) | (8 << 6) | 4) << 8);
+  }
+#endif
 
   // ---- epilogue: O[q][h*128 + 32db + 8g + 4hh + 0..3] = O^T / l
   const float l_tot = xhalf_sum(l_run);
@@ -394,3 +444,9 @@ hipError_t mavlm_launch_frame_scores(const float* part, int H, int S, int F, int
     hipLaunchKernelGGL(frame_scores_kernel<BF16>, dim3(F), dim3(64), 0, s, part, H, S, P, out, out_f32);
   return hipGetLastError();
 }
+
+#ifdef MAVLM_ATTN_STAMPS
+extern "C" int mavlm_debug_read_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * n);
+}
+#endif

@@ -1,0 +1,49 @@
+"""Micro-benchmark of the individual kernels at the bench shapes (not a test; used for A/B timing and for
+rocprofv3 --pmc runs).  usage: python tests/bench_ops.py [attn|gemm|colsum|all] [iters]"""
+import math, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import memory_augmented_vlm_amd
+from memory_augmented_vlm_amd import _capi as capi, _ops as ops
+
+what = sys.argv[1] if len(sys.argv) > 1 else "all"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dev = "cuda"
+torch.manual_seed(0)
+
+
+def timeit(fn, flops, name):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print(f"{name:44s} {ms*1e3:9.1f} us  {flops/ms/1e9:8.1f} TFLOP/s", flush=True)
+
+
+R, S, H, D = 12544, 6272, 8, 1024
+if what in ("attn", "all"):
+    q = torch.randn(R, D, device=dev).bfloat16()
+    kv = torch.randn(S, 4 * D, device=dev).bfloat16()
+    timeit(lambda: ops.attention(q, kv[:, :D], kv[:, D:2 * D], H, want_lse=True), 4.0 * R * S * D, f"attn R={R} S={S}")
+    kv2 = torch.randn(R, 2 * D, device=dev).bfloat16()
+    timeit(lambda: ops.attention(q, kv2[:, :D], kv2[:, D:], H), 4.0 * R * R * D, f"attn R={R} S={R} (evolution n=1)")
+if what in ("colsum", "all"):
+    q = torch.randn(R, D, device=dev).bfloat16()
+    kv = torch.randn(S, 4 * D, device=dev).bfloat16()
+    _, lse = ops.attention(q, kv[:, :D], kv[:, D:2 * D], H, want_lse=True)
+    timeit(lambda: ops.attention_colsum(q, kv[:, :D], lse, H), 2.0 * R * S * D, f"colsum R={R} S={S}")
+if what in ("gemm", "all"):
+    for (M, N, K, epi) in [(S, 4 * D, D, 0), (R, D, D, 0), (R, D, D, 3), (R, 4 * D, D, 1), (R, D, 4 * D, 3), (R, 2 * D, D, 0),
+                           (R, 4 * D, D, 2)]:
+        a = torch.randn(M, K, device=dev).bfloat16()
+        w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
+        b = torch.randn(N, device=dev)
+        res = torch.randn(M, N, device=dev).bfloat16() if epi == 3 else None
+        out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == 3 else torch.bfloat16)
+        timeit(lambda: ops.linear(a, w, b, epi, residual=res, out=out), 2.0 * M * N * K, f"gemm M={M} N={N} K={K} epi={epi}")
