@@ -136,6 +136,10 @@ int mavlm_layernorm(const float* x, const float* gamma, const float* beta, void*
 int mavlm_row_add(const void* x, const int64_t* src, const void* table, const int64_t* idx, void* out, int32_t T,
                   int32_t P, int32_t D, int32_t dtype, void* stream);
 
+/* tuning hook: force the GEMM block tile (128 or 256; 0 = automatic choice by grid size).  Results are identical
+ * up to fp32 summation order. */
+int mavlm_set_gemm_tile(int32_t tile);
+
 /* --- measurement hooks (bench.py only; new - the reference has no profiling) ------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on its own stream.  Kinds: 0 GEMM, 1 attention
  * forward, 2 attention column-sum, 3 LayerNorm, 4 row-add, 5 misc.  Not re-entrant, not graph-capturable. */

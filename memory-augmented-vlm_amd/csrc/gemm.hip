@@ -166,6 +166,18 @@ hipError_t launch_epi(const mavlm_gemm_args& g, hipStream_t s) {
 
 }  // namespace
 
+int g_mavlm_gemm_tile = 0;
+
+// Tile choice: the 256^2 kernel runs one workgroup per CU, so it wants >= ~1 full wave of 256 tiles; below that the
+// 128^2 kernel (two workgroups per CU, 4x the tiles) fills the chip better.
+static bool use_256(const mavlm_gemm_args& g) {
+  if (!mavlm_gemm256_supported(g)) return false;
+  if (g_mavlm_gemm_tile == 256) return true;
+  if (g_mavlm_gemm_tile == 128) return false;
+  const long tiles = (long)((g.M + 255) / 256) * (g.N / 256);
+  return tiles >= 192;
+}
+
 hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s) {
   if (g.M <= 0) return hipSuccess;
   if (g.N % BN != 0 || g.K % BK != 0 || g.K <= 0 || (g.lda & 7) || (g.ldw & 7) || (g.ldc & 3)) return hipErrorInvalidValue;
@@ -173,5 +185,6 @@ hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s)
   const double osz = g.epilogue == MAVLM_EPI_RES_F32 ? 6.0 : 2.0;   // fp32 out + 16-bit residual in
   mavlm_prof_scope prof(MAVLM_K_GEMM, 2.0 * g.M * (double)g.N * g.K,
                         2.0 * ((double)g.M * g.K + (double)g.N * g.K) + osz * g.M * (double)g.N, s);
+  if (use_256(g)) return mavlm_launch_gemm256(g, dtype, s);
   return dtype == MAVLM_F16 ? launch_epi<F16>(g, s) : launch_epi<BF16>(g, s);
 }

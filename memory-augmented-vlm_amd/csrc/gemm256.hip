@@ -1,0 +1,243 @@
+// 256x256x64 "4-phase per K-tile" MFMA GEMM for the large projections of the memory path.
+// Same contract as gemm_tn_kernel (gemm.hip): C[M,N] = epi(A[M,K] . W[N,K]^T + bias), nn.Linear layout.
+//
+// Structure (after cdna_hip_programming.md "The 256^2 8-phase template", re-derived for this layout):
+//   * 8 waves (2 along M x 4 along N), wave tile 128x64 = 8x4 MFMA 16x16x32 tiles (128 accumulator VGPRs), one
+//     workgroup per CU, 128 KiB LDS = 2 stages x {A0,A1,B0,B1} half-tiles of 128 rows x 64 k (16 KiB each).
+//   * Operands arrive by LDS-DMA (16-byte global_load_lds), XOR-swizzled through the per-lane SOURCE address;
+//     a half-tile is 2 DMA instructions per wave.
+//   * A K-tile is consumed in 4 phases of 16 MFMAs (one 64x32 quadrant of the wave tile x K=64):
+//        phase 1: read A(rows 0-63) + all of B into registers (16 ds_read_b128), quadrant (0,0)
+//        phase 2: quadrant (0,1)            phase 3: read A(rows 64-127) (8 reads), quadrant (1,1)
+//        phase 4: quadrant (1,0)
+//     so the B half-tiles of the stage are dead after phase 1 and the A half-tiles after phase 3, and every phase
+//     re-stages ONE half-tile: phase 1 -> A1 of K-tile kt+1 (other stage), phases 2,3,4 -> B0,B1,A0 of K-tile kt+2
+//     (this stage).  Loads therefore stay in flight across barriers; the only vmcnt wait is a COUNTED one per K-tile
+//     (vmcnt(6): the three youngest half-tiles stay in flight), never 0 inside the loop.
+//   * Raw s_barrier (a __syncthreads() would drain the DMA queue), MFMA clusters bracketed by s_setprio.
+//
+// Hazards (LDS-DMA is ordered by nothing but the issuing wave's vmcnt + a barrier):
+//   RAW  K-tile kt+1 is read in the phase after {vmcnt(6) ; barrier} at the end of K-tile kt's phase 4.
+//   WAR  a half-tile is re-staged >= 1 full phase after its last ds_read; those reads were retired by the
+//        lgkmcnt(0) in front of that phase's MFMAs and a barrier separates them from the DMA issue.
+#include "mavlm_common.h"
+#include "mavlm_kernels.h"
+
+namespace {
+
+constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
+constexpr int HALF = 128 * BK2 * 2;          // 16 KiB half-tile
+constexpr int STAGE2 = 4 * HALF;             // A0 A1 B0 B1
+constexpr int GEMM256_LDS = 2 * STAGE2;      // 128 KiB
+
+// raw workgroup barrier fenced against compiler motion of memory operations (s_barrier itself is IntrNoMem)
+#define MAVLM_BAR()                          \
+  do {                                       \
+    asm volatile("" ::: "memory");           \
+    __builtin_amdgcn_s_barrier();            \
+    asm volatile("" ::: "memory");           \
+  } while (0)
+// all LDS reads of this phase retired before its MFMAs (WAR rule above); sched_barrier: hipcc may hoist a
+// register-only MFMA above an inline-asm wait (cdna_hip_programming.md rule 18)
+#define MAVLM_LGKM0()                                          \
+  do {                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
+    __builtin_amdgcn_sched_barrier(0);                         \
+  } while (0)
+
+__device__ __forceinline__ float gelu_erf2(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restrict__ A, int lda,
+                                                         const uint16_t* __restrict__ W, int ldw,
+                                                         const float* __restrict__ bias,
+                                                         const uint16_t* __restrict__ res, int ldr,
+                                                         void* __restrict__ Cout, int ldc, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int ntn = N / BN2;
+  const int ntm = (M + BM2 - 1) / BM2;
+  const int wg = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (wg / ntn) * BM2;
+  const int n0 = (wg % ntn) * BN2;
+
+  // ---- LDS-DMA sources: wave w stages 8-row groups g = 2w, 2w+1 of every half-tile
+  const int srow = lane >> 3, sp = lane & 7;
+  const uint16_t* gA[2][2];   // [half][inst]
+  const uint16_t* gB[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (wave * 2 + j) * 8 + srow;          // row inside the half-tile
+      const int c = sp ^ ((row >> 1) & 7);                // logical 16-B chunk stored at physical chunk sp
+      int ar = m0 + h * 128 + row;
+      ar = ar < M ? ar : M - 1;
+      gA[h][j] = A + (size_t)ar * lda + c * 8;
+      gB[h][j] = W + (size_t)(n0 + h * 128 + row) * ldw + c * 8;
+    }
+  // half-tile ids: 0 = A0, 1 = A1, 2 = B0, 3 = B1
+  auto dma = [&](int stage, int half_id, int kt) {
+    char* dst = smem + stage * STAGE2 + half_id * HALF + wave * 2048;
+    const int h = half_id & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint16_t* src = (half_id < 2 ? gA[h][j] : gB[h][j]) + (size_t)kt * BK2;
+      __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)src, (MAVLM_LDS void*)(dst + j * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment read offsets
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = (lane >> 1) & 7;
+  const int ck0 = (fq ^ sw) << 4, ck1 = ((4 + fq) ^ sw) << 4;
+  const int offA = wm * HALF + fr * 128;                               // + mh*8192 + mt*2048
+  const int offB = 2 * HALF + (wn >> 1) * HALF + ((wn & 1) * 64 + fr) * 128;   // + nh*4096 + nt*2048
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  typename T::vec8 af[4][2];      // [m-tile of the current 64-row slice][k-step]
+  typename T::vec8 bf[4][2];      // [n-tile of the wave's 64 columns][k-step]
+
+  const int nk = K / BK2;
+
+  // ---- prologue: K-tile 0 completely, K-tile 1 minus its last half-tile (order B0,B1,A0,A1)
+  dma(0, 2, 0); dma(0, 3, 0); dma(0, 0, 0); dma(0, 1, 0);
+  if (nk > 1) {
+    dma(1, 2, 1); dma(1, 3, 1); dma(1, 0, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  MAVLM_BAR();
+
+  auto read_a = [&](const char* st, int mh) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      af[mt][0] = *(const typename T::vec8*)(st + offA + mh * 8192 + mt * 2048 + ck0);
+      af[mt][1] = *(const typename T::vec8*)(st + offA + mh * 8192 + mt * 2048 + ck1);
+    }
+  };
+  auto read_b = [&](const char* st) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      bf[nt][0] = *(const typename T::vec8*)(st + offB + nt * 2048 + ck0);
+      bf[nt][1] = *(const typename T::vec8*)(st + offB + nt * 2048 + ck1);
+    }
+  };
+#define MAVLM_QUADRANT(MH, NH)                                                              \
+  {                                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                        \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                        \
+      acc[MH * 4 + mt][NH * 2 + nt] = T::mfma16(bf[NH * 2 + nt][ks], af[mt][ks], acc[MH * 4 + mt][NH * 2 + nt]); \
+    __builtin_amdgcn_s_setprio(0);                                                          \
+  }
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int s = kt & 1;
+    const char* st = smem + s * STAGE2;
+    // -------- phase 1
+    read_a(st, 0);
+    read_b(st);
+    if (kt + 1 < nk) dma(s ^ 1, 1, kt + 1);              // A1 of the next K-tile
+    MAVLM_BAR();
+    MAVLM_LGKM0();
+    MAVLM_QUADRANT(0, 0)
+    MAVLM_BAR();
+    // -------- phase 2   (B half-tiles of this stage are dead: everything is in registers)
+    if (kt + 2 < nk) dma(s, 2, kt + 2);
+    MAVLM_BAR();
+    MAVLM_QUADRANT(0, 1)
+    MAVLM_BAR();
+    // -------- phase 3
+    read_a(st, 1);
+    if (kt + 2 < nk) dma(s, 3, kt + 2);
+    MAVLM_BAR();
+    MAVLM_LGKM0();
+    MAVLM_QUADRANT(1, 1)
+    MAVLM_BAR();
+    // -------- phase 4   (A half-tiles dead)
+    if (kt + 2 < nk) {
+      dma(s, 0, kt + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // K-tile kt+1 landed; 3 half-tiles of kt+2 stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    MAVLM_BAR();
+    MAVLM_QUADRANT(1, 0)
+    MAVLM_BAR();
+  }
+#undef MAVLM_QUADRANT
+
+  // ---- epilogue: lane holds C[m][n..n+3], m = m0 + wm*128 + 16 i + fr, n = n0 + wn*64 + 16 j + 4 fq
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wm * 128 + i * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fq * 4;
+      const f32x4 bv = *(const f32x4*)(bias + n);
+      float v0 = acc[i][j][0] + bv[0], v1 = acc[i][j][1] + bv[1], v2 = acc[i][j][2] + bv[2],
+            v3 = acc[i][j][3] + bv[3];
+      if (EPI == MAVLM_EPI_RELU) {
+        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+      } else if (EPI == MAVLM_EPI_GELU) {
+        v0 = gelu_erf2(v0); v1 = gelu_erf2(v1); v2 = gelu_erf2(v2); v3 = gelu_erf2(v3);
+      }
+      if (EPI == MAVLM_EPI_RES_F32) {
+        const u16x4 rv = *(const u16x4*)(res + (size_t)m * ldr + n);
+        f32x4 o;
+        o[0] = v0 + T::to_f32(rv[0]); o[1] = v1 + T::to_f32(rv[1]);
+        o[2] = v2 + T::to_f32(rv[2]); o[3] = v3 + T::to_f32(rv[3]);
+        *(f32x4*)((float*)Cout + (size_t)m * ldc + n) = o;
+      } else {
+        *(u32x2*)((uint16_t*)Cout + (size_t)m * ldc + n) = pack4<T>(v0, v1, v2, v3);
+      }
+    }
+  }
+}
+
+template <typename T, int EPI>
+hipError_t launch256(const mavlm_gemm_args& g, hipStream_t s) {
+  auto kern = gemm256_kernel<T, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int ntm = (g.M + BM2 - 1) / BM2, ntn = g.N / BN2;
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(512), GEMM256_LDS, s, (const uint16_t*)g.A, g.lda, (const uint16_t*)g.W,
+                     g.ldw, g.bias, (const uint16_t*)g.res, g.ldr, g.C, g.ldc, g.M, g.N, g.K);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch256_epi(const mavlm_gemm_args& g, hipStream_t s) {
+  switch (g.epilogue) {
+    case MAVLM_EPI_BIAS: return launch256<T, MAVLM_EPI_BIAS>(g, s);
+    case MAVLM_EPI_RELU: return launch256<T, MAVLM_EPI_RELU>(g, s);
+    case MAVLM_EPI_GELU: return launch256<T, MAVLM_EPI_GELU>(g, s);
+    case MAVLM_EPI_RES_F32: return launch256<T, MAVLM_EPI_RES_F32>(g, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+bool mavlm_gemm256_supported(const mavlm_gemm_args& g) { return g.N % BN2 == 0 && g.K % BK2 == 0 && g.M >= 1; }
+
+hipError_t mavlm_launch_gemm256(const mavlm_gemm_args& g, int dtype, hipStream_t s) {
+  return dtype == MAVLM_F16 ? launch256_epi<F16>(g, s) : launch256_epi<BF16>(g, s);
+}

@@ -89,6 +89,12 @@ extern "C" {
 
 int mavlm_abi_version(void) { return MAVLM_ABI_VERSION; }
 
+int mavlm_set_gemm_tile(int32_t tile) {
+  if (tile != 0 && tile != 128 && tile != 256) return MAVLM_E_ARG;
+  g_mavlm_gemm_tile = tile;
+  return 0;
+}
+
 size_t mavlm_workspace_bytes(const mavlm_config* cfg) {
   if (!cfg_ok(cfg)) return 0;
   mavlm_ctx t;

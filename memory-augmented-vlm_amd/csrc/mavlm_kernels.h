@@ -16,6 +16,10 @@ struct mavlm_gemm_args {
   int epilogue;
 };
 hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s);
+// 256x256x64 8-wave kernel (gemm256.hip); mavlm_launch_gemm picks it when the grid fills the chip
+bool mavlm_gemm256_supported(const mavlm_gemm_args& g);
+hipError_t mavlm_launch_gemm256(const mavlm_gemm_args& g, int dtype, hipStream_t s);
+extern int g_mavlm_gemm_tile;   // 0 = auto, 128 / 256 = forced (tuning hook, mavlm_set_gemm_tile)
 
 struct mavlm_attn_args {
   const void* Q; int ldq;        // [R, >=H*128] 16-bit; head h at column h*128

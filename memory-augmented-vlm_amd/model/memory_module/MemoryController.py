@@ -311,6 +311,18 @@ class TransformerProjector(nn.Module):
             self._engine = None
         return out
 
+    def spawn_replica(self) -> "TransformerProjector":
+        """A second recurrent state over the SAME parameters: shares every Parameter / sub-module object with this
+        module (no weight copy) but owns its own engine, FIFO ring and workspace.  Used to keep several videos in
+        flight on different HIP streams (MemoryPathPool in llava_arch.py): one video's partial-wave kernel tails
+        are then filled by the other's kernels."""
+        import copy
+        r = copy.copy(self)                    # shallow: _parameters / _modules dicts are shared
+        r._engine = None
+        r._memory_cache = []
+        r.frame_attn_scores = []
+        return r
+
     # -- forward -----------------------------------------------------------------------------------------
     def forward(self, image_features: torch.Tensor):
         if image_features.dim() != 3:

@@ -22,9 +22,18 @@ def _int_mat(shape, seed, lo=-4, hi=4):
     return np.floor(O.hash_uniform(shape, seed, lo, hi + 0.999)).astype(np.float32)
 
 
+@pytest.fixture(params=[128, 256])
+def gemm_tile(request):
+    """Run the GEMM tests once per block-tile kernel (128^2 4-wave, 256^2 8-wave LDS-DMA pipeline)."""
+    capi.check(capi.lib().mavlm_set_gemm_tile(request.param), "set tile")
+    yield request.param
+    capi.lib().mavlm_set_gemm_tile(0)
+
+
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
-@pytest.mark.parametrize("M,N,K", [(16, 128, 64), (200, 256, 192), (129, 128, 1024), (1, 384, 64)])
-def test_linear_integer_exact(mode, M, N, K):
+@pytest.mark.parametrize("M,N,K", [(16, 128, 64), (200, 256, 192), (129, 128, 1024), (1, 384, 64), (513, 512, 64),
+                                   (300, 256, 128), (256, 768, 320)])
+def test_linear_integer_exact(mode, M, N, K, gemm_tile):
     """A = I-like / asymmetric integer data: catches any row/col swap in the fragment or C maps exactly."""
     A = _int_mat((M, K), 1)
     W = _int_mat((N, K), 2)
@@ -41,7 +50,7 @@ def test_linear_integer_exact(mode, M, N, K):
 
 @pytest.mark.parametrize("M,N,K,epi", [(1568, 1024, 1024, "bias"), (588, 4096, 1024, "bias"), (777, 512, 4096, "gelu"),
                                        (300, 4096, 1024, "relu")])
-def test_linear_random_vs_oracle(M, N, K, epi):
+def test_linear_random_vs_oracle(M, N, K, epi, gemm_tile):
     r = O.bf16_round
     A = r(O.hash_normal_like((M, K), 11))
     W = r(O.hash_uniform((N, K), 12, -1 / math.sqrt(K), 1 / math.sqrt(K)))

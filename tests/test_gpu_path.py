@@ -353,3 +353,22 @@ def test_baseline_size_properties():
     z = (mem - bb) / g
     assert float(z.mean(-1).abs().max().detach()) < 2e-2
     assert float((z.var(-1, unbiased=False) - 1).abs().max().detach()) < 5e-2
+
+
+def test_pool_two_videos_in_flight_bit_identical():
+    """MemoryPathPool: two videos on two streams over shared weights == the serial path, bit for bit."""
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=13)
+    model, _ = _tiny_host(cfg, w)
+    vids = [(to_dev(O.bf16_round(O.hash_normal_like((40 if i % 2 else 33, 196, 1024), 1300 + i))),
+             torch.arange(40 if i % 2 else 33)) for i in range(4)]
+    mp = torch.randn((10, 1024), device="cuda").bfloat16()
+    fp = torch.randn((9, 1024), device="cuda").bfloat16()
+    serial = [arch.video_memory_tokens(model, v, i, mp, fp, model.image_newline)[0].clone() for v, i in vids]
+    pool = arch.MemoryPathPool(model, 2)
+    assert pool.slots[1].recurrent_memory_transformer.layers[0].mlp[0].weight is \
+        model.recurrent_memory_transformer.layers[0].mlp[0].weight          # shared parameters, no copy
+    outs = pool.run(vids, mp, fp, model.image_newline)
+    torch.cuda.synchronize()
+    for a, b in zip(serial, outs):
+        assert torch.equal(a, b)
