@@ -35,7 +35,7 @@ typedef struct mavlm_ctx mavlm_ctx;
 /* Hyper-parameters: `Config` (llava/model/memory_module/MemoryController.py:7-18) as overridden at
  * llava/model/llava_arch.py:117-129, plus the FIFO cap (MemoryController.py:153-154). */
 typedef struct mavlm_config {
-  int32_t hidden;           /* D, mm_hidden_size; multiple of 128; head_dim = D/heads must be 128 */
+  int32_t hidden;           /* D, mm_hidden_size; multiple of 128; head_dim = D/heads <= 128 (D = 896, 1024 ...) */
   int32_t heads;            /* H, mm_num_attention_heads (8) */
   int32_t patches;          /* P, patch_size (196) */
   int32_t mem_tokens;       /* M, num_memory_tokens (8) */
@@ -48,7 +48,10 @@ typedef struct mavlm_config {
 } mavlm_config;
 
 /* One `Attention` block (MemoryController.py:31-57) minus its K/V projections.  Weights [out,in] 16-bit
- * (nn.Linear layout), biases and LayerNorm affine parameters fp32. */
+ * (nn.Linear layout), biases and LayerNorm affine parameters fp32.
+ * Head padding: with Dp = heads*128, every projection that produces or consumes per-head columns is packed with each
+ * head's head_dim rows/columns followed by (128 - head_dim) zeros: wq [Dp,D], bq [Dp], wo [D,Dp] (and the K/V
+ * packs below).  For head_dim = 128 this is the plain nn.Linear weight. */
 typedef struct mavlm_attn_weights {
   const void* wq;  const float* bq;     /* q_proj            [D,D],[D] */
   const void* wo;  const float* bo;     /* residual.dense    [D,D],[D] */
@@ -59,13 +62,13 @@ typedef struct mavlm_attn_weights {
  * reference state-dict names listed in SURVEY.md §8b). */
 typedef struct mavlm_weights {
   const void* mem0;                     /* [M*P, D] 16-bit: initial_memory + memory_pos_embed (MemoryController.py:123) */
-  const void* w_kv_seg; const float* b_kv_seg; /* [2*L*D, D]: rows K_0,V_0,K_1,V_1,... of layers[l].memory_segment_fusion_attention.{k,v}_proj */
+  const void* w_kv_seg; const float* b_kv_seg; /* [2*L*Dp, D]: rows K_0,V_0,K_1,V_1,... of layers[l].memory_segment_fusion_attention.{k,v}_proj (head-padded) */
   mavlm_attn_weights layer_attn[MAVLM_MAX_DEPTH];
   const void* w_up[MAVLM_MAX_DEPTH];   const float* b_up[MAVLM_MAX_DEPTH];   /* layers[l].mlp.0          [I,D] */
   const void* w_down[MAVLM_MAX_DEPTH]; const float* b_down[MAVLM_MAX_DEPTH]; /* layers[l].residual.dense [D,I] */
   const float* ln2_g[MAVLM_MAX_DEPTH]; const float* ln2_b[MAVLM_MAX_DEPTH];  /* layers[l].residual.layernorm */
   mavlm_attn_weights evo;               /* memory_update_attention */
-  const void* w_kv_evo; const float* b_kv_evo; /* [2D, D]: rows K,V of memory_update_attention.{k,v}_proj */
+  const void* w_kv_evo; const float* b_kv_evo; /* [2Dp, D]: rows K,V of memory_update_attention.{k,v}_proj (head-padded) */
   const void* w_f1; const float* b_f1;  /* memory_fuser.0 [I,D]  (llava_arch.py:132-136) */
   const void* w_f2; const float* b_f2_type0; /* memory_fuser.2 [D,I]; bias + token_type_embedding[0] (llava_arch.py:548-553) */
   const void* type1;                    /* [D] 16-bit token_type_embedding[1] (llava_arch.py:554) */
@@ -74,7 +77,7 @@ typedef struct mavlm_weights {
 /* Caller-allocated state and scratch (the module owns them as torch tensors). */
 typedef struct mavlm_buffers {
   void* mem_ring;       /* [cache_cap, M*P, D]  16-bit  memory_cache entries, slot = step % cache_cap */
-  void* evo_kv_ring;    /* [cache_cap, M*P, 2D] 16-bit  K|V projections of each cached memory (projected once) */
+  void* evo_kv_ring;    /* [cache_cap, M*P, 2Dp] 16-bit K|V projections of each cached memory (projected once) */
   void* workspace;      /* mavlm_workspace_bytes() bytes, 256-B aligned */
   size_t workspace_bytes;
 } mavlm_buffers;

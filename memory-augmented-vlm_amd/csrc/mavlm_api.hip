@@ -2,6 +2,8 @@
 // No allocation, no synchronisation: every entry point only enqueues kernels on the caller's stream.
 #include "../../include/mavlm.h"
 
+#include <math.h>
+
 #include <new>
 
 #include "mavlm_kernels.h"
@@ -29,19 +31,22 @@ bool cfg_ok(const mavlm_config* c) {
   return true;
 }
 
-// shapes the gfx950 kernels implement (DESIGN.md "Supported shapes")
+// shapes the gfx950 kernels implement (DESIGN.md "Supported shapes"): head_dim <= 128 (heads are zero-padded to
+// 128 columns in the Q/K/V/ctx buffers and in the packed weights), D and I multiples of 128
 bool shape_ok(const mavlm_config* c) {
-  return c->hidden % 128 == 0 && c->hidden == c->heads * 128 && c->inter % 128 == 0;
+  return c->hidden % 128 == 0 && c->hidden % c->heads == 0 && c->hidden / c->heads <= 128 && c->inter % 128 == 0;
 }
+inline int padded_width(const mavlm_config& c) { return c.heads * 128; }
+inline float attn_scale(const mavlm_config& c) { return 1.0f / sqrtf((float)(c.hidden / c.heads)); }
 
 void carve(mavlm_ctx* x) {
   const mavlm_config& c = x->cfg;
   const size_t R = (size_t)c.mem_tokens * c.patches, S = (size_t)c.max_chunk_frames * c.patches, D = c.hidden,
-               I = c.inter, L = c.depth, H = c.heads;
+               I = c.inter, L = c.depth, H = c.heads, Dp = (size_t)padded_width(c);
   size_t o = 0;
-  x->o_kv = o;   o += al(S * 2 * L * D * 2);
-  x->o_q = o;    o += al(R * D * 2);
-  x->o_ctx = o;  o += al(R * D * 2);
+  x->o_kv = o;   o += al(S * 2 * L * Dp * 2);
+  x->o_q = o;    o += al(R * Dp * 2);
+  x->o_ctx = o;  o += al(R * Dp * 2);
   x->o_a = o;    o += al(R * D * 2);
   x->o_h = o;    o += al(R * I * 2);
   x->o_pre = o;  o += al(R * D * 4);
@@ -72,13 +77,13 @@ hipError_t gemm(int dtype, hipStream_t s, const void* A, int lda, const void* W,
 int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const void* xq, const void* K, int ldk,
                const void* V, int ldv, int S, void* out, float* lse2) {
   const mavlm_config& c = x->cfg;
-  const int R = c.mem_tokens * c.patches, D = c.hidden, H = c.heads, dt = c.dtype;
-  MAVLM_TRY(gemm(dt, s, xq, D, aw.wq, D, aw.bq, ws(x, x->o_q), D, R, D, D, MAVLM_EPI_BIAS));
+  const int R = c.mem_tokens * c.patches, D = c.hidden, H = c.heads, dt = c.dtype, Dp = padded_width(c);
+  MAVLM_TRY(gemm(dt, s, xq, D, aw.wq, D, aw.bq, ws(x, x->o_q), Dp, R, Dp, D, MAVLM_EPI_BIAS));
   mavlm_attn_args a;
-  a.Q = ws(x, x->o_q); a.ldq = D; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = ws(x, x->o_ctx); a.ldo = D;
-  a.lse2 = lse2; a.R = R; a.S = S; a.H = H; a.scale = 0.08838834764831845f;   // 1/sqrt(128)
+  a.Q = ws(x, x->o_q); a.ldq = Dp; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = ws(x, x->o_ctx); a.ldo = Dp;
+  a.lse2 = lse2; a.R = R; a.S = S; a.H = H; a.scale = attn_scale(c);
   MAVLM_TRY(mavlm_launch_attention(a, dt, s));
-  MAVLM_TRY(gemm(dt, s, ws(x, x->o_ctx), D, aw.wo, D, aw.bo, ws(x, x->o_pre), D, R, D, D, MAVLM_EPI_RES_F32, xq, D));
+  MAVLM_TRY(gemm(dt, s, ws(x, x->o_ctx), Dp, aw.wo, Dp, aw.bo, ws(x, x->o_pre), D, R, D, Dp, MAVLM_EPI_RES_F32, xq, D));
   MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), aw.ln_g, aw.ln_b, out, R, D, c.eps, dt, s));
   return 0;
 }
@@ -175,8 +180,9 @@ int mavlm_step(mavlm_ctx* x, const void* seg, int32_t F, void* frame_scores, int
   if (F <= 0 || F > c.max_chunk_frames) return MAVLM_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   const int R = c.mem_tokens * c.patches, D = c.hidden, I = c.inter, L = c.depth, H = c.heads, dt = c.dtype;
+  const int Dp = padded_width(c);
   const int S = F * c.patches;
-  const size_t mem_bytes = (size_t)R * D * 2, kv_bytes = (size_t)R * 2 * D * 2;
+  const size_t mem_bytes = (size_t)R * D * 2, kv_bytes = (size_t)R * 2 * Dp * 2;
   const int cap = c.cache_cap;
   const int n = x->steps < cap ? x->steps : cap;
 
@@ -187,29 +193,29 @@ int mavlm_step(mavlm_ctx* x, const void* seg, int32_t F, void* frame_scores, int
     const char* mem_new = (const char*)x->b.mem_ring + (size_t)newest * mem_bytes;
     char* kv_new = (char*)x->b.evo_kv_ring + (size_t)newest * kv_bytes;
     // K/V of a cached memory are row-independent -> project each memory once, when it becomes the newest
-    MAVLM_TRY(gemm(dt, s, mem_new, D, x->w.w_kv_evo, D, x->w.b_kv_evo, kv_new, 2 * D, R, 2 * D, D, MAVLM_EPI_BIAS));
+    MAVLM_TRY(gemm(dt, s, mem_new, D, x->w.w_kv_evo, D, x->w.b_kv_evo, kv_new, 2 * Dp, R, 2 * Dp, D, MAVLM_EPI_BIAS));
     const char* kv = (const char*)x->b.evo_kv_ring;
-    int rc = attn_block(x, s, x->w.evo, mem_new, kv, 2 * D, kv + (size_t)D * 2, 2 * D, n * R, ws(x, x->o_mA), nullptr);
+    int rc = attn_block(x, s, x->w.evo, mem_new, kv, 2 * Dp, kv + (size_t)Dp * 2, 2 * Dp, n * R, ws(x, x->o_mA), nullptr);
     if (rc) return rc;
     cur = ws(x, x->o_mA);
   }
 
   // ---- memory formation (MemoryController.py:132-133): K/V of the chunk for all L layers in one GEMM
   char* kvs = ws(x, x->o_kv);
-  const int ldkv = 2 * L * D;
+  const int ldkv = 2 * L * Dp;
   MAVLM_TRY(gemm(dt, s, seg, D, x->w.w_kv_seg, D, x->w.b_kv_seg, kvs, ldkv, S, ldkv, D, MAVLM_EPI_BIAS));
   for (int l = 0; l < L; ++l) {
     const bool last = l == L - 1;
     const bool want_scores = last && frame_scores != nullptr;
-    const char* Kl = kvs + (size_t)(2 * l) * D * 2;
-    const char* Vl = Kl + (size_t)D * 2;
+    const char* Kl = kvs + (size_t)(2 * l) * Dp * 2;
+    const char* Vl = Kl + (size_t)Dp * 2;
     float* lse = want_scores ? (float*)ws(x, x->o_lse) : nullptr;
     int rc = attn_block(x, s, x->w.layer_attn[l], cur, Kl, ldkv, Vl, ldkv, S, ws(x, x->o_a), lse);
     if (rc) return rc;
     if (want_scores) {
       mavlm_colsum_args ca;
-      ca.Q = ws(x, x->o_q); ca.ldq = D; ca.K = Kl; ca.ldk = ldkv; ca.lse2 = lse; ca.part = (float*)ws(x, x->o_part);
-      ca.R = R; ca.S = S; ca.H = H; ca.scale = 0.08838834764831845f;
+      ca.Q = ws(x, x->o_q); ca.ldq = Dp; ca.K = Kl; ca.ldk = ldkv; ca.lse2 = lse; ca.part = (float*)ws(x, x->o_part);
+      ca.R = R; ca.S = S; ca.H = H; ca.scale = attn_scale(c);
       MAVLM_TRY(mavlm_launch_colsum(ca, dt, s));
       MAVLM_TRY(mavlm_launch_frame_scores(ca.part, H, S, F, c.patches, frame_scores, scores_f32, dt, s));
     }

@@ -96,6 +96,9 @@ class Attention(nn.Module):
     def forward(self, hidden_states, kv_hidden_states=None, output_attentions=True):
         if hidden_states.dim() != 3 or hidden_states.shape[0] != 1:
             raise capi.MavlmError("Attention.forward: batch size 1 only (as the reference, MemoryController.py:121)")
+        if self.attention_head_size != 128:
+            raise capi.MavlmError("stand-alone Attention.forward needs head_dim 128; head_dim < 128 runs through the "
+                                  "fused TransformerProjector path (zero-padded heads)")
         kv = hidden_states if kv_hidden_states is None else kv_hidden_states
         xq, xkv = hidden_states[0], kv[0]
         q = ops.linear(xq, self.q_proj.weight, self.q_proj.bias.float())
@@ -142,8 +145,10 @@ class _Engine:
         capi.check(lib.mavlm_create(self.c, h), "mavlm_create")
         self.ctx = h
         R, D = self.c.mem_tokens * self.c.patches, self.c.hidden
+        self.head_dim = D // self.c.heads
+        self.Dp = self.c.heads * 128                      # per-head columns zero-padded to 128 (attention kernel width)
         self.mem_ring = torch.empty((self.c.cache_cap, self.c.mem_tokens, self.c.patches, D), device=device, dtype=dtype)
-        self.evo_kv = torch.empty((self.c.cache_cap, R, 2 * D), device=device, dtype=dtype)
+        self.evo_kv = torch.empty((self.c.cache_cap, R, 2 * self.Dp), device=device, dtype=dtype)
         nbytes = lib.mavlm_workspace_bytes(self.c)
         self.workspace = torch.empty(nbytes + 256, device=device, dtype=torch.uint8)
         base = (self.workspace.data_ptr() + 255) & ~255
@@ -175,9 +180,28 @@ class _Engine:
             keep[name] = t.detach().to(device=dev, dtype=torch.float32).contiguous()
             return keep[name].data_ptr()
 
+        H, hd = self.c.heads, self.head_dim
+
+        def pad_out(t):      # [H*hd, ...] -> [H*128, ...]: zero rows after each head (projection OUTPUT side)
+            if hd == 128:
+                return t
+            t = t.detach()
+            shp = t.shape[1:]
+            z = torch.zeros((H, 128) + tuple(shp), device=t.device, dtype=t.dtype)
+            z[:, :hd] = t.reshape((H, hd) + tuple(shp))
+            return z.reshape((H * 128,) + tuple(shp))
+
+        def pad_in(t):       # [D, H*hd] -> [D, H*128]: zero columns after each head (projection INPUT side)
+            if hd == 128:
+                return t
+            t = t.detach()
+            z = torch.zeros((t.shape[0], H, 128), device=t.device, dtype=t.dtype)
+            z[:, :, :hd] = t.reshape(t.shape[0], H, hd)
+            return z.reshape(t.shape[0], H * 128)
+
         def attn(prefix, a: Attention):
-            return capi.AttnWeights(wq=w16(prefix + "wq", a.q_proj.weight), bq=f32(prefix + "bq", a.q_proj.bias),
-                                    wo=w16(prefix + "wo", a.residual.dense.weight), bo=f32(prefix + "bo", a.residual.dense.bias),
+            return capi.AttnWeights(wq=w16(prefix + "wq", pad_out(a.q_proj.weight)), bq=f32(prefix + "bq", pad_out(a.q_proj.bias)),
+                                    wo=w16(prefix + "wo", pad_in(a.residual.dense.weight)), bo=f32(prefix + "bo", a.residual.dense.bias),
                                     ln_g=f32(prefix + "g", a.residual.layernorm.weight),
                                     ln_b=f32(prefix + "b", a.residual.layernorm.bias))
 
@@ -186,8 +210,8 @@ class _Engine:
         # initial_memory + memory_pos_embed in the parameter dtype, then cast (MemoryController.py:123-124)
         W.mem0 = w16("mem0", (proj.initial_memory + proj.memory_pos_embed).reshape(R, D))
         ats = [l.memory_segment_fusion_attention for l in proj.layers]
-        W.w_kv_seg = w16("wkv", torch.cat([t for a in ats for t in (a.k_proj.weight, a.v_proj.weight)], dim=0))
-        W.b_kv_seg = f32("bkv", torch.cat([t for a in ats for t in (a.k_proj.bias, a.v_proj.bias)], dim=0))
+        W.w_kv_seg = w16("wkv", torch.cat([pad_out(t) for a in ats for t in (a.k_proj.weight, a.v_proj.weight)], dim=0))
+        W.b_kv_seg = f32("bkv", torch.cat([pad_out(t) for a in ats for t in (a.k_proj.bias, a.v_proj.bias)], dim=0))
         for l, layer in enumerate(proj.layers):
             W.layer_attn[l] = attn(f"l{l}.", ats[l])
             W.w_up[l] = w16(f"l{l}.up", layer.mlp[0].weight)
@@ -198,8 +222,8 @@ class _Engine:
             W.ln2_b[l] = f32(f"l{l}.b2", layer.residual.layernorm.bias)
         e = proj.memory_update_attention
         W.evo = attn("evo.", e)
-        W.w_kv_evo = w16("evo.wkv", torch.cat([e.k_proj.weight, e.v_proj.weight], dim=0))
-        W.b_kv_evo = f32("evo.bkv", torch.cat([e.k_proj.bias, e.v_proj.bias], dim=0))
+        W.w_kv_evo = w16("evo.wkv", torch.cat([pad_out(e.k_proj.weight), pad_out(e.v_proj.weight)], dim=0))
+        W.b_kv_evo = f32("evo.bkv", torch.cat([pad_out(e.k_proj.bias), pad_out(e.v_proj.bias)], dim=0))
         if fuser is not None and type_emb is not None:
             te = type_emb.weight.detach().to(device=dev, dtype=dt)
             W.w_f1 = w16("f1", fuser[0].weight)
@@ -225,7 +249,8 @@ class _Engine:
         c = self.c
         R, S, D, I, L, H = c.mem_tokens * c.patches, c.max_chunk_frames * c.patches, c.hidden, c.inter, c.depth, c.heads
         names = ("kv_seg", "q", "ctx", "a", "h", "pre", "mA", "mB", "lse2", "part")
-        shapes = ((S, 2 * L * D), (R, D), (R, D), (R, D), (R, I), (R, D), (R, D), (R, D), (H, R), (H, S))
+        Dp = self.Dp
+        shapes = ((S, 2 * L * Dp), (R, Dp), (R, Dp), (R, D), (R, I), (R, D), (R, D), (R, D), (H, R), (H, S))
         dts = (self.dtype,) * 5 + (torch.float32, self.dtype, self.dtype, torch.float32, torch.float32)
         out = {}
         for n_, o, shp, dt in zip(names, offs, shapes, dts):

@@ -58,9 +58,12 @@ def make_projector(cfg: O.PathConfig, w, mode="bf16", cache_cap=10):
     return m.to("cuda").to(DT[mode])
 
 
-@pytest.mark.parametrize("mode,H,M,frames", [("bf16", 8, 8, [3, 2, 3, 1]), ("fp16", 2, 4, [2, 1, 2]), ("bf16", 1, 3, [1, 1])])
-def test_recurrent_steps_vs_oracle(mode, H, M, frames):
-    cfg = O.PathConfig(hidden=128 * H, heads=H, mem_tokens=M, depth=2)
+@pytest.mark.parametrize("mode,H,M,frames,hd", [("bf16", 8, 8, [3, 2, 3, 1], 128), ("fp16", 2, 4, [2, 1, 2], 128),
+                                                 ("bf16", 1, 3, [1, 1], 128), ("bf16", 8, 8, [2, 3, 1], 112),
+                                                 ("fp16", 4, 2, [1, 2], 64)])
+def test_recurrent_steps_vs_oracle(mode, H, M, frames, hd):
+    """hd = 112 is the Qwen2-0.5B shape (D = 896, the reference Config default): heads run zero-padded to 128."""
+    cfg = O.PathConfig(hidden=hd * H, heads=H, mem_tokens=M, depth=2)
     w = O.make_weights(cfg, seed=5, grid=mode)
     proj = make_projector(cfg, w, mode)
     r = O.rounder(mode)

@@ -50,8 +50,13 @@ def test_config_validation_without_gpu(built_lib):
     assert lib.mavlm_steps(h) == 0 and lib.mavlm_cache_len(h) == 0 and lib.mavlm_newest_slot(h) == -1
     assert lib.mavlm_step(h, 1, 4, None, 0, None) == capi.E_STATE       # nothing bound yet
     lib.mavlm_destroy(h)
-    bad = capi.Config(hidden=896, heads=8, patches=196, mem_tokens=8, depth=2, inter=3584, cache_cap=10,
-                      max_chunk_frames=32, dtype=0, eps=1e-12)               # head_dim 112: not implemented yet
+    q05 = capi.Config(hidden=896, heads=8, patches=196, mem_tokens=8, depth=2, inter=3584, cache_cap=10,
+                      max_chunk_frames=32, dtype=0, eps=1e-12)               # Qwen2-0.5B: head_dim 112, padded to 128
+    h2 = capi.vp()
+    assert lib.mavlm_create(q05, h2) == 0
+    lib.mavlm_destroy(h2)
+    bad = capi.Config(hidden=3584, heads=8, patches=196, mem_tokens=8, depth=2, inter=14336, cache_cap=10,
+                      max_chunk_frames=32, dtype=0, eps=1e-12)               # OV-7B: head_dim 448, not implemented yet
     assert lib.mavlm_create(bad, capi.vp()) == capi.E_SHAPE
     bad2 = capi.Config(hidden=1024, heads=8, patches=196, mem_tokens=0, depth=2, inter=4096, cache_cap=10,
                        max_chunk_frames=32, dtype=0, eps=1e-12)
