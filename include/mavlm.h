@@ -142,6 +142,9 @@ int mavlm_row_add(const void* x, const int64_t* src, const void* table, const in
 /* tuning hook: force the GEMM block tile (128 or 256; 0 = automatic choice by grid size).  Results are identical
  * up to fp32 summation order. */
 int mavlm_set_gemm_tile(int32_t tile);
+/* tuning hook: attention forward kernel - 2 = register-staged (attention.hip), 3 = software-pipelined LDS-DMA
+ * (attention3.hip), 0 = default (3).  Same rounding points; results equal up to fp32 summation order. */
+int mavlm_set_attention_impl(int32_t impl);
 
 /* --- measurement hooks (bench.py only; new - the reference has no profiling) ------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on its own stream.  Kinds: 0 GEMM, 1 attention

@@ -63,6 +63,7 @@ SIGNATURES = {
     "mavlm_layernorm": (C.c_int, [vp, vp, vp, vp, i32, i32, C.c_float, i32, vp]),
     "mavlm_row_add": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mavlm_set_gemm_tile": (C.c_int, [i32]),
+    "mavlm_set_attention_impl": (C.c_int, [i32]),
     "mavlm_prof_enable": (C.c_int, [i32]),
     "mavlm_prof_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), i32]),

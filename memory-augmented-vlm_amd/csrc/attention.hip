@@ -396,9 +396,13 @@ hipError_t set_lds(K kern, int bytes) {
 
 }  // namespace
 
+static hipError_t launch_attention2(const mavlm_attn_args& a, int dtype, hipStream_t s, float c, dim3 grid);
+
 static bool attn_args_ok(const void* q, int ldq, const void* k, int ldk, int R, int S, int H) {
   return q && k && R > 0 && S > 0 && H > 0 && (ldq & 7) == 0 && (ldk & 7) == 0 && ldq >= H * HD && ldk >= HD;
 }
+
+int g_mavlm_attn_impl = 0;
 
 hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream_t s) {
   if (!attn_args_ok(a.Q, a.ldq, a.K, a.ldk, a.R, a.S, a.H) || !a.V || !a.O || (a.ldv & 7) || (a.ldo & 3))
@@ -407,6 +411,11 @@ hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream
   dim3 grid(((a.R + 127) / 128) * a.H);
   mavlm_prof_scope prof(MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD,
                         2.0 * HD * a.H * (2.0 * a.R + 2.0 * a.S), s);
+  if (g_mavlm_attn_impl != 2) return mavlm_launch_attention3(a, dtype, s);
+  return launch_attention2(a, dtype, s, c, grid);
+}
+
+static hipError_t launch_attention2(const mavlm_attn_args& a, int dtype, hipStream_t s, float c, dim3 grid) {
   static bool done[2] = {false, false};
   if (dtype == MAVLM_F16) {
     if (!done[1]) { hipError_t e = set_lds(attn_fwd_kernel<F16>, ATTN_LDS); if (e != hipSuccess) return e; done[1] = true; }

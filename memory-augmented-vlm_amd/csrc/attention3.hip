@@ -1,0 +1,322 @@
+// attn_fwd3_kernel: software-pipelined flash attention (head_dim 128) - same math, MFMA mapping and LDS image as
+// attn_fwd_kernel (attention.hip), restructured around what the in-kernel stamps of that kernel showed
+// (cycles per 64-key tile per wave: QK^T 1100, softmax 880, P.V 1180, register->LDS staging 630):
+//
+//   * K/V tiles arrive by LDS-DMA (16-byte global_load_lds; the XOR swizzle of the image is applied to the per-lane
+//     SOURCE address) - no VGPR staging, no ds_write phase.
+//   * Each wave overlaps its own matrix and vector work: while the 16 MFMAs of S(t+1) = K(t+1).Q^T issue, the
+//     exp2/fma of tile t's softmax run in their shadow; while the 16 MFMAs of O += V(t)^T.P(t)^T issue, the row
+//     sums and 16-bit converts of tile t and the row maximum of tile t+1 run.  Two S tiles are live (the registers
+//     the DMA staging freed).
+//   * The tile loop is unrolled by two, so every LDS address is a loop-invariant VGPR plus an immediate.
+//
+// Ring: K(t+1) is consumed one iteration before V(t+1), so K and V each keep two 16 KiB slots:
+//   iteration t reads K[(t+1)&1] and V[t&1]; at its top it issues the DMA of K(t+2) -> K[t&1] and V(t+1) -> V[(t+1)&1]
+//   (both slots were last read in iteration t-1, before the closing barrier); it ends with vmcnt(0) + s_barrier.
+#include "mavlm_common.h"
+#include "mavlm_kernels.h"
+
+namespace {
+
+constexpr int HD3 = 128, KT3 = 64;
+constexpr int TILE3 = KT3 * HD3 * 2;          // 16 KiB
+constexpr int ATTN3_LDS = 4 * TILE3;          // K0 K1 V0 V1
+constexpr float RESCALE3_LOG2 = 8.0f;         // same deferred-rescale rule as attn_fwd_kernel (mirrored by the oracle)
+
+__device__ __forceinline__ int img3_x(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+template <int V>
+struct IC { static constexpr int value = V; };
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __restrict__ Q, int ldq,
+                                                           const uint16_t* __restrict__ K, int ldk,
+                                                           const uint16_t* __restrict__ V, int ldv,
+                                                           uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
+                                                           int R, int S, int H, float c) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.x % H;                               // one head per XCD L2 when H == 8
+  const int q0 = (blockIdx.x / H) * 128 + wave * 32;
+  const int r = lane & 31, hh = lane >> 5;
+  const int nt = (S + KT3 - 1) / KT3;
+
+  // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0+r][h*128 + 16ks + 8hh + 0..7]
+  typename T::vec8 qf[8];
+  {
+    int qrow = q0 + r;
+    qrow = qrow < R ? qrow : R - 1;
+    const uint16_t* qp = Q + (size_t)qrow * ldq + h * HD3 + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const typename T::vec8*)(qp + 16 * ks);
+  }
+
+  // ---- LDS-DMA geometry: instruction i (0..3) of wave w writes the 1 KiB block of rows 16 i + 4 w + (lane>>4).
+  // Physical 16-B chunk p = lane & 15 of row `row` holds logical chunk p ^ x(row), x = ((row&3)<<2) | ((row>>2)&3)
+  // = ((lane>>4)<<2) | w: independent of i, so the four sources of a tile differ by the uniform stride 16*ld.
+  const int drow = 4 * wave + (lane >> 4);                    // + 16 i
+  const int dch = (lane & 15) ^ (((lane >> 4) << 2) | wave);
+  const int koff = drow * ldk + h * HD3 + dch * 8;            // element offset of instruction 0 inside a tile
+  const int voff = drow * ldv + h * HD3 + dch * 8;
+  auto dma_tile = [&](const uint16_t* base, int ld, int off, int t, char* dst) {
+    char* d = dst + wave * 1024;
+    if ((t + 1) * KT3 <= S) {                                 // full tile: uniform base + one per-lane offset
+      const uint16_t* b = base + (size_t)t * KT3 * ld;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)(b + (size_t)i * 16 * ld + off),
+                                         (MAVLM_LDS void*)(d + i * 4096), 16, 0, 0);
+    } else {                                                  // ragged last tile: clamp the row (masked later)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int row = t * KT3 + drow + 16 * i;
+        row = row < S ? row : S - 1;
+        const uint16_t* p = base + (size_t)row * ld + h * HD3 + dch * 8;
+        __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)p, (MAVLM_LDS void*)(d + i * 4096), 16, 0, 0);
+      }
+    }
+  };
+  char* const kbuf = smem;                 // K slots at 0, TILE3
+  char* const vbuf = smem + 2 * TILE3;     // V slots at 2*TILE3, 3*TILE3
+
+  // ---- fragment read geometry (loop-invariant VGPRs; stage / block / k-step offsets are immediates)
+  const int xr = img3_x(r);
+  int kaddr[8];                                               // K row read: + TILE3*slot + 8192*b
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kaddr[ks] = 256 * r + 16 * ((2 * ks + hh) ^ xr);
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+  const int v_rd = 256 * (4 * hh + tq) + 8 * (tp & 1) + 16 * ((tp >> 1) ^ hh);
+  unsigned vaddr[4][2];                                       // [db][jj]: + TILE3*slot + 256*(32b+16s)
+  const unsigned vbase = (unsigned)(uintptr_t)(MAVLM_LDS const char*)vbuf;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+      vaddr[db][jj] = vbase + v_rd + 256 * 8 * jj + 16 * (((db ^ tq) << 2) | ((tg1 ^ jj) << 1));
+
+  f32x16 ot[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ot[d][i] = 0.f;
+  f32x16 st[2][2];                                            // [parity][key block]
+  float m_run = -1e30f, l_run = 0.f;
+
+  // S(t) = K(t).Q^T into st[P] (no overlap; used for tile 0 only)
+  auto qk_plain = [&](auto par, int slot) {
+    constexpr int P = decltype(par)::value;
+    const char* kb = kbuf + slot * TILE3;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st[P][b][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const typename T::vec8 kf = *(const typename T::vec8*)(kb + kaddr[i >> 1] + 8192 * (i & 1));
+      st[P][i & 1] = T::mfma32(kf, qf[i >> 1], st[P][i & 1]);
+    }
+  };
+  auto mask_tail = [&](auto par, int t) {
+    constexpr int P = decltype(par)::value;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = t * KT3 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (key >= S) st[P][b][i] = -INFINITY;
+      }
+  };
+  // row maximum of S in st[P] across the wave's 64 keys; deferred-rescale decision (wave-uniform), applied to O and l
+  auto max_and_rescale = [&](auto par) {
+    constexpr int P = decltype(par)::value;
+    float mx = st[P][0][0];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[P][b][i]);
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    if (__any((m_new - m_run) * c > RESCALE3_LOG2)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ot[d][i] *= alpha;
+    }
+  };
+
+  // ---- prologue: K(0), V(0), K(1) ; S(0) ; reference maximum for tile 0
+  dma_tile(K, ldk, koff, 0, kbuf);
+  dma_tile(V, ldv, voff, 0, vbuf);
+  if (nt > 1) dma_tile(K, ldk, koff, 1, kbuf + TILE3);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));   // Q resident before the loop (see attention.hip)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  qk_plain(IC<0>{}, 0);
+  if (nt == 1 && (S & (KT3 - 1))) mask_tail(IC<0>{}, 0);
+  max_and_rescale(IC<0>{});
+
+  // ---- one pipelined iteration: S in st[P] (tile t, reference m_run already decided), S' of tile t+1 into st[P^1]
+  auto iteration = [&](auto par, int t) {
+    constexpr int P = decltype(par)::value;
+    constexpr int N = P ^ 1;
+    const bool has_next = t + 1 < nt;
+    // K(t+2) -> K slot (t&1) == P ; V(t+1) -> V slot N.  Both slots were last read before the previous barrier.
+    if (t + 2 < nt) dma_tile(K, ldk, koff, t + 2, kbuf + P * TILE3);
+    if (has_next) dma_tile(V, ldv, voff, t + 1, vbuf + N * TILE3);
+
+    const float mc = m_run * c;
+    // [A] S'(t+1) = K(t+1).Q^T  ||  p = exp2(s*c - mc) for tile t (2 elements per MFMA).  The order is pinned with
+    // sched_barrier(0): left alone hipcc hoists all 32 v_exp in front of the MFMA chain (no overlap at all) and sinks
+    // the fragment reads to their use; K fragments are read KPF steps ahead.
+    if (has_next) {
+      const char* kb = kbuf + N * TILE3;                      // K(t+1) sits in slot (t+1)&1 == N
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[N][b][i] = 0.f;
+      constexpr int KPF = 1;
+      typename T::vec8 kfr[16];
+#pragma unroll
+      for (int i = 0; i < KPF; ++i) kfr[i] = *(const typename T::vec8*)(kb + kaddr[i >> 1] + 8192 * (i & 1));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i + KPF < 16)
+          kfr[i + KPF] = *(const typename T::vec8*)(kb + kaddr[(i + KPF) >> 1] + 8192 * ((i + KPF) & 1));
+        st[N][i & 1] = T::mfma32(kfr[i], qf[i >> 1], st[N][i & 1]);
+        const int e0 = 2 * i, e1 = 2 * i + 1;                 // elements (b = e>>4, idx = e&15) of tile t
+        // The two empty asm statements are ordered against sched_barrier (both have side effects); the pure
+        // fma/exp between them cannot be hoisted in front of the MFMA chain or sunk behind it.
+        float x0 = st[P][e0 >> 4][e0 & 15], x1 = st[P][e1 >> 4][e1 & 15];
+        asm volatile("" : "+v"(x0), "+v"(x1));
+        x0 = __builtin_amdgcn_exp2f(x0 * c - mc);
+        x1 = __builtin_amdgcn_exp2f(x1 * c - mc);
+        asm volatile("" : "+v"(x0), "+v"(x1));
+        st[P][e0 >> 4][e0 & 15] = x0;
+        st[P][e1 >> 4][e1 & 15] = x1;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[P][b][i] = __builtin_amdgcn_exp2f(st[P][b][i] * c - mc);
+    }
+
+    // [B] O^T += V(t)^T.P(t)^T  ||  16-bit converts + row sums of tile t, row maximum of tile t+1
+    if (has_next && t + 1 == nt - 1 && (S & (KT3 - 1))) mask_tail(IC<N>{}, t + 1);
+    float psum = 0.f;
+    float mx = has_next ? st[N][0][0] : 0.f;
+    {
+      constexpr int VPF = 1;
+      typename T::vec4 vlo[16], vhi[16];
+      typename T::vec8 pf[4];
+      auto vread = [&](int i) {                               // step i = (bs = i>>2, db = i&3)
+        const int bs = i >> 2, db = i & 3;
+        const unsigned off = P * TILE3 + 256 * (32 * (bs >> 1) + 16 * (bs & 1));
+        vlo[i] = T::ds_read_tr(vaddr[db][0] + off);
+        vhi[i] = T::ds_read_tr(vaddr[db][1] + off);
+      };
+      auto cvt = [&](int bs) {                                // P^T fragment of keys 16 bs .. 16 bs + 15
+        u32x4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          w[j] = pack2<T>(st[P][bs >> 1][8 * (bs & 1) + 2 * j], st[P][bs >> 1][8 * (bs & 1) + 2 * j + 1]);
+        pf[bs] = __builtin_bit_cast(typename T::vec8, w);
+      };
+#pragma unroll
+      for (int i = 0; i < VPF; ++i) vread(i);
+      cvt(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int bs = i >> 2, db = i & 3;
+        if (i + VPF < 16) vread(i + VPF);
+        const typename T::vec8 vf = __builtin_shufflevector(vlo[i], vhi[i], 0, 1, 2, 3, 4, 5, 6, 7);
+        ot[db] = T::mfma32(vf, pf[bs], ot[db]);
+        if (db == 1 && bs < 3) cvt(bs + 1);                   // next group's converts, 2 MFMAs ahead of their use
+        const int e0 = 8 * bs + 2 * db, e1 = e0 + 1;          // 2 of the 32 p values / 2 of the next 32 scores per MFMA
+        psum += st[P][e0 >> 4][e0 & 15];
+        psum += st[P][e1 >> 4][e1 & 15];
+        if (has_next) mx = fmaxf(mx, fmaxf(st[N][e0 >> 4][e0 & 15], st[N][e1 >> 4][e1 & 15]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    l_run += psum;
+
+    // reference maximum for tile t+1 (after P.V(t): the rescale touches O)
+    if (has_next) {
+      mx = xhalf_max(mx);
+      const float m_new = fmaxf(m_run, mx);
+      if (__any((m_new - m_run) * c > RESCALE3_LOG2)) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) ot[d][i] *= alpha;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMAs of K(t+2), V(t+1) have landed
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    iteration(IC<0>{}, t);
+    iteration(IC<1>{}, t + 1);
+  }
+  if (t < nt) iteration(IC<0>{}, t);
+
+  // ---- epilogue: O[q][h*128 + 32db + 8g + 4hh + 0..3] = O^T / l
+  const float l_tot = xhalf_sum(l_run);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + r;
+  if (q < R) {
+    uint16_t* op = O + (size_t)q * ldo + h * HD3 + 4 * hh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(u32x2*)(op + 32 * db + 8 * g) = pack4<T>(ot[db][4 * g] * inv, ot[db][4 * g + 1] * inv,
+                                                   ot[db][4 * g + 2] * inv, ot[db][4 * g + 3] * inv);
+    if (lse2 != nullptr && hh == 0) lse2[(size_t)h * R + q] = m_run * c + log2f(l_tot);
+  }
+}
+
+}  // namespace
+
+hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStream_t s) {
+  const float c = a.scale * 1.44269504088896340736f;
+  dim3 grid(((a.R + 127) / 128) * a.H);
+  static bool done[2] = {false, false};
+  if (dtype == MAVLM_F16) {
+    if (!done[1]) {
+      hipError_t e = hipFuncSetAttribute((const void*)attn_fwd3_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN3_LDS);
+      if (e != hipSuccess) return e;
+      done[1] = true;
+    }
+    hipLaunchKernelGGL(attn_fwd3_kernel<F16>, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
+                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c);
+  } else {
+    if (!done[0]) {
+      hipError_t e = hipFuncSetAttribute((const void*)attn_fwd3_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN3_LDS);
+      if (e != hipSuccess) return e;
+      done[0] = true;
+    }
+    hipLaunchKernelGGL(attn_fwd3_kernel<BF16>, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
+                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c);
+  }
+  return hipGetLastError();
+}

@@ -94,6 +94,12 @@ extern "C" {
 
 int mavlm_abi_version(void) { return MAVLM_ABI_VERSION; }
 
+int mavlm_set_attention_impl(int32_t impl) {
+  if (impl != 0 && impl != 2 && impl != 3) return MAVLM_E_ARG;
+  g_mavlm_attn_impl = impl;
+  return 0;
+}
+
 int mavlm_set_gemm_tile(int32_t tile) {
   if (tile != 0 && tile != 128 && tile != 256) return MAVLM_E_ARG;
   g_mavlm_gemm_tile = tile;

@@ -31,6 +31,9 @@ struct mavlm_attn_args {
   float scale;                   // 1/sqrt(head_dim)
 };
 hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream_t s);
+// software-pipelined LDS-DMA variant (attention3.hip); mavlm_launch_attention dispatches to it
+hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStream_t s);
+extern int g_mavlm_attn_impl;   // 0 = auto, 2 = register-staged kernel, 3 = pipelined kernel (tuning hook)
 
 // column sums of the normalised probabilities: part[h][k] = sum_q exp2(s*c - lse2[h][q])
 struct mavlm_colsum_args {

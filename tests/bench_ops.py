@@ -28,11 +28,15 @@ def timeit(fn, flops, name):
 
 R, S, H, D = 12544, 6272, 8, 1024
 if what in ("attn", "all"):
+  for impl in (2, 3):
+    capi.lib().mavlm_set_attention_impl(impl)
+    print("attention impl", impl)
     q = torch.randn(R, D, device=dev).bfloat16()
     kv = torch.randn(S, 4 * D, device=dev).bfloat16()
     timeit(lambda: ops.attention(q, kv[:, :D], kv[:, D:2 * D], H, want_lse=True), 4.0 * R * S * D, f"attn R={R} S={S}")
     kv2 = torch.randn(R, 2 * D, device=dev).bfloat16()
     timeit(lambda: ops.attention(q, kv2[:, :D], kv2[:, D:], H), 4.0 * R * R * D, f"attn R={R} S={R} (evolution n=1)")
+  capi.lib().mavlm_set_attention_impl(0)
 if what in ("colsum", "all"):
     q = torch.randn(R, D, device=dev).bfloat16()
     kv = torch.randn(S, 4 * D, device=dev).bfloat16()

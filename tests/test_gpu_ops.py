@@ -65,6 +65,14 @@ def test_linear_random_vs_oracle(M, N, K, epi, gemm_tile):
     assert O.rel_l2(got, r(y)) < TOL
 
 
+@pytest.fixture(params=[2, 3])
+def attn_impl(request):
+    """Run the attention tests once per forward kernel (2 = register-staged, 3 = software-pipelined LDS-DMA)."""
+    capi.check(capi.lib().mavlm_set_attention_impl(request.param), "set attention impl")
+    yield request.param
+    capi.lib().mavlm_set_attention_impl(0)
+
+
 def _attn_oracle(q, k, v, H, mode="bf16"):
     """ctx (rounded to the 16-bit grid), lse2 [H,R], per-head column sums [H,S] from the oracle's emulation of the
     kernel (64-key tiles, running maximum, P rounded per tile)."""
@@ -73,8 +81,9 @@ def _attn_oracle(q, k, v, H, mode="bf16"):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
-@pytest.mark.parametrize("R,S,H", [(32, 64, 1), (200, 300, 2), (128, 64 * 5 + 1, 1), (392, 588, 8), (1, 1, 1)])
-def test_attention_vs_oracle(mode, R, S, H):
+@pytest.mark.parametrize("R,S,H", [(32, 64, 1), (200, 300, 2), (128, 64 * 5 + 1, 1), (392, 588, 8), (1, 1, 1), (64, 128, 1),
+                                   (129, 64 * 3, 2), (300, 64 * 4 + 63, 1)])
+def test_attention_vs_oracle(mode, R, S, H, attn_impl):
     r = O.rounder(mode)
     q = r(O.hash_normal_like((R, H * 128), 21))
     k = r(O.hash_normal_like((S, H * 128), 22))
@@ -89,7 +98,7 @@ def test_attention_vs_oracle(mode, R, S, H):
     assert abs(float(part.sum()) - H * R) < 1e-3 * H * R
 
 
-def test_attention_strided_kv_and_identity_v():
+def test_attention_strided_kv_and_identity_v(attn_impl):
     """K/V as column slices of a wider [S, 4D] buffer (how the step lays them out) and V = one-hot columns:
     ctx then equals the probabilities themselves - catches any key/column permutation error in the P.V MFMA."""
     R, S, H = 64, 128, 2
@@ -108,7 +117,7 @@ def test_attention_strided_kv_and_identity_v():
     assert O.rel_l2(to_np(got), ctx) < TOL
 
 
-def test_attention_forced_rescale():
+def test_attention_forced_rescale(attn_impl):
     """Rule 26: force the online-softmax rescale branch - one key in a LATE tile dominates one query row."""
     R, S, H = 64, 64 * 6, 1
     r = O.bf16_round
