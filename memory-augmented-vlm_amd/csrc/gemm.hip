@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const uint16_t* __restr
       if (EPI == MAVLM_EPI_RELU) {
         v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
       } else if (EPI == MAVLM_EPI_GELU) {
-        v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+        v0 = gelu_erf_fast(v0); v1 = gelu_erf_fast(v1); v2 = gelu_erf_fast(v2); v3 = gelu_erf_fast(v3);
       }
       if (EPI == MAVLM_EPI_RES_F32) {
         const u16x4 rv = *(const u16x4*)(res + (size_t)m * ldr + n);

@@ -15,11 +15,23 @@
 //     (this stage).  Loads therefore stay in flight across barriers; the only vmcnt wait is a COUNTED one per K-tile
 //     (vmcnt(6): the three youngest half-tiles stay in flight), never 0 inside the loop.
 //   * Raw s_barrier (a __syncthreads() would drain the DMA queue), MFMA clusters bracketed by s_setprio.
+//   * Ping-pong: every phase is two barrier segments, L (fragment reads + DMA issue + the counted wait) and M (16
+//     MFMAs).  Waves 4-7 run ONE SEGMENT BEHIND waves 0-3 (they execute one extra s_barrier before their first
+//     segment, waves 0-3 one extra after their last, so both groups execute the same number of barriers).  Each
+//     SIMD hosts one wave of either group, so while one group's M segment owns the matrix pipe the other group
+//     issues its LDS reads and DMAs.  Without the skew all eight waves are in lockstep: both waves of a SIMD do
+//     their MFMAs back to back and then both sit in the L segment with the pipe idle (measured: 3.8k clk per
+//     K-tile against 2.05k of MFMA).
 //
-// Hazards (LDS-DMA is ordered by nothing but the issuing wave's vmcnt + a barrier):
-//   RAW  K-tile kt+1 is read in the phase after {vmcnt(6) ; barrier} at the end of K-tile kt's phase 4.
-//   WAR  a half-tile is re-staged >= 1 full phase after its last ds_read; those reads were retired by the
-//        lgkmcnt(0) in front of that phase's MFMAs and a barrier separates them from the DMA issue.
+// Hazards (LDS-DMA is ordered by nothing but the issuing wave's vmcnt + a barrier), with g = global barrier index,
+// the leading group executing segment g and the trailing group segment g-1, K-tile kt = segments 8kt+1 .. 8kt+8
+// (L1 M1 L2 M2 L3 M3 L4 M4), stage s = kt & 1:
+//   reads of stage s: L1 (A rows 0-63 + B) and L3 (A rows 64-127): g = 8kt+1, 8kt+5 (leading), 8kt+2, 8kt+6 (trailing);
+//        every read is retired by the lgkmcnt(0) at the top of the following M segment.
+//   WAR  B half-tiles of s are dead from g = 8kt+3, A half-tiles from g = 8kt+7.  Re-staging (K-tile kt+2) is issued
+//        by the leading group in L2 (g = 8kt+3: B0), L3 (8kt+5: B1), L4 (8kt+7: A0) and the next L1 (8kt+9: A1).
+//   RAW  K-tile kt+1 is first read at g = 8kt+9.  Its last half-tile (A1) is issued in L1 of kt; both groups wait
+//        vmcnt(6) in L4 (g = 8kt+7 / 8kt+8) and pass a barrier before g = 8kt+9.
 #include "mavlm_common.h"
 #include "mavlm_kernels.h"
 
@@ -108,6 +120,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   typename T::vec8 bf[4][2];      // [n-tile of the wave's 64 columns][k-step]
 
   const int nk = K / BK2;
+  const bool trailing = wm == 1;     // waves 4-7 (wave-uniform: wm comes from a readfirstlane)
 
   // ---- prologue: K-tile 0 completely, K-tile 1 minus its last half-tile (order B0,B1,A0,A1)
   dma(0, 2, 0); dma(0, 3, 0); dma(0, 0, 0); dma(0, 1, 0);
@@ -143,6 +156,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
     __builtin_amdgcn_s_setprio(0);                                                          \
   }
 
+  if (trailing) MAVLM_BAR();           // ping-pong skew: pairs with the leading group's first in-loop barrier
+
   for (int kt = 0; kt < nk; ++kt) {
     const int s = kt & 1;
     const char* st = smem + s * STAGE2;
@@ -177,6 +192,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
     MAVLM_QUADRANT(1, 0)
     MAVLM_BAR();
   }
+  if (!trailing) MAVLM_BAR();          // matches the trailing group's last barrier
 #undef MAVLM_QUADRANT
 
   // ---- epilogue: lane holds C[m][n..n+3], m = m0 + wm*128 + 16 i + fr, n = n0 + wn*64 + 16 j + 4 fq
@@ -193,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
       if (EPI == MAVLM_EPI_RELU) {
         v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
       } else if (EPI == MAVLM_EPI_GELU) {
-        v0 = gelu_erf2(v0); v1 = gelu_erf2(v1); v2 = gelu_erf2(v2); v3 = gelu_erf2(v3);
+        v0 = gelu_erf_fast(v0); v1 = gelu_erf_fast(v1); v2 = gelu_erf_fast(v2); v3 = gelu_erf_fast(v3);
       }
       if (EPI == MAVLM_EPI_RES_F32) {
         const u16x4 rv = *(const u16x4*)(res + (size_t)m * ldr + n);
