@@ -191,14 +191,23 @@ def main():
                              "ms_per_step": round(ms[i] / args.steps, 4),
                              "tflops": round(fl[i] / (ms[i] * 1e-3) / 1e12, 1) if fl[i] else None,
                              "alg_gbs": round(by[i] / (ms[i] * 1e-3) / 1e9, 1)}
-    dom = max(("gemm", "attention_fwd"), key=lambda k: kernels.get(k, {}).get("ms_per_step", 0.0))
+    # Dominant kernel SYMBOL: attn_fwd3_kernel<BF16> (5 launches per video of one template; the GEMM time is spread
+    # over four epilogue instantiations of two tile kernels, see `kernels`).
+    dom = "attention_fwd"
     di = capi.KERNEL_KINDS.index(dom)
     achieved = fl[di] / (ms[di] * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_attn_fwd3_hbm_traffic.json")
+    if os.path.exists(tpath):      # PMC summary committed from a separate rocprofv3 --pmc run (tests/pmc_traffic.sh)
+        traffic = json.load(open(tpath)).get("bench_avg_bytes_per_launch")
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "kernel": {"gemm": "gemm_tn_kernel<BF16,*>", "attention_fwd": "attn_fwd_kernel<BF16>"}[dom],
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_note": "HBM bytes per launch, PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, profiles/"
+                                "r01_attn_fwd3_hbm_traffic.json; algorithmic bytes per launch in alg_bytes_per_launch",
+                "kernel": "attn_fwd3_kernel<BF16>",
                 "avg_launch_ms": round(ms[di] / ln[di], 5), "launches_per_step": ln[di] / args.steps,
-                "alg_flops_per_launch": fl[di] / ln[di]}
+                "alg_flops_per_launch": fl[di] / ln[di], "alg_bytes_per_launch": by[di] / ln[di],
+                "hbm_gbs_algorithmic": round(by[di] / (ms[di] * 1e-3) / 1e9, 1)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

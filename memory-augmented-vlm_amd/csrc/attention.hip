@@ -434,6 +434,7 @@ hipError_t mavlm_launch_colsum(const mavlm_colsum_args& a, int dtype, hipStream_
   const float c = a.scale * 1.44269504088896340736f;
   dim3 grid(((a.S + 127) / 128) * a.H);
   mavlm_prof_scope prof(MAVLM_K_COLSUM, 2.0 * a.R * (double)a.S * a.H * HD, 2.0 * HD * a.H * ((double)a.R + a.S), s);
+  if (g_mavlm_attn_impl != 2) return mavlm_launch_colsum3(a, dtype, s);
   if (dtype == MAVLM_F16)
     hipLaunchKernelGGL(attn_colsum_kernel<F16>, grid, dim3(256), CS_LDS, s, (const uint16_t*)a.Q, a.ldq,
                        (const uint16_t*)a.K, a.ldk, a.lse2, a.part, a.R, a.S, a.H, c);

@@ -320,3 +320,178 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
   }
   return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// attn_colsum3_kernel: column sums of the normalised probabilities (frame scores, MemoryController.py:135-139),
+// software-pipelined like attn_fwd3_kernel.  A wave keeps 32 keys in registers (A operand) and streams the queries:
+// 64-query Q tiles and their 64 lse2 values arrive by LDS-DMA into a 2-slot ring; S^T(qb) for the next 32-query
+// block is computed (8 MFMAs) while exp2(s*c - lse2) of the previous block is accumulated per key in registers.
+namespace {
+
+constexpr int CS3_LSE = 2 * TILE3;             // 2 x 256 B of lse2 behind the two Q slots
+constexpr int CS3_LDS = 2 * TILE3 + 512;
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_colsum3_kernel(const uint16_t* __restrict__ Q, int ldq,
+                                                              const uint16_t* __restrict__ K, int ldk,
+                                                              const float* __restrict__ lse2, float* __restrict__ part,
+                                                              int R, int S, int H, float c) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.x % H;
+  const int k0 = (blockIdx.x / H) * 128 + wave * 32;
+  const int r = lane & 31, hh = lane >> 5;
+  const int nt = (R + KT3 - 1) / KT3;
+
+  typename T::vec8 kf[8];
+  {
+    int krow = k0 + r;
+    krow = krow < S ? krow : S - 1;
+    const uint16_t* kp = K + (size_t)krow * ldk + h * HD3 + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) kf[ks] = *(const typename T::vec8*)(kp + 16 * ks);
+  }
+
+  // Q tile DMA: same geometry as dma_tile of attn_fwd3_kernel
+  const int drow = 4 * wave + (lane >> 4);
+  const int dch = (lane & 15) ^ (((lane >> 4) << 2) | wave);
+  const int qoff = drow * ldq + h * HD3 + dch * 8;
+  const float* lrow = lse2 + (size_t)h * R;
+  auto dma_q = [&](int t, int slot) {
+    char* d = smem + slot * TILE3 + wave * 1024;
+    if ((t + 1) * KT3 <= R) {
+      const uint16_t* b = Q + (size_t)t * KT3 * ldq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)(b + (size_t)i * 16 * ldq + qoff),
+                                         (MAVLM_LDS void*)(d + i * 4096), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int row = t * KT3 + drow + 16 * i;
+        row = row < R ? row : R - 1;
+        const uint16_t* p = Q + (size_t)row * ldq + h * HD3 + dch * 8;
+        __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)p, (MAVLM_LDS void*)(d + i * 4096), 16, 0, 0);
+      }
+    }
+    if (wave == 0) {                                           // 64 lse2 values of the tile: one 4-byte DMA per lane
+      int qi = t * KT3 + lane;
+      qi = qi < R ? qi : R - 1;
+      __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)(lrow + qi), (MAVLM_LDS void*)(smem + CS3_LSE + slot * 256),
+                                       4, 0, 0);
+    }
+  };
+
+  const int xr = img3_x(r);
+  int qaddr[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) qaddr[ks] = 256 * r + 16 * ((2 * ks + hh) ^ xr);
+
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  f32x16 st[2];
+
+  auto qk = [&](auto pc, const char* qb) {                      // st[P] = K . Q(block)^T, 8 MFMAs
+    constexpr int P = decltype(pc)::value;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[P][i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const typename T::vec8 qf = *(const typename T::vec8*)(qb + qaddr[ks]);
+      st[P] = T::mfma32(kf[ks], qf, st[P]);
+    }
+  };
+  // st[P] of block (t, qb) -> acc, while st[P^1] of the following block is being produced
+  auto qk_overlap = [&](auto pc, const char* qb_next, float l2, bool ok) {
+    constexpr int P = decltype(pc)::value;
+    constexpr int N = P ^ 1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[N][i] = 0.f;
+    const float l2m = ok ? l2 : INFINITY;                       // masked query: exp2(-inf) = 0
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const typename T::vec8 qf = *(const typename T::vec8*)(qb_next + qaddr[ks]);
+      st[N] = T::mfma32(kf[ks], qf, st[N]);
+      float x0 = st[P][2 * ks], x1 = st[P][2 * ks + 1];
+      asm volatile("" : "+v"(x0), "+v"(x1));
+      x0 = __builtin_amdgcn_exp2f(x0 * c - l2m);
+      x1 = __builtin_amdgcn_exp2f(x1 * c - l2m);
+      asm volatile("" : "+v"(x0), "+v"(x1));
+      acc[2 * ks] += x0;
+      acc[2 * ks + 1] += x1;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto drain = [&](auto pc, float l2, bool ok) {                // last block: no MFMAs to hide behind
+    constexpr int P = decltype(pc)::value;
+    const float l2m = ok ? l2 : INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += __builtin_amdgcn_exp2f(st[P][i] * c - l2m);
+  };
+
+  dma_q(0, 0);
+  if (nt > 1) dma_q(1, 1);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(kf[ks]));
+  if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile 0 landed; up to 4 DMAs of tile 1 stay in flight
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  qk(IC<0>{}, smem + 0);                                       // block (0, 0)
+
+  for (int t = 0; t < nt; ++t) {
+    const int slot = t & 1;
+    const char* qs = smem + slot * TILE3;
+    const float* ls = (const float*)(smem + CS3_LSE + slot * 256);
+    const float l0 = ls[r], l1 = ls[32 + r];
+    const bool ok0 = t * KT3 + r < R, ok1 = t * KT3 + 32 + r < R;
+    // block (t,0) accumulated under the MFMAs of block (t,1)
+    qk_overlap(IC<0>{}, qs + 8192, l0, ok0);
+    if (t + 1 < nt) {
+      // tile t+1 must be visible before its block 0 is read: this wave's DMAs + barrier
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // every wave has passed the barrier, i.e. finished reading tile t (its block 1 fed the MFMAs above, its lse2
+      // values are in registers): the slot can be refilled while block (t,1) is accumulated
+      if (t + 2 < nt) dma_q(t + 2, slot);
+      qk_overlap(IC<1>{}, smem + (slot ^ 1) * TILE3, l1, ok1);   // block (t,1) under the MFMAs of block (t+1,0)
+    } else {
+      drain(IC<1>{}, l1, ok1);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float v = acc[i];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    acc[i] = v;
+  }
+  if (r == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (key < S) part[(size_t)h * S + key] = acc[i];
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t mavlm_launch_colsum3(const mavlm_colsum_args& a, int dtype, hipStream_t s) {
+  const float c = a.scale * 1.44269504088896340736f;
+  dim3 grid(((a.S + 127) / 128) * a.H);
+  if (dtype == MAVLM_F16)
+    hipLaunchKernelGGL(attn_colsum3_kernel<F16>, grid, dim3(256), CS3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
+                       a.ldk, a.lse2, a.part, a.R, a.S, a.H, c);
+  else
+    hipLaunchKernelGGL(attn_colsum3_kernel<BF16>, grid, dim3(256), CS3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
+                       a.ldk, a.lse2, a.part, a.R, a.S, a.H, c);
+  return hipGetLastError();
+}

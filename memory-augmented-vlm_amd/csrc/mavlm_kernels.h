@@ -45,6 +45,7 @@ struct mavlm_colsum_args {
   float scale;
 };
 hipError_t mavlm_launch_colsum(const mavlm_colsum_args& a, int dtype, hipStream_t s);
+hipError_t mavlm_launch_colsum3(const mavlm_colsum_args& a, int dtype, hipStream_t s);   // pipelined (attention3.hip)
 
 // frame_scores[f] = (1/P) * sum_{p<P} sum_h part[h][f*P+p]     (MemoryController.py:135-139)
 hipError_t mavlm_launch_frame_scores(const float* part, int H, int S, int F, int P, void* out, int out_f32, int dtype,

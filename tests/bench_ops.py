@@ -38,10 +38,13 @@ if what in ("attn", "all"):
     timeit(lambda: ops.attention(q, kv2[:, :D], kv2[:, D:], H), 4.0 * R * R * D, f"attn R={R} S={R} (evolution n=1)")
   capi.lib().mavlm_set_attention_impl(0)
 if what in ("colsum", "all"):
+  for impl in (2, 3):
+    capi.lib().mavlm_set_attention_impl(impl)
     q = torch.randn(R, D, device=dev).bfloat16()
     kv = torch.randn(S, 4 * D, device=dev).bfloat16()
     _, lse = ops.attention(q, kv[:, :D], kv[:, D:2 * D], H, want_lse=True)
-    timeit(lambda: ops.attention_colsum(q, kv[:, :D], lse, H), 2.0 * R * S * D, f"colsum R={R} S={S}")
+    timeit(lambda: ops.attention_colsum(q, kv[:, :D], lse, H), 2.0 * R * S * D, f"colsum impl {impl} R={R} S={S}")
+  capi.lib().mavlm_set_attention_impl(0)
 if what in ("gemm", "all"):
   for tile in (128, 256):
     capi.lib().mavlm_set_gemm_tile(tile)
