@@ -58,15 +58,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
   // = ((lane>>4)<<2) | w: independent of i, so the four sources of a tile differ by the uniform stride 16*ld.
   const int drow = 4 * wave + (lane >> 4);                    // + 16 i
   const int dch = (lane & 15) ^ (((lane >> 4) << 2) | wave);
-  const int koff = drow * ldk + h * HD3 + dch * 8;            // element offset of instruction 0 inside a tile
-  const int voff = drow * ldv + h * HD3 + dch * 8;
-  auto dma_tile = [&](const uint16_t* base, int ld, int off, int t, char* dst) {
+  // byte offset of instruction 0 inside a tile: loop-invariant, 32-bit (added to a wave-uniform 64-bit base that
+  // the scalar unit advances, so a DMA costs no vector address arithmetic)
+  const unsigned koff = (unsigned)(drow * ldk + h * HD3 + dch * 8) * 2u;
+  const unsigned voff = (unsigned)(drow * ldv + h * HD3 + dch * 8) * 2u;
+  auto dma_tile = [&](const uint16_t* base, int ld, unsigned off, int t, char* dst) {
     char* d = dst + wave * 1024;
     if ((t + 1) * KT3 <= S) {                                 // full tile: uniform base + one per-lane offset
-      const uint16_t* b = base + (size_t)t * KT3 * ld;
+      const char* b = (const char*)base + (size_t)t * KT3 * ld * 2;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)(b + (size_t)i * 16 * ld + off),
+        __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)(b + (size_t)i * 32 * ld + off),
                                          (MAVLM_LDS void*)(d + i * 4096), 16, 0, 0);
     } else {                                                  // ragged last tile: clamp the row (masked later)
 #pragma unroll
@@ -216,14 +218,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
     float psum = 0.f;
     float mx = has_next ? st[N][0][0] : 0.f;
     {
-      constexpr int VPF = 1;
-      typename T::vec4 vlo[16], vhi[16];
+      // The transposed V reads go through inline asm with hand-counted lgkmcnt waits: through the builtin, hipcc puts
+      // an s_waitcnt vmcnt(0) in front of the first one (it cannot prove that the read does not alias the LDS-DMA in
+      // flight), which drains this iteration's DMAs of K(t+2) / V(t+1) in the middle of the tile.  These are the only
+      // LGKM operations outstanding in this block (the K reads of [A] were consumed by its MFMAs), so the counts
+      // are exact: step i issues the two reads of step i+1, then waits until only those two are outstanding.
+      u32x2 vlo[16], vhi[16];
       typename T::vec8 pf[4];
-      auto vread = [&](int i) {                               // step i = (bs = i>>2, db = i&3)
-        const int bs = i >> 2, db = i & 3;
-        const unsigned off = P * TILE3 + 256 * (32 * (bs >> 1) + 16 * (bs & 1));
-        vlo[i] = T::ds_read_tr(vaddr[db][0] + off);
-        vhi[i] = T::ds_read_tr(vaddr[db][1] + off);
+      auto vread = [&](auto ic) {                             // step i = (bs = i>>2, db = i&3)
+        constexpr int i = decltype(ic)::value;
+        constexpr int bs = i >> 2, db = i & 3;
+        constexpr int off = P * TILE3 + 256 * (32 * (bs >> 1) + 16 * (bs & 1));
+        // (asm operands do not trigger implicit lambda capture: go through locals)
+        const unsigned a0 = vaddr[db][0], a1 = vaddr[db][1];
+        u32x2 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "i"(off));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "i"(off));
+        vlo[i] = lo;
+        vhi[i] = hi;
       };
       auto cvt = [&](int bs) {                                // P^T fragment of keys 16 bs .. 16 bs + 15
         u32x4 w;
@@ -232,23 +244,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
           w[j] = pack2<T>(st[P][bs >> 1][8 * (bs & 1) + 2 * j], st[P][bs >> 1][8 * (bs & 1) + 2 * j + 1]);
         pf[bs] = __builtin_bit_cast(typename T::vec8, w);
       };
-#pragma unroll
-      for (int i = 0; i < VPF; ++i) vread(i);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // nothing older than the reads below is outstanding
+      vread(IC<0>{});
       cvt(0);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int bs = i >> 2, db = i & 3;
-        if (i + VPF < 16) vread(i + VPF);
-        const typename T::vec8 vf = __builtin_shufflevector(vlo[i], vhi[i], 0, 1, 2, 3, 4, 5, 6, 7);
+      auto step = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int bs = i >> 2, db = i & 3;
+        if constexpr (i + 1 < 16) {
+          vread(IC<i + 1>{});
+          asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);                    // keep the MFMA below the wait (rule 18)
+        u32x4 both;
+        both[0] = vlo[i][0]; both[1] = vlo[i][1]; both[2] = vhi[i][0]; both[3] = vhi[i][1];
+        const typename T::vec8 vf = __builtin_bit_cast(typename T::vec8, both);
         ot[db] = T::mfma32(vf, pf[bs], ot[db]);
         if (db == 1 && bs < 3) cvt(bs + 1);                   // next group's converts, 2 MFMAs ahead of their use
         const int e0 = 8 * bs + 2 * db, e1 = e0 + 1;          // 2 of the 32 p values / 2 of the next 32 scores per MFMA
         psum += st[P][e0 >> 4][e0 & 15];
         psum += st[P][e1 >> 4][e1 & 15];
-        if (has_next) mx = fmaxf(mx, fmaxf(st[N][e0 >> 4][e0 & 15], st[N][e1 >> 4][e1 & 15]));
+        if (has_next) mx = max3_asm(mx, st[N][e0 >> 4][e0 & 15], st[N][e1 >> 4][e1 & 15]);
         __builtin_amdgcn_sched_barrier(0);
-      }
+      };
+      step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{}); step(IC<4>{}); step(IC<5>{}); step(IC<6>{});
+      step(IC<7>{}); step(IC<8>{}); step(IC<9>{}); step(IC<10>{}); step(IC<11>{}); step(IC<12>{}); step(IC<13>{});
+      step(IC<14>{}); step(IC<15>{});
     }
     l_run += psum;
 

@@ -127,6 +127,14 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   return x * (x < 0.f ? q : 1.0f - q);
 }
 
+// max(a, b, c) in ONE instruction.  fmaxf() on MFMA results makes hipcc emit a canonicalising v_max(x, x) per
+// operand first (3 instructions for what v_max3_f32 does in one); the asm form has no such prologue.
+__device__ __forceinline__ float max3_asm(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -12,23 +12,27 @@ dev = "cuda"
 torch.manual_seed(0)
 
 
-def timeit(fn, flops, name):
-    for _ in range(3):
+def timeit(fn, flops, name, rounds=5):
+    for _ in range(5):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    print(f"{name:44s} {ms*1e3:9.1f} us  {flops/ms/1e9:8.1f} TFLOP/s", flush=True)
+    t = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t.append(e0.elapsed_time(e1) / iters)
+    t.sort()
+    ms, best = t[len(t) // 2], t[0]
+    print(f"{name:44s} median {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF/s | best {best*1e3:8.1f} us {flops/best/1e9:7.1f} TF/s", flush=True)
 
 
 R, S, H, D = 12544, 6272, 8, 1024
 if what in ("attn", "all"):
-  for impl in (2, 3):
+  for impl in ((3,) if os.environ.get("ATTN_ONLY3") else (2, 3)):
     capi.lib().mavlm_set_attention_impl(impl)
     print("attention impl", impl)
     q = torch.randn(R, D, device=dev).bfloat16()
