@@ -114,6 +114,10 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     capi.lib()   # fail loudly if the HIP library is missing
+    if os.environ.get("MAVLM_GEMM_TILE"):      # A/B hook (diagnostics): 128 / 256 / 257, default automatic
+        capi.check(capi.lib().mavlm_set_gemm_tile(int(os.environ["MAVLM_GEMM_TILE"])), "set_gemm_tile")
+    if os.environ.get("MAVLM_ATTN_IMPL"):
+        capi.check(capi.lib().mavlm_set_attention_impl(int(os.environ["MAVLM_ATTN_IMPL"])), "set_attention_impl")
 
     model, arch = build_model(device)
     rm = model.recurrent_memory_transformer
@@ -129,6 +133,8 @@ def main():
     mem_ids = torch.tensor(arch.MEMORY_PROMPT_IDS, device=device)
     frame_ids = torch.tensor(arch.FRAME_PROMPT_IDS, device=device)
     gathered = torch.empty((world, MEM_TOKENS, PATCHES, HIDDEN), device=device, dtype=torch.bfloat16) if world > 1 else None
+    # the gather runs asynchronously while the next video overwrites the FIFO ring -> gather from a private copy
+    send = torch.empty((MEM_TOKENS, PATCHES, HIDDEN), device=device, dtype=torch.bfloat16) if world > 1 else None
     pending = [None]
     do_gather = world > 1 and not args.no_gather
 
@@ -141,8 +147,9 @@ def main():
             toks = pool.run([(xi, idx_cpu) for xi in xs], mp, fp, model.image_newline)[0]
         if do_gather:
             if pending[0] is not None:
-                pending[0].wait()                       # previous video's gather (overlapped with this video)
-            _, pending[0] = D.all_gather_memory_state(rm.memory_cache[-1], out=gathered, async_op=True)
+                pending[0].wait()                       # previous gather (overlapped with this step) is done with `send`
+            send.copy_(rm.memory_cache[-1])             # final memory state of this rank's (first) video
+            _, pending[0] = D.all_gather_memory_state(send, out=gathered, async_op=True)
         return toks
 
     def sync():

@@ -123,7 +123,7 @@ int mavlm_fuse_emit(mavlm_ctx* ctx, const void* x_pe, const int64_t* fine_idx, i
 
 /* --- operator-level entry points (used by the parity tests; same kernels the step uses) --------------- */
 /* C = epi(A[M,K] . W[N,K]^T + bias); epilogue: 0 bias, 1 bias+ReLU, 2 bias+GELU(erf),
- * 3 bias+residual -> fp32 C.   nn.Linear call sites: MemoryController.py:23,37-39,63-67; llava_arch.py:132-136 */
+ * 3 bias+residual -> fp32 C, 4 bias -> fp32 C.   nn.Linear call sites: MemoryController.py:23,37-39,63-67; llava_arch.py:132-136 */
 int mavlm_linear(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const void* res, int32_t ldr,
                  void* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t dtype, void* stream);
 /* ctx[R,H*128] = softmax(Q K^T / sqrt(128)) V per head; lse2 [H,R] fp32 optional.  MemoryController.py:51-54 */
@@ -132,14 +132,16 @@ int mavlm_attention(const void* Q, int32_t ldq, const void* K, int32_t ldk, cons
 /* part[H,S] fp32 = column sums over queries of the normalised probabilities.  MemoryController.py:135 */
 int mavlm_attention_colsum(const void* Q, int32_t ldq, const void* K, int32_t ldk, const float* lse2, float* part,
                            int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream);
-/* out = LayerNorm(x fp32 [rows,D]) * gamma + beta -> 16-bit.  MemoryController.py:24,28 */
-int mavlm_layernorm(const float* x, const float* gamma, const float* beta, void* out, int32_t rows, int32_t D, float eps,
-                    int32_t dtype, void* stream);
+/* out = LayerNorm(x fp32 [rows,D] + res) * gamma + beta -> 16-bit; res: 16-bit [rows, ldr] residual or null.
+ * MemoryController.py:24,26-28 */
+int mavlm_layernorm(const float* x, const void* res, int32_t ldr, const float* gamma, const float* beta, void* out,
+                    int32_t rows, int32_t D, float eps, int32_t dtype, void* stream);
 /* out[t,p,:] = x[src[t],p,:] + table[idx[t],:] (src/idx may be null).  position_encoding.py:64; llava_arch.py:524,554 */
 int mavlm_row_add(const void* x, const int64_t* src, const void* table, const int64_t* idx, void* out, int32_t T,
                   int32_t P, int32_t D, int32_t dtype, void* stream);
 
-/* tuning hook: force the GEMM block tile (128 or 256; 0 = automatic choice by grid size).  Results are identical
+/* tuning hook: force the GEMM kernel (128 = 128^2 tile, 256 = 256^2 non-persistent, 257 = 256^2 persistent;
+ * 0 = automatic choice by grid size and epilogue).  Results are identical
  * up to fp32 summation order. */
 int mavlm_set_gemm_tile(int32_t tile);
 /* tuning hook: attention forward kernel - 2 = register-staged (attention.hip), 3 = software-pipelined LDS-DMA

@@ -10,7 +10,7 @@ from ._build import library_path
 
 MAX_DEPTH = 8
 BF16, F16 = 0, 1
-EPI_BIAS, EPI_RELU, EPI_GELU, EPI_RES_F32 = 0, 1, 2, 3
+EPI_BIAS, EPI_RELU, EPI_GELU, EPI_RES_F32, EPI_F32 = 0, 1, 2, 3, 4
 E_ARG, E_SHAPE, E_STATE = -1, -2, -3
 
 vp = C.c_void_p
@@ -60,7 +60,7 @@ SIGNATURES = {
     "mavlm_linear": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mavlm_attention": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.c_float, i32, vp]),
     "mavlm_attention_colsum": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, i32, i32, C.c_float, i32, vp]),
-    "mavlm_layernorm": (C.c_int, [vp, vp, vp, vp, i32, i32, C.c_float, i32, vp]),
+    "mavlm_layernorm": (C.c_int, [vp, vp, i32, vp, vp, vp, i32, i32, C.c_float, i32, vp]),
     "mavlm_row_add": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mavlm_set_gemm_tile": (C.c_int, [i32]),
     "mavlm_set_attention_impl": (C.c_int, [i32]),

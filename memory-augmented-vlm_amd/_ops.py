@@ -41,7 +41,8 @@ def linear(x, weight, bias_f32, epilogue=capi.EPI_BIAS, residual=None, out=None)
     if K2 != K or weight.dtype != x.dtype or bias_f32.dtype != torch.float32 or bias_f32.numel() != N:
         raise capi.MavlmError("linear: operand mismatch")
     if out is None:
-        out = torch.empty((M, N), device=x.device, dtype=torch.float32 if epilogue == capi.EPI_RES_F32 else x.dtype)
+        out = torch.empty((M, N), device=x.device,
+                          dtype=torch.float32 if epilogue in (capi.EPI_RES_F32, capi.EPI_F32) else x.dtype)
     _, _, ldc = _rows(out)
     rp, ldr = (0, 0)
     if epilogue == capi.EPI_RES_F32:
@@ -85,15 +86,23 @@ def attention_colsum(q, k, lse2, heads):
     return part
 
 
-def layernorm(x_f32, gamma_f32, beta_f32, eps, out_dtype, out=None):
-    _need_gpu(x_f32, gamma_f32, beta_f32)
+def layernorm(x_f32, gamma_f32, beta_f32, eps, out_dtype, out=None, residual=None):
+    """out = LayerNorm(x_f32 + residual) * gamma + beta; residual: optional 16-bit [rows, D] (added in fp32)."""
+    _need_gpu(x_f32, gamma_f32, beta_f32, residual)
     if x_f32.dtype != torch.float32 or not x_f32.is_contiguous():
         raise capi.MavlmError("layernorm: fp32 contiguous input expected")
     rows, D = x_f32.shape
     if out is None:
         out = torch.empty((rows, D), device=x_f32.device, dtype=out_dtype)
-    capi.check(capi.lib().mavlm_layernorm(x_f32.data_ptr(), gamma_f32.data_ptr(), beta_f32.data_ptr(), out.data_ptr(),
-                                          rows, D, float(eps), dtype_code(out_dtype), stream_ptr()), "mavlm_layernorm")
+    rp, ldr = 0, 0
+    if residual is not None:
+        if residual.dtype != out_dtype or residual.shape != x_f32.shape:
+            raise capi.MavlmError("layernorm: residual mismatch")
+        _, _, ldr = _rows(residual)
+        rp = residual.data_ptr()
+    capi.check(capi.lib().mavlm_layernorm(x_f32.data_ptr(), rp, ldr, gamma_f32.data_ptr(), beta_f32.data_ptr(),
+                                          out.data_ptr(), rows, D, float(eps), dtype_code(out_dtype), stream_ptr()),
+               "mavlm_layernorm")
     return out
 
 

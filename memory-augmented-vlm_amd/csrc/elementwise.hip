@@ -11,7 +11,8 @@ namespace {
 
 // one wave per row, NV float4 per lane (D <= 256*NV)
 template <typename T, int NV>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const uint16_t* __restrict__ res,
+                                                        int ldr, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, uint16_t* __restrict__ out,
                                                         int rows, int D, float eps) {
   const int lane = threadIdx.x & 63;
@@ -26,6 +27,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int j = i * 64 + lane;
     if (j < nvec) {
       v[i] = xr[j];
+      if (res != nullptr) {      // residual add of the Residual block, in fp32 (MemoryController.py:28)
+        const u16x4 rv = *(const u16x4*)(res + (size_t)row * ldr + 4 * j);
+        v[i][0] += T::to_f32(rv[0]); v[i][1] += T::to_f32(rv[1]); v[i][2] += T::to_f32(rv[2]); v[i][3] += T::to_f32(rv[3]);
+      }
       s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     } else {
       v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -83,33 +88,34 @@ __global__ __launch_bounds__(256) void row_add_kernel(const uint16_t* __restrict
 }
 
 template <typename T, int NV>
-void ln_launch(const float* x, const float* g, const float* b, void* out, int rows, int D, float eps, hipStream_t s) {
-  hipLaunchKernelGGL((layernorm_kernel<T, NV>), dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, (uint16_t*)out, rows, D,
-                     eps);
+void ln_launch(const float* x, const void* res, int ldr, const float* g, const float* b, void* out, int rows, int D,
+               float eps, hipStream_t s) {
+  hipLaunchKernelGGL((layernorm_kernel<T, NV>), dim3((rows + 3) / 4), dim3(256), 0, s, x, (const uint16_t*)res, ldr, g, b,
+                     (uint16_t*)out, rows, D, eps);
 }
 
 template <typename T>
-hipError_t ln_dispatch(const float* x, const float* g, const float* b, void* out, int rows, int D, float eps,
-                       hipStream_t s) {
+hipError_t ln_dispatch(const float* x, const void* res, int ldr, const float* g, const float* b, void* out, int rows, int D,
+                       float eps, hipStream_t s) {
   const int nv = (D / 4 + 63) / 64;
-  if (nv <= 1) ln_launch<T, 1>(x, g, b, out, rows, D, eps, s);
-  else if (nv <= 2) ln_launch<T, 2>(x, g, b, out, rows, D, eps, s);
-  else if (nv <= 4) ln_launch<T, 4>(x, g, b, out, rows, D, eps, s);
-  else if (nv <= 8) ln_launch<T, 8>(x, g, b, out, rows, D, eps, s);
-  else if (nv <= 16) ln_launch<T, 16>(x, g, b, out, rows, D, eps, s);
+  if (nv <= 1) ln_launch<T, 1>(x, res, ldr, g, b, out, rows, D, eps, s);
+  else if (nv <= 2) ln_launch<T, 2>(x, res, ldr, g, b, out, rows, D, eps, s);
+  else if (nv <= 4) ln_launch<T, 4>(x, res, ldr, g, b, out, rows, D, eps, s);
+  else if (nv <= 8) ln_launch<T, 8>(x, res, ldr, g, b, out, rows, D, eps, s);
+  else if (nv <= 16) ln_launch<T, 16>(x, res, ldr, g, b, out, rows, D, eps, s);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t mavlm_launch_layernorm(const float* x, const float* gamma, const float* beta, void* out, int rows, int D,
-                                  float eps, int dtype, hipStream_t s) {
+hipError_t mavlm_launch_layernorm(const float* x, const void* res, int ldr, const float* gamma, const float* beta,
+                                  void* out, int rows, int D, float eps, int dtype, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
-  if (!x || !gamma || !beta || !out || D <= 0 || (D & 3)) return hipErrorInvalidValue;
-  mavlm_prof_scope prof(MAVLM_K_LN, 0.0, 6.0 * rows * (double)D, s);
-  return dtype == MAVLM_F16 ? ln_dispatch<F16>(x, gamma, beta, out, rows, D, eps, s)
-                            : ln_dispatch<BF16>(x, gamma, beta, out, rows, D, eps, s);
+  if (!x || !gamma || !beta || !out || D <= 0 || (D & 3) || (res && (ldr & 3))) return hipErrorInvalidValue;
+  mavlm_prof_scope prof(MAVLM_K_LN, 0.0, (res ? 8.0 : 6.0) * rows * (double)D, s);
+  return dtype == MAVLM_F16 ? ln_dispatch<F16>(x, res, ldr, gamma, beta, out, rows, D, eps, s)
+                            : ln_dispatch<BF16>(x, res, ldr, gamma, beta, out, rows, D, eps, s);
 }
 
 hipError_t mavlm_launch_row_add(const void* x, const int64_t* src, const void* table, const int64_t* idx, void* out,

@@ -131,6 +131,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const uint16_t* __restr
         o[0] = v0 + T::to_f32(rv[0]); o[1] = v1 + T::to_f32(rv[1]);
         o[2] = v2 + T::to_f32(rv[2]); o[3] = v3 + T::to_f32(rv[3]);
         *(f32x4*)((float*)Cout + (size_t)m * ldc + n) = o;
+      } else if (EPI == MAVLM_EPI_F32) {
+        *(f32x4*)((float*)Cout + (size_t)m * ldc + n) = f32x4{v0, v1, v2, v3};
       } else {
         *(u32x2*)((uint16_t*)Cout + (size_t)m * ldc + n) = pack4<T>(v0, v1, v2, v3);
       }
@@ -160,6 +162,7 @@ hipError_t launch_epi(const mavlm_gemm_args& g, hipStream_t s) {
     case MAVLM_EPI_RELU: return launch<T, MAVLM_EPI_RELU>(g, s);
     case MAVLM_EPI_GELU: return launch<T, MAVLM_EPI_GELU>(g, s);
     case MAVLM_EPI_RES_F32: return launch<T, MAVLM_EPI_RES_F32>(g, s);
+    case MAVLM_EPI_F32: return launch<T, MAVLM_EPI_F32>(g, s);
   }
   return hipErrorInvalidValue;
 }
@@ -172,7 +175,7 @@ int g_mavlm_gemm_tile = 0;
 // 128^2 kernel (two workgroups per CU, 4x the tiles) fills the chip better.
 static bool use_256(const mavlm_gemm_args& g) {
   if (!mavlm_gemm256_supported(g)) return false;
-  if (g_mavlm_gemm_tile == 256) return true;
+  if (g_mavlm_gemm_tile == 256 || g_mavlm_gemm_tile == 257) return true;
   if (g_mavlm_gemm_tile == 128) return false;
   const long tiles = (long)((g.M + 255) / 256) * (g.N / 256);
   return tiles >= 192;
@@ -182,9 +185,16 @@ hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s)
   if (g.M <= 0) return hipSuccess;
   if (g.N % BN != 0 || g.K % BK != 0 || g.K <= 0 || (g.lda & 7) || (g.ldw & 7) || (g.ldc & 3)) return hipErrorInvalidValue;
   if (g.epilogue == MAVLM_EPI_RES_F32 && (g.res == nullptr || (g.ldr & 3))) return hipErrorInvalidValue;
-  const double osz = g.epilogue == MAVLM_EPI_RES_F32 ? 6.0 : 2.0;   // fp32 out + 16-bit residual in
+  const double osz = g.epilogue == MAVLM_EPI_RES_F32 ? 6.0 : (g.epilogue == MAVLM_EPI_F32 ? 4.0 : 2.0);
   mavlm_prof_scope prof(MAVLM_K_GEMM, 2.0 * g.M * (double)g.N * g.K,
                         2.0 * ((double)g.M * g.K + (double)g.N * g.K) + osz * g.M * (double)g.N, s);
-  if (use_256(g)) return mavlm_launch_gemm256(g, dtype, s);
+  if (use_256(g)) {
+    // persistent kernel when workgroups get more than one tile each (its pipeline never drains between tiles);
+    // with at most one tile per CU the plain kernel is the same work with less code in flight
+    const long tiles = (long)((g.M + 255) / 256) * (g.N / 256);
+    const bool want_p = g_mavlm_gemm_tile == 257 || (g_mavlm_gemm_tile == 0 && tiles > 256);
+    if (want_p && mavlm_gemm256p_supported(g)) return mavlm_launch_gemm256p(g, dtype, s);
+    return mavlm_launch_gemm256(g, dtype, s);
+  }
   return dtype == MAVLM_F16 ? launch_epi<F16>(g, s) : launch_epi<BF16>(g, s);
 }

@@ -217,6 +217,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
         o[0] = v0 + T::to_f32(rv[0]); o[1] = v1 + T::to_f32(rv[1]);
         o[2] = v2 + T::to_f32(rv[2]); o[3] = v3 + T::to_f32(rv[3]);
         *(f32x4*)((float*)Cout + (size_t)m * ldc + n) = o;
+      } else if (EPI == MAVLM_EPI_F32) {
+        *(f32x4*)((float*)Cout + (size_t)m * ldc + n) = f32x4{v0, v1, v2, v3};
       } else {
         *(u32x2*)((uint16_t*)Cout + (size_t)m * ldc + n) = pack4<T>(v0, v1, v2, v3);
       }
@@ -246,6 +248,7 @@ hipError_t launch256_epi(const mavlm_gemm_args& g, hipStream_t s) {
     case MAVLM_EPI_RELU: return launch256<T, MAVLM_EPI_RELU>(g, s);
     case MAVLM_EPI_GELU: return launch256<T, MAVLM_EPI_GELU>(g, s);
     case MAVLM_EPI_RES_F32: return launch256<T, MAVLM_EPI_RES_F32>(g, s);
+    case MAVLM_EPI_F32: return launch256<T, MAVLM_EPI_F32>(g, s);
   }
   return hipErrorInvalidValue;
 }

@@ -1,0 +1,321 @@
+// PERSISTENT variant of gemm256_kernel (gemm256.hip; read that header first - tile geometry, LDS image, 4-phase
+// K-tile, ping-pong skew and the hazard analysis are identical).  One workgroup per CU walks tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ...  and the K pipeline NEVER DRAINS between tiles: K-tiles are numbered
+// v = it*nk + kt across the tile sequence, stage = v & 1, and the half-tile DMAs issued during the last two K-tiles
+// of a tile already fetch the first two K-tiles of the next one.  The epilogue of tile `it` therefore runs while
+// those DMAs are in flight (the non-persistent kernel pays ~8 us per tile for prologue + epilogue + relaunch at
+// K = 1024, a quarter of its tile time).
+//   * The epilogue must not contain VMEM loads: vmcnt retires in order, so waiting for a bias or residual load
+//     would drain the DMA queue.  The tile's 256 bias values arrive by a 1 KiB LDS-DMA (issued by wave 0 as the
+//     OLDEST operation of the tile's first K-tile, so the counted vmcnt(6) waits are unchanged) and are read from
+//     LDS; the residual add of the LN-fused epilogue is done by the LayerNorm kernel instead (EPI_F32 here).
+//   * Epilogue stores count in vmcnt too, but they are older than the three half-tiles that stay in flight.
+// Same contract as gemm_tn_kernel (gemm.hip): C[M,N] = epi(A[M,K] . W[N,K]^T + bias), nn.Linear layout.
+//
+// Structure (after cdna_hip_programming.md "The 256^2 8-phase template", re-derived for this layout):
+//   * 8 waves (2 along M x 4 along N), wave tile 128x64 = 8x4 MFMA 16x16x32 tiles (128 accumulator VGPRs), one
+//     workgroup per CU, 128 KiB LDS = 2 stages x {A0,A1,B0,B1} half-tiles of 128 rows x 64 k (16 KiB each).
+//   * Operands arrive by LDS-DMA (16-byte global_load_lds), XOR-swizzled through the per-lane SOURCE address;
+//     a half-tile is 2 DMA instructions per wave.
+//   * A K-tile is consumed in 4 phases of 16 MFMAs (one 64x32 quadrant of the wave tile x K=64):
+//        phase 1: read A(rows 0-63) + all of B into registers (16 ds_read_b128), quadrant (0,0)
+//        phase 2: quadrant (0,1)            phase 3: read A(rows 64-127) (8 reads), quadrant (1,1)
+//        phase 4: quadrant (1,0)
+//     so the B half-tiles of the stage are dead after phase 1 and the A half-tiles after phase 3, and every phase
+//     re-stages ONE half-tile: phase 1 -> A1 of K-tile kt+1 (other stage), phases 2,3,4 -> B0,B1,A0 of K-tile kt+2
+//     (this stage).  Loads therefore stay in flight across barriers; the only vmcnt wait is a COUNTED one per K-tile
+//     (vmcnt(6): the three youngest half-tiles stay in flight), never 0 inside the loop.
+//   * Raw s_barrier (a __syncthreads() would drain the DMA queue), MFMA clusters bracketed by s_setprio.
+//   * Ping-pong: every phase is two barrier segments, L (fragment reads + DMA issue + the counted wait) and M (16
+//     MFMAs).  Waves 4-7 run ONE SEGMENT BEHIND waves 0-3 (they execute one extra s_barrier before their first
+//     segment, waves 0-3 one extra after their last, so both groups execute the same number of barriers).  Each
+//     SIMD hosts one wave of either group, so while one group's M segment owns the matrix pipe the other group
+//     issues its LDS reads and DMAs.  Without the skew all eight waves are in lockstep: both waves of a SIMD do
+//     their MFMAs back to back and then both sit in the L segment with the pipe idle (measured: 3.8k clk per
+//     K-tile against 2.05k of MFMA).
+//
+// Hazards (LDS-DMA is ordered by nothing but the issuing wave's vmcnt + a barrier), with g = global barrier index,
+// the leading group executing segment g and the trailing group segment g-1, K-tile kt = segments 8kt+1 .. 8kt+8
+// (L1 M1 L2 M2 L3 M3 L4 M4), stage s = kt & 1:
+//   reads of stage s: L1 (A rows 0-63 + B) and L3 (A rows 64-127): g = 8kt+1, 8kt+5 (leading), 8kt+2, 8kt+6 (trailing);
+//        every read is retired by the lgkmcnt(0) at the top of the following M segment.
+//   WAR  B half-tiles of s are dead from g = 8kt+3, A half-tiles from g = 8kt+7.  Re-staging (K-tile kt+2) is issued
+//        by the leading group in L2 (g = 8kt+3: B0), L3 (8kt+5: B1), L4 (8kt+7: A0) and the next L1 (8kt+9: A1).
+//   RAW  K-tile kt+1 is first read at g = 8kt+9.  Its last half-tile (A1) is issued in L1 of kt; both groups wait
+//        vmcnt(6) in L4 (g = 8kt+7 / 8kt+8) and pass a barrier before g = 8kt+9.
+#include "mavlm_common.h"
+#include "mavlm_kernels.h"
+
+namespace {
+
+constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
+constexpr int HALF = 128 * BK2 * 2;          // 16 KiB half-tile
+constexpr int STAGE2 = 4 * HALF;             // A0 A1 B0 B1
+constexpr int GEMM256_LDS = 2 * STAGE2;      // 128 KiB
+constexpr int BIAS_OFF = GEMM256_LDS;        // 2 x 1 KiB bias ring behind the stages
+constexpr int GEMM256P_LDS = GEMM256_LDS + 2048;
+
+// raw workgroup barrier fenced against compiler motion of memory operations (s_barrier itself is IntrNoMem)
+#define MAVLM_BAR()                          \
+  do {                                       \
+    asm volatile("" ::: "memory");           \
+    __builtin_amdgcn_s_barrier();            \
+    asm volatile("" ::: "memory");           \
+  } while (0)
+// all LDS reads of this phase retired before its MFMAs (WAR rule above); sched_barrier: hipcc may hoist a
+// register-only MFMA above an inline-asm wait (cdna_hip_programming.md rule 18)
+#define MAVLM_LGKM0()                                          \
+  do {                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
+    __builtin_amdgcn_sched_barrier(0);                         \
+  } while (0)
+
+__device__ __forceinline__ float gelu_erf2p(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __restrict__ A, int lda,
+                                                          const uint16_t* __restrict__ W, int ldw,
+                                                          const float* __restrict__ bias, void* __restrict__ Cout,
+                                                          int ldc, int M, int N, int K, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int ntn = N / BN2;
+  const int G = gridDim.x;
+  const int ntl = (total_tiles - (int)blockIdx.x + G - 1) / G;      // tiles of this workgroup (>= 1)
+  const int nk = K / BK2;                                           // >= 2 (host check)
+  const int VT = ntl * nk;                                          // virtual K-tiles of this workgroup
+
+  // ---- LDS-DMA sources: wave w stages 8-row groups g = 2w, 2w+1 of every half-tile.  32-bit element offsets of
+  // the tile being computed (cur) and of the next one (nxt): the DMAs run up to two K-tiles ahead.
+  const int srow = lane >> 3, sp = lane & 7;
+  int offA[2][2][2], offB[2][2][2];                                 // [cur/nxt][half][inst]
+  int m0c = 0, n0c = 0;
+  auto tile_origin = [&](int it, int& m0, int& n0) {
+    int lin = (int)blockIdx.x + it * G;
+    // XCD-aware order inside every full window of G tiles (blocks b, b+8 share an XCD)
+    if ((it + 1) * G <= total_tiles && (G & 7) == 0) lin = it * G + xcd_remap((int)blockIdx.x, G);
+    m0 = (lin / ntn) * BM2;
+    n0 = (lin % ntn) * BN2;
+  };
+  auto set_offsets = [&](int which, int m0, int n0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 8 + srow;
+        const int c = sp ^ ((row >> 1) & 7);
+        int ar = m0 + h * 128 + row;
+        ar = ar < M ? ar : M - 1;
+        offA[which][h][j] = ar * lda + c * 8;
+        offB[which][h][j] = (n0 + h * 128 + row) * ldw + c * 8;
+      }
+  };
+  // half-tile ids: 0 = A0, 1 = A1, 2 = B0, 3 = B1 ; u = virtual K-tile ; it = tile being computed
+  auto dma = [&](int half_id, int u, int it) {
+    const int which = u >= (it + 1) * nk;                           // wave-uniform: next tile?
+    const int kt = u - (it + which) * nk;
+    char* dst = smem + (u & 1) * STAGE2 + half_id * HALF + wave * 2048;
+    const int h = half_id & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int oa = which ? offA[1][h][j] : offA[0][h][j];     // (static indices: runtime-indexed arrays go to scratch)
+      const int ob = which ? offB[1][h][j] : offB[0][h][j];
+      const uint16_t* src = (half_id < 2 ? A + oa : W + ob) + (size_t)kt * BK2;
+      __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)src, (MAVLM_LDS void*)(dst + j * 1024), 16, 0, 0);
+    }
+  };
+  auto dma_bias = [&](int it, int n0) {                             // 256 floats = 64 lanes x 16 B, wave 0 only
+    if (wave == 0)
+      __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)(bias + n0 + lane * 4),
+                                       (MAVLM_LDS void*)(smem + BIAS_OFF + (it & 1) * 1024), 16, 0, 0);
+  };
+
+  // ---- fragment read offsets
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = (lane >> 1) & 7;
+  const int ck0 = (fq ^ sw) << 4, ck1 = ((4 + fq) ^ sw) << 4;
+  const int offA_f = wm * HALF + fr * 128;                               // + mh*8192 + mt*2048
+  const int offB_f = 2 * HALF + (wn >> 1) * HALF + ((wn & 1) * 64 + fr) * 128;   // + nh*4096 + nt*2048
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  typename T::vec8 af[4][2];      // [m-tile of the current 64-row slice][k-step]
+  typename T::vec8 bf[4][2];      // [n-tile of the wave's 64 columns][k-step]
+
+  const bool trailing = wm == 1;     // waves 4-7 (wave-uniform: wm comes from a readfirstlane)
+
+  // ---- prologue: bias(0), K-tile 0 completely, K-tile 1 minus its last half-tile (order B0,B1,A0,A1)
+  tile_origin(0, m0c, n0c);
+  set_offsets(0, m0c, n0c);
+  {
+    int m0n = 0, n0n = 0;
+    if (ntl > 1) tile_origin(1, m0n, n0n);
+    set_offsets(1, m0n, n0n);
+  }
+  dma_bias(0, n0c);
+  dma(2, 0, 0); dma(3, 0, 0); dma(0, 0, 0); dma(1, 0, 0);
+  dma(2, 1, 0); dma(3, 1, 0); dma(0, 1, 0);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  MAVLM_BAR();
+
+  auto read_a = [&](const char* st, int mh) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      af[mt][0] = *(const typename T::vec8*)(st + offA_f + mh * 8192 + mt * 2048 + ck0);
+      af[mt][1] = *(const typename T::vec8*)(st + offA_f + mh * 8192 + mt * 2048 + ck1);
+    }
+  };
+  auto read_b = [&](const char* st) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      bf[nt][0] = *(const typename T::vec8*)(st + offB_f + nt * 2048 + ck0);
+      bf[nt][1] = *(const typename T::vec8*)(st + offB_f + nt * 2048 + ck1);
+    }
+  };
+#define MAVLM_QUADRANT(MH, NH)                                                              \
+  {                                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                        \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                        \
+      acc[MH * 4 + mt][NH * 2 + nt] = T::mfma16(bf[NH * 2 + nt][ks], af[mt][ks], acc[MH * 4 + mt][NH * 2 + nt]); \
+    __builtin_amdgcn_s_setprio(0);                                                          \
+  }
+
+  if (trailing) MAVLM_BAR();           // ping-pong skew: pairs with the leading group's first in-loop barrier
+
+  int v = 0;
+  for (int it = 0; it < ntl; ++it) {
+    for (int kt = 0; kt < nk; ++kt, ++v) {
+      const char* st = smem + (v & 1) * STAGE2;
+      // -------- phase 1
+      read_a(st, 0);
+      read_b(st);
+      if (kt == 0 && it > 0) dma_bias(it, n0c);              // oldest VMEM operation of this K-tile
+      if (v + 1 < VT) dma(1, v + 1, it);                     // A1 of the next virtual K-tile
+      MAVLM_BAR();
+      MAVLM_LGKM0();
+      MAVLM_QUADRANT(0, 0)
+      MAVLM_BAR();
+      // -------- phase 2   (B half-tiles of this stage are dead: everything is in registers)
+      if (v + 2 < VT) dma(2, v + 2, it);
+      MAVLM_BAR();
+      MAVLM_QUADRANT(0, 1)
+      MAVLM_BAR();
+      // -------- phase 3
+      read_a(st, 1);
+      if (v + 2 < VT) dma(3, v + 2, it);
+      MAVLM_BAR();
+      MAVLM_LGKM0();
+      MAVLM_QUADRANT(1, 1)
+      MAVLM_BAR();
+      // -------- phase 4   (A half-tiles dead)
+      if (v + 2 < VT) {
+        dma(0, v + 2, it);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // K-tile v+1 landed; 3 half-tiles of v+2 stay in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      MAVLM_BAR();
+      MAVLM_QUADRANT(1, 0)
+      MAVLM_BAR();
+    }
+
+    // ---- epilogue of tile `it` (no barriers, no VMEM loads): the next tile's first K-tiles are already in flight.
+    // lane holds C[m][n..n+3], m = m0 + wm*128 + 16 i + fr, n = n0 + wn*64 + 16 j + 4 fq
+    const float* bl = (const float*)(smem + BIAS_OFF + (it & 1) * 1024) + wn * 64 + fq * 4;
+    f32x4 bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(bl + j * 16);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0c + wm * 128 + i * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0c + wn * 64 + j * 16 + fq * 4;
+        float v0 = acc[i][j][0] + bv[j][0], v1 = acc[i][j][1] + bv[j][1], v2 = acc[i][j][2] + bv[j][2],
+              v3 = acc[i][j][3] + bv[j][3];
+        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EPI == MAVLM_EPI_RELU) {
+          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        } else if (EPI == MAVLM_EPI_GELU) {
+          v0 = gelu_erf_fast(v0); v1 = gelu_erf_fast(v1); v2 = gelu_erf_fast(v2); v3 = gelu_erf_fast(v3);
+        }
+        if (m < M) {
+          if (EPI == MAVLM_EPI_F32) {
+            *(f32x4*)((float*)Cout + (size_t)m * ldc + n) = f32x4{v0, v1, v2, v3};
+          } else {
+            *(u32x2*)((uint16_t*)Cout + (size_t)m * ldc + n) = pack4<T>(v0, v1, v2, v3);
+          }
+        }
+      }
+    }
+    // ---- next tile becomes current; offsets of the one after it
+    if (it + 1 < ntl) {
+      tile_origin(it + 1, m0c, n0c);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { offA[0][h][j] = offA[1][h][j]; offB[0][h][j] = offB[1][h][j]; }
+      if (it + 2 < ntl) {
+        int m0n, n0n;
+        tile_origin(it + 2, m0n, n0n);
+        set_offsets(1, m0n, n0n);
+      }
+    }
+  }
+  if (!trailing) MAVLM_BAR();          // matches the trailing group's last barrier
+#undef MAVLM_QUADRANT
+}
+
+template <typename T, int EPI>
+hipError_t launch256p(const mavlm_gemm_args& g, hipStream_t s) {
+  auto kern = gemm256p_kernel<T, EPI>;
+  static bool attr_done = false;
+  static int cus = 0;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256P_LDS);
+    if (e != hipSuccess) return e;
+    int dev = 0;
+    e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess || cus <= 0) return hipErrorInvalidValue;
+    attr_done = true;
+  }
+  const int tiles = ((g.M + BM2 - 1) / BM2) * (g.N / BN2);
+  const int grid = tiles < cus ? tiles : cus;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), GEMM256P_LDS, s, (const uint16_t*)g.A, g.lda, (const uint16_t*)g.W,
+                     g.ldw, g.bias, g.C, g.ldc, g.M, g.N, g.K, tiles);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// persistent kernel: bias / ReLU / GELU / fp32-out epilogues (no residual: see the header), K >= 128,
+// operands addressable with 32-bit element offsets
+bool mavlm_gemm256p_supported(const mavlm_gemm_args& g) {
+  if (g.N % BN2 != 0 || g.K % BK2 != 0 || g.K < 2 * BK2 || g.M < 1) return false;
+  if (g.epilogue == MAVLM_EPI_RES_F32) return false;
+  if ((double)g.M * g.lda >= 2.0e9 || (double)g.N * g.ldw >= 2.0e9) return false;
+  return true;
+}
+
+hipError_t mavlm_launch_gemm256p(const mavlm_gemm_args& g, int dtype, hipStream_t s) {
+  const bool h = dtype == MAVLM_F16;
+  switch (g.epilogue) {
+    case MAVLM_EPI_BIAS: return h ? launch256p<F16, MAVLM_EPI_BIAS>(g, s) : launch256p<BF16, MAVLM_EPI_BIAS>(g, s);
+    case MAVLM_EPI_RELU: return h ? launch256p<F16, MAVLM_EPI_RELU>(g, s) : launch256p<BF16, MAVLM_EPI_RELU>(g, s);
+    case MAVLM_EPI_GELU: return h ? launch256p<F16, MAVLM_EPI_GELU>(g, s) : launch256p<BF16, MAVLM_EPI_GELU>(g, s);
+    case MAVLM_EPI_F32: return h ? launch256p<F16, MAVLM_EPI_F32>(g, s) : launch256p<BF16, MAVLM_EPI_F32>(g, s);
+  }
+  return hipErrorInvalidValue;
+}

@@ -83,8 +83,9 @@ int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const 
   a.Q = ws(x, x->o_q); a.ldq = Dp; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = ws(x, x->o_ctx); a.ldo = Dp;
   a.lse2 = lse2; a.R = R; a.S = S; a.H = H; a.scale = attn_scale(c);
   MAVLM_TRY(mavlm_launch_attention(a, dt, s));
-  MAVLM_TRY(gemm(dt, s, ws(x, x->o_ctx), Dp, aw.wo, Dp, aw.bo, ws(x, x->o_pre), D, R, D, Dp, MAVLM_EPI_RES_F32, xq, D));
-  MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), aw.ln_g, aw.ln_b, out, R, D, c.eps, dt, s));
+  // Residual: dense + bias in fp32 (GEMM epilogue), + residual and LayerNorm in the row kernel (MemoryController.py:26-29)
+  MAVLM_TRY(gemm(dt, s, ws(x, x->o_ctx), Dp, aw.wo, Dp, aw.bo, ws(x, x->o_pre), D, R, D, Dp, MAVLM_EPI_F32));
+  MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), xq, D, aw.ln_g, aw.ln_b, out, R, D, c.eps, dt, s));
   return 0;
 }
 
@@ -101,7 +102,7 @@ int mavlm_set_attention_impl(int32_t impl) {
 }
 
 int mavlm_set_gemm_tile(int32_t tile) {
-  if (tile != 0 && tile != 128 && tile != 256) return MAVLM_E_ARG;
+  if (tile != 0 && tile != 128 && tile != 256 && tile != 257) return MAVLM_E_ARG;
   g_mavlm_gemm_tile = tile;
   return 0;
 }
@@ -228,10 +229,11 @@ int mavlm_step(mavlm_ctx* x, const void* seg, int32_t F, void* frame_scores, int
     // MLP: Linear(D,I)+ReLU -> Residual(I->D)  (MemoryController.py:63-67,71)
     MAVLM_TRY(gemm(dt, s, ws(x, x->o_a), D, x->w.w_up[l], D, x->w.b_up[l], ws(x, x->o_h), I, R, I, D, MAVLM_EPI_RELU));
     MAVLM_TRY(gemm(dt, s, ws(x, x->o_h), I, x->w.w_down[l], I, x->w.b_down[l], ws(x, x->o_pre), D, R, D, I,
-                   MAVLM_EPI_RES_F32, ws(x, x->o_a), D));
+                   MAVLM_EPI_F32));
     void* dst = last ? (void*)((char*)x->b.mem_ring + (size_t)(x->steps % cap) * mem_bytes)
                      : (void*)ws(x, (l & 1) ? x->o_mA : x->o_mB);
-    MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), x->w.ln2_g[l], x->w.ln2_b[l], dst, R, D, c.eps, dt, s));
+    MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), ws(x, x->o_a), D, x->w.ln2_g[l], x->w.ln2_b[l], dst, R, D,
+                                     c.eps, dt, s));
     cur = dst;
   }
   x->steps += 1;   // append; the slot written above evicts the oldest entry once the ring is full (:152-154)
@@ -309,9 +311,9 @@ int mavlm_attention_colsum(const void* Q, int32_t ldq, const void* K, int32_t ld
   return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
 }
 
-int mavlm_layernorm(const float* xin, const float* gamma, const float* beta, void* out, int32_t rows, int32_t D, float eps,
-                    int32_t dtype, void* stream) {
-  hipError_t e = mavlm_launch_layernorm(xin, gamma, beta, out, rows, D, eps, dtype, (hipStream_t)stream);
+int mavlm_layernorm(const float* xin, const void* res, int32_t ldr, const float* gamma, const float* beta, void* out,
+                    int32_t rows, int32_t D, float eps, int32_t dtype, void* stream) {
+  hipError_t e = mavlm_launch_layernorm(xin, res, ldr, gamma, beta, out, rows, D, eps, dtype, (hipStream_t)stream);
   return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
 }
 

@@ -4,7 +4,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-enum { MAVLM_EPI_BIAS = 0, MAVLM_EPI_RELU = 1, MAVLM_EPI_GELU = 2, MAVLM_EPI_RES_F32 = 3 };
+enum { MAVLM_EPI_BIAS = 0, MAVLM_EPI_RELU = 1, MAVLM_EPI_GELU = 2, MAVLM_EPI_RES_F32 = 3, MAVLM_EPI_F32 = 4 };
 
 struct mavlm_gemm_args {
   const void* A; int lda;        // [M,K] 16-bit, row stride lda elements
@@ -19,7 +19,10 @@ hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s)
 // 256x256x64 8-wave kernel (gemm256.hip); mavlm_launch_gemm picks it when the grid fills the chip
 bool mavlm_gemm256_supported(const mavlm_gemm_args& g);
 hipError_t mavlm_launch_gemm256(const mavlm_gemm_args& g, int dtype, hipStream_t s);
-extern int g_mavlm_gemm_tile;   // 0 = auto, 128 / 256 = forced (tuning hook, mavlm_set_gemm_tile)
+// persistent 256x256x64 kernel (gemm256p.hip): no residual epilogue, K >= 128
+bool mavlm_gemm256p_supported(const mavlm_gemm_args& g);
+hipError_t mavlm_launch_gemm256p(const mavlm_gemm_args& g, int dtype, hipStream_t s);
+extern int g_mavlm_gemm_tile;   // 0 = auto, 128 / 256 = forced non-persistent, 257 = forced persistent (tuning hook)
 
 struct mavlm_attn_args {
   const void* Q; int ldq;        // [R, >=H*128] 16-bit; head h at column h*128
@@ -51,9 +54,10 @@ hipError_t mavlm_launch_colsum3(const mavlm_colsum_args& a, int dtype, hipStream
 hipError_t mavlm_launch_frame_scores(const float* part, int H, int S, int F, int P, void* out, int out_f32, int dtype,
                                      hipStream_t s);
 
-// out[r,:] = LayerNorm(x[r,:]) * gamma + beta   (x fp32 [rows, D]; biased variance; rsqrt(var+eps))
-hipError_t mavlm_launch_layernorm(const float* x, const float* gamma, const float* beta, void* out, int rows, int D,
-                                  float eps, int dtype, hipStream_t s);
+// out[r,:] = LayerNorm(x[r,:] + res[r,:]) * gamma + beta   (x fp32 [rows, D]; res 16-bit [rows, ldr] or null;
+// biased variance; rsqrt(var+eps))
+hipError_t mavlm_launch_layernorm(const float* x, const void* res, int ldr, const float* gamma, const float* beta,
+                                  void* out, int rows, int D, float eps, int dtype, hipStream_t s);
 
 // out[t,p,:] = x[src[t],p,:] + table[idx[t],:]   (src null = identity, idx null = row 0)
 hipError_t mavlm_launch_row_add(const void* x, const int64_t* src, const void* table, const int64_t* idx, void* out,

@@ -50,14 +50,14 @@ if what in ("colsum", "all"):
     timeit(lambda: ops.attention_colsum(q, kv[:, :D], lse, H), 2.0 * R * S * D, f"colsum impl {impl} R={R} S={S}")
   capi.lib().mavlm_set_attention_impl(0)
 if what in ("gemm", "all"):
-  for tile in (128, 256):
+  for tile in (256, 257):
     capi.lib().mavlm_set_gemm_tile(tile)
     print("tile", tile)
-    for (M, N, K, epi) in [(S, 4 * D, D, 0), (R, D, D, 0), (R, D, D, 3), (R, 4 * D, D, 1), (R, D, 4 * D, 3), (R, 2 * D, D, 0),
+    for (M, N, K, epi) in [(S, 4 * D, D, 0), (R, D, D, 0), (R, D, D, 4), (R, 4 * D, D, 1), (R, D, 4 * D, 4), (R, 2 * D, D, 0),
                            (R, 4 * D, D, 2)]:
       a = torch.randn(M, K, device=dev).bfloat16()
       w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
       b = torch.randn(N, device=dev)
       res = torch.randn(M, N, device=dev).bfloat16() if epi == 3 else None
-      out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == 3 else torch.bfloat16)
+      out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi in (3, 4) else torch.bfloat16)
       timeit(lambda: ops.linear(a, w, b, epi, residual=res, out=out), 2.0 * M * N * K, f"gemm M={M} N={N} K={K} epi={epi}")

@@ -22,9 +22,10 @@ def _int_mat(shape, seed, lo=-4, hi=4):
     return np.floor(O.hash_uniform(shape, seed, lo, hi + 0.999)).astype(np.float32)
 
 
-@pytest.fixture(params=[128, 256])
+@pytest.fixture(params=[128, 256, 257])
 def gemm_tile(request):
-    """Run the GEMM tests once per block-tile kernel (128^2 4-wave, 256^2 8-wave LDS-DMA pipeline)."""
+    """Run the GEMM tests once per kernel: 128^2 4-wave, 256^2 8-wave LDS-DMA pipeline, 256^2 persistent (257;
+    shapes / epilogues it does not take fall through to the non-persistent kernels)."""
     capi.check(capi.lib().mavlm_set_gemm_tile(request.param), "set tile")
     yield request.param
     capi.lib().mavlm_set_gemm_tile(0)
@@ -32,7 +33,7 @@ def gemm_tile(request):
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("M,N,K", [(16, 128, 64), (200, 256, 192), (129, 128, 1024), (1, 384, 64), (513, 512, 64),
-                                   (300, 256, 128), (256, 768, 320)])
+                                   (300, 256, 128), (256, 768, 320), (4100, 4096, 192)])
 def test_linear_integer_exact(mode, M, N, K, gemm_tile):
     """A = I-like / asymmetric integer data: catches any row/col swap in the fragment or C maps exactly."""
     A = _int_mat((M, K), 1)
@@ -46,6 +47,10 @@ def test_linear_integer_exact(mode, M, N, K, gemm_tile):
     out_relu = ops.linear(to_dev(A, mode), to_dev(W, mode), f32_dev(b), capi.EPI_RELU)
     r = O.rounder(mode)
     np.testing.assert_array_equal(to_np(out_relu), r(np.maximum(ref, 0)))
+    out_f32 = ops.linear(to_dev(A, mode), to_dev(W, mode), f32_dev(b), capi.EPI_F32)       # bias -> fp32 (no residual)
+    np.testing.assert_array_equal(to_np(out_f32), ref)
+    out_b = ops.linear(to_dev(A, mode), to_dev(W, mode), f32_dev(b), capi.EPI_BIAS)
+    np.testing.assert_array_equal(to_np(out_b), r(ref))
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(1568, 1024, 1024, "bias"), (588, 4096, 1024, "bias"), (777, 512, 4096, "gelu"),
@@ -142,6 +147,11 @@ def test_layernorm_vs_oracle(D):
     ref = O.bf16_round(O.layernorm(x, g, b, 1e-12))
     got = to_np(ops.layernorm(f32_dev(x), f32_dev(g), f32_dev(b), 1e-12, torch.bfloat16))
     assert O.rel_l2(got, ref) < 2e-4
+    # fused residual add (fp32) of the Residual block
+    res = O.bf16_round(O.hash_normal_like((rows, D), 54))
+    ref_r = O.bf16_round(O.layernorm(x + res, g, b, 1e-12))
+    got_r = to_np(ops.layernorm(f32_dev(x), f32_dev(g), f32_dev(b), 1e-12, torch.bfloat16, residual=to_dev(res)))
+    assert O.rel_l2(got_r, ref_r) < 2e-4
     # constant rows: var = 0 -> rsqrt(0 + 1e-12) finite, output = beta
     xc = np.full((4, D), 2.5, np.float32)
     gc = to_np(ops.layernorm(f32_dev(xc), f32_dev(g), f32_dev(b), 1e-12, torch.bfloat16))

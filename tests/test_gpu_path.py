@@ -141,9 +141,9 @@ def test_step_stagewise_teacher_forced():
     errs["a(LN)"] = O.rel_l2(ws["a"], r(O.layernorm(pre_a, w[a1 + ".residual.layernorm.weight"],
                                                   w[a1 + ".residual.layernorm.bias"], cfg.eps)))
     errs["h(relu)"] = O.rel_l2(ws["h"], r(np.maximum(lin(ws["a"], f"{T}.layers.1.mlp.0"), 0)))
-    errs["pre(fp32)"] = O.rel_l2(ws["pre"], lin(ws["h"], f"{T}.layers.1.residual.dense") + ws["a"])
-    errs["m_out(LN)"] = O.rel_l2(to_np(cache[-1]).reshape(R, D),
-                                 r(O.layernorm(ws["pre"], w[f"{T}.layers.1.residual.layernorm.weight"],
+    errs["pre(fp32)"] = O.rel_l2(ws["pre"], lin(ws["h"], f"{T}.layers.1.residual.dense"))   # dense + bias, fp32
+    errs["m_out(LN)"] = O.rel_l2(to_np(cache[-1]).reshape(R, D),                              # + residual in the LN kernel
+                                 r(O.layernorm(ws["pre"] + ws["a"], w[f"{T}.layers.1.residual.layernorm.weight"],
                                                w[f"{T}.layers.1.residual.layernorm.bias"], cfg.eps)))
     part = eng.workspace_views()["part"].reshape(-1)[:H * S].view(H, S).cpu().numpy()
     errs["colsum"] = O.rel_l2(part, col)
