@@ -111,7 +111,7 @@ def main():
     rank, world, local = D.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % max(1, torch.cuda.device_count()))   # (rehearsals may share one GPU)
     torch.cuda.set_device(device)
     capi.lib()   # fail loudly if the HIP library is missing
     if os.environ.get("MAVLM_GEMM_TILE"):      # A/B hook (diagnostics): 128 / 256 / 257, default automatic
