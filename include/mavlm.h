@@ -140,6 +140,12 @@ int mavlm_layernorm(const float* x, const void* res, int32_t ldr, const float* g
 int mavlm_row_add(const void* x, const int64_t* src, const void* table, const int64_t* idx, void* out, int32_t T,
                   int32_t P, int32_t D, int32_t dtype, void* stream);
 
+/* step before the path: get_2dPool bilinear branch, llava_arch.py:277-297 -
+ * x [F, side*side, D] -> out [F, ceil(side/stride)^2, D] (F.interpolate bilinear, align_corners=False), optionally fused
+ * with the temporal PE add (pe_table/idx non-null; position_encoding.py:58,64).  One rounding per reference op. */
+int mavlm_pool_bilinear(const void* x, void* out, const void* pe_table, const int64_t* idx, int32_t F, int32_t side,
+                        int32_t stride, int32_t D, int32_t dtype, void* stream);
+
 /* tuning hook: force the GEMM kernel (128 = 128^2 tile, 256 = 256^2 non-persistent, 257 = 256^2 persistent;
  * 0 = automatic choice by grid size and epilogue).  Results are identical
  * up to fp32 summation order. */

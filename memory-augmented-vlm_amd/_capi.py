@@ -62,6 +62,7 @@ SIGNATURES = {
     "mavlm_attention_colsum": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, i32, i32, C.c_float, i32, vp]),
     "mavlm_layernorm": (C.c_int, [vp, vp, i32, vp, vp, vp, i32, i32, C.c_float, i32, vp]),
     "mavlm_row_add": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mavlm_pool_bilinear": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "mavlm_set_gemm_tile": (C.c_int, [i32]),
     "mavlm_set_attention_impl": (C.c_int, [i32]),
     "mavlm_prof_enable": (C.c_int, [i32]),

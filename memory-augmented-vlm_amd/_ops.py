@@ -121,3 +121,20 @@ def row_add(x, table, idx=None, src=None, out=None):
                                         idx.data_ptr() if idx is not None else 0, out.data_ptr(), T, P, D,
                                         dtype_code(x.dtype), stream_ptr()), "mavlm_row_add")
     return out
+
+
+def pool_bilinear(x, side, stride=2, pe_table=None, idx=None, out=None):
+    """[F, side*side, D] -> [F, ceil(side/stride)**2, D], bilinear (align_corners=False); optional fused PE add."""
+    _need_gpu(x, pe_table, idx, out)
+    if x.dim() != 3 or not x.is_contiguous() or x.shape[1] != side * side:
+        raise capi.MavlmError("pool_bilinear: expected contiguous [F, side*side, D]")
+    F, _, D = x.shape
+    os_ = -(-side // stride)
+    if out is None:
+        out = torch.empty((F, os_ * os_, D), device=x.device, dtype=x.dtype)
+    if pe_table is not None and (idx is None or idx.numel() != F or pe_table.dtype != x.dtype):
+        raise capi.MavlmError("pool_bilinear: PE table / index mismatch")
+    capi.check(capi.lib().mavlm_pool_bilinear(x.data_ptr(), out.data_ptr(), pe_table.data_ptr() if pe_table is not None else 0,
+                                              idx.data_ptr() if idx is not None else 0, F, side, stride, D,
+                                              dtype_code(x.dtype), stream_ptr()), "mavlm_pool_bilinear")
+    return out

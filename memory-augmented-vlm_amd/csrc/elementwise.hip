@@ -87,6 +87,48 @@ __global__ __launch_bounds__(256) void row_add_kernel(const uint16_t* __restrict
   }
 }
 
+// get_2dPool, bilinear branch (llava/model/llava_arch.py:277-297): F.interpolate(size=ceil(side/stride), mode='bilinear',
+// align_corners=False) over the [side, side] token grid, channels last.  One workgroup per output token, 8 channels
+// per lane (16-B loads of the 4 source tokens), fp32 lerp, ONE rounding to 16 bits; optionally followed by the
+// temporal PE add (position_encoding.py:58,64) with its own rounding, exactly as the two reference ops round.
+template <typename T>
+__global__ __launch_bounds__(128) void pool_bilinear_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ out,
+                                                            const uint16_t* __restrict__ table,
+                                                            const int64_t* __restrict__ idx, int side, int oside, int D,
+                                                            float scale) {
+  const int f = blockIdx.y;
+  const int o = blockIdx.x;
+  const int oy = o / oside, ox = o % oside;
+  // area_pixel_compute_source_index(scale, dst, align_corners=false, cubic=false): max(scale*(dst+0.5)-0.5, 0)
+  const float sy = fmaxf(scale * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(scale * (ox + 0.5f) - 0.5f, 0.f);
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = y0 + (y0 < side - 1), x1 = x0 + (x0 < side - 1);
+  const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+  const uint16_t* base = x + (size_t)f * side * side * D;
+  const uint16_t* p00 = base + (size_t)(y0 * side + x0) * D;
+  const uint16_t* p01 = base + (size_t)(y0 * side + x1) * D;
+  const uint16_t* p10 = base + (size_t)(y1 * side + x0) * D;
+  const uint16_t* p11 = base + (size_t)(y1 * side + x1) * D;
+  uint16_t* op = out + ((size_t)f * oside * oside + o) * D;
+  const uint16_t* pe = table ? table + (size_t)idx[f] * D : nullptr;
+  for (int c = threadIdx.x * 8; c < D; c += blockDim.x * 8) {
+    const u16x8 a = *(const u16x8*)(p00 + c), b = *(const u16x8*)(p01 + c), cc = *(const u16x8*)(p10 + c),
+                d = *(const u16x8*)(p11 + c);
+    u16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = hy * (hx * T::to_f32(a[e]) + lx * T::to_f32(b[e])) + ly * (hx * T::to_f32(cc[e]) + lx * T::to_f32(d[e]));
+      r[e] = T::from_f32(v);
+    }
+    if (pe) {
+      const u16x8 q = *(const u16x8*)(pe + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = T::from_f32(T::to_f32(r[e]) + T::to_f32(q[e]));
+    }
+    *(u16x8*)(op + c) = r;
+  }
+}
+
 template <typename T, int NV>
 void ln_launch(const float* x, const void* res, int ldr, const float* g, const float* b, void* out, int rows, int D,
                float eps, hipStream_t s) {
@@ -132,5 +174,22 @@ hipError_t mavlm_launch_row_add(const void* x, const int64_t* src, const void* t
   else
     hipLaunchKernelGGL(row_add_kernel<BF16>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)x, src,
                        (const uint16_t*)table, idx, (uint16_t*)out, T_, P, D);
+  return hipGetLastError();
+}
+
+hipError_t mavlm_launch_pool_bilinear(const void* x, void* out, const void* table, const int64_t* idx, int F, int side,
+                                      int stride, int D, int dtype, hipStream_t s) {
+  if (F <= 0) return hipSuccess;
+  if (!x || !out || side <= 0 || stride <= 0 || D <= 0 || (D & 7) || (table && !idx)) return hipErrorInvalidValue;
+  const int oside = (side + stride - 1) / stride;
+  const float scale = (float)side / (float)oside;
+  mavlm_prof_scope prof(MAVLM_K_ROWADD, 0.0, 2.0 * F * ((double)side * side + oside * oside) * D, s);
+  dim3 grid(oside * oside, F);
+  if (dtype == MAVLM_F16)
+    hipLaunchKernelGGL(pool_bilinear_kernel<F16>, grid, dim3(128), 0, s, (const uint16_t*)x, (uint16_t*)out,
+                       (const uint16_t*)table, idx, side, oside, D, scale);
+  else
+    hipLaunchKernelGGL(pool_bilinear_kernel<BF16>, grid, dim3(128), 0, s, (const uint16_t*)x, (uint16_t*)out,
+                       (const uint16_t*)table, idx, side, oside, D, scale);
   return hipGetLastError();
 }

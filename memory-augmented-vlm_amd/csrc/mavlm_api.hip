@@ -317,6 +317,12 @@ int mavlm_layernorm(const float* xin, const void* res, int32_t ldr, const float*
   return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
 }
 
+int mavlm_pool_bilinear(const void* xin, void* out, const void* pe_table, const int64_t* idx, int32_t F, int32_t side,
+                        int32_t stride, int32_t D, int32_t dtype, void* stream) {
+  hipError_t e = mavlm_launch_pool_bilinear(xin, out, pe_table, idx, F, side, stride, D, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
 int mavlm_row_add(const void* xin, const int64_t* src, const void* table, const int64_t* idx, void* out, int32_t T,
                   int32_t P, int32_t D, int32_t dtype, void* stream) {
   hipError_t e = mavlm_launch_row_add(xin, src, table, idx, out, T, P, D, dtype, (hipStream_t)stream);

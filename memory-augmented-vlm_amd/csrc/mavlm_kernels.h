@@ -63,6 +63,10 @@ hipError_t mavlm_launch_layernorm(const float* x, const void* res, int ldr, cons
 hipError_t mavlm_launch_row_add(const void* x, const int64_t* src, const void* table, const int64_t* idx, void* out,
                                 int T, int P, int D, int dtype, hipStream_t s);
 
+// out[f, oy*os+ox, :] = bilinear(x[f, side x side, :]) (+ table[idx[f], :] when table != null); os = ceil(side/stride)
+hipError_t mavlm_launch_pool_bilinear(const void* x, void* out, const void* table, const int64_t* idx, int F, int side,
+                                      int stride, int D, int dtype, hipStream_t s);
+
 // ---- optional per-kernel HIP-event profiling (bench.py roofline line); off by default, zero cost when off.
 enum { MAVLM_K_GEMM = 0, MAVLM_K_ATTN = 1, MAVLM_K_COLSUM = 2, MAVLM_K_LN = 3, MAVLM_K_ROWADD = 4, MAVLM_K_MISC = 5,
        MAVLM_K_COUNT = 6 };

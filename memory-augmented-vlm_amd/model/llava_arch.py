@@ -218,11 +218,15 @@ class LlavaMetaForCausalLM:
 
     def get_2dPool(self, image_feature, stride=2):
         """[F, side*side, D] -> [F, ceil(side/stride)^2, D]  (llava_arch.py:277-297).  Step before the path
-        (SURVEY.md §8f rank 1): stays a backbone op on PyTorch-ROCm in this round."""
+        (SURVEY.md §8f rank 1).  The bilinear mode the reference scripts use runs as a HIP kernel on 16-bit GPU
+        tensors (no NCHW permute round trip); the average / max modes stay backbone ops."""
         side = self.get_vision_tower().num_patches_per_side
         nf, _, nd = image_feature.shape
-        x = image_feature.view(nf, side, side, -1).permute(0, 3, 1, 2).contiguous()
         mode = self.config.mm_spatial_pool_mode
+        if mode == "bilinear" and image_feature.is_cuda and image_feature.dtype in (torch.bfloat16, torch.float16) \
+                and nd % 8 == 0:
+            return ops.pool_bilinear(image_feature.contiguous(), side, stride)      # HIP kernel (channels stay last)
+        x = image_feature.view(nf, side, side, -1).permute(0, 3, 1, 2).contiguous()
         if mode == "average":
             x = nn.functional.avg_pool2d(x, stride)
         elif mode == "max":

@@ -179,3 +179,29 @@ def test_bad_arguments_fail_loudly():
         ops.linear(a, w, f32_dev(np.zeros(100, np.float32)))
     with pytest.raises(capi.MavlmError):
         ops.linear(a.cpu(), w.cpu(), torch.zeros(100))
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_pool_bilinear_vs_oracle_and_reference_golden(mode):
+    """get_2dPool bilinear 27x27 -> 14x14 (llava_arch.py:277-297).  The oracle's bilinear_pool is pinned to the
+    reference's own output (tests/golden/g6_glue.npz: pooled_2); here the HIP kernel is checked against it."""
+    from conftest import load_golden
+    r = O.rounder(mode)
+    side, D, F = 27, 256, 5
+    x = r(O.hash_normal_like((F, side * side, D), 71))
+    ref = r(O.bilinear_pool(x, side))
+    got = to_np(ops.pool_bilinear(to_dev(x, mode), side))
+    ulp = 2.0 ** (-7 if mode == "bf16" else -10)      # spacing of the grid in [1, 2): 7 / 10 stored mantissa bits
+    assert np.abs(got - ref).max() <= ulp * np.abs(ref).max() * 1.01          # at most one 16-bit ulp
+    assert O.rel_l2(got, ref) < 3e-4
+    # fused PE add keeps the two reference roundings
+    table = r(O.pe_table(50, D))
+    idx = np.array([0, 49, 7, 7, 13])
+    ref2 = r(ref + table[idx][:, None, :])
+    got2 = to_np(ops.pool_bilinear(to_dev(x, mode), side, pe_table=to_dev(table, mode), idx=torch.from_numpy(idx).cuda()))
+    assert O.rel_l2(got2, ref2) < 3e-4
+    if mode == "bf16":   # the reference's own pooled output (fp32 run on bf16-grid inputs), D = 32
+        z, m = load_golden("g6_glue.npz")
+        feats = O.bf16_round(O.hash_normal_like((8, side * side, m["D"]), int(z["pool_in_seed"])))[:2]
+        got3 = to_np(ops.pool_bilinear(to_dev(feats), side))
+        assert O.rel_l2(got3, z["pooled_2"]) < 3e-3                            # bf16 output rounding vs fp32 reference
