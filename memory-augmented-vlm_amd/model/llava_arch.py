@@ -197,6 +197,48 @@ class MemoryPathPool:
         return outs
 
 
+class GraphedVideoMemory:
+    """hipGraph-captured memory path for one video shape (T frames): PE add, every chunk step (evolution +
+    formation, FIFO slots baked in), fuser MLP + type add + concat - ONE graph launch per video instead of ~45 kernel
+    launches (BASELINE.json configs[2]: "hipGraph-captured per-chunk memory update").  Possible because no entry
+    point of the C ABI allocates or synchronises and the recurrent state lives in caller-owned buffers.
+
+    usage:  g = GraphedVideoMemory(model, T=256, frame_idx_cpu=idx)        # captures on the current device
+            tokens = g(frames, mem_prompt, frame_prompt, newline)          # copies into the static inputs, replays
+    The returned tensor is the graph's static output buffer (valid until the next call).  A new shape (T, indices,
+    with_frames) needs a new instance."""
+
+    def __init__(self, model, T: int, frame_idx_cpu: torch.Tensor, with_frames: bool = True, slot=None):
+        rm = model.recurrent_memory_transformer
+        self.view = slot if slot is not None else _ReplicaView(model, rm.spawn_replica())
+        self.idx = frame_idx_cpu.clone()
+        self.with_frames = with_frames
+        p = next(rm.parameters())
+        D, P = rm.hidden_size, rm.patch_size
+        dev, dt = p.device, p.dtype
+        self.x = torch.zeros((T, P, D), device=dev, dtype=dt)
+        self.mp = torch.zeros((len(MEMORY_PROMPT_IDS), D), device=dev, dtype=dt)
+        self.fp = torch.zeros((len(FRAME_PROMPT_IDS), D), device=dev, dtype=dt)
+        self.nl = torch.zeros((D,), device=dev, dtype=dt)
+        # warm-up outside capture: engine creation, weight packing, kernel attribute calls, index uploads
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            video_memory_tokens(self.view, self.x, self.idx, self.mp, self.fp, self.nl, with_frames)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out, _ = video_memory_tokens(self.view, self.x, self.idx, self.mp, self.fp, self.nl, with_frames)
+
+    def __call__(self, frames, memory_prompt_embeds, frame_prompt_embeds, image_newline):
+        self.x.copy_(frames)
+        self.mp.copy_(memory_prompt_embeds)
+        self.fp.copy_(frame_prompt_embeds)
+        self.nl.copy_(image_newline)
+        self.graph.replay()
+        return self.out
+
+
 class _ReplicaView:
     """The four memory sub-modules as seen by one pool slot (shared weights, private recurrent state)."""
 

@@ -375,3 +375,80 @@ def test_pool_two_videos_in_flight_bit_identical():
     torch.cuda.synchronize()
     for a, b in zip(serial, outs):
         assert torch.equal(a, b)
+
+
+def test_graph_capture_replay_bit_identical():
+    """The whole per-video launch sequence captured into one hipGraph replays to the same bits as eager launches."""
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=14)
+    model, _ = _tiny_host(cfg, w)
+    T = 70
+    idx = torch.arange(T)
+    mp = torch.randn((10, 1024), device="cuda").bfloat16()
+    fp = torch.randn((9, 1024), device="cuda").bfloat16()
+    g = arch.GraphedVideoMemory(model, T, idx)
+    for seed in (1400, 1401):
+        x = to_dev(O.bf16_round(O.hash_normal_like((T, 196, 1024), seed)))
+        eager, _ = arch.video_memory_tokens(model, x, idx, mp, fp, model.image_newline)
+        out = g(x, mp, fp, model.image_newline)
+        torch.cuda.synchronize()
+        assert out.shape == eager.shape == (10 + 3 * 1568 + 1 + 9 + 32 * 196 + 1, 1024)
+        assert torch.equal(out, eager)
+
+
+@pytest.mark.parametrize("T", [1, 5, 33])
+def test_short_and_ragged_videos_vs_oracle(T):
+    """Edge cases of the chunking (llava_arch.py:437-457, segment.py:169-192): a single frame, a short single chunk,
+    and 32 + 1 frames (a one-frame tail chunk that still goes through memory evolution)."""
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=15)
+    model, _ = _tiny_host(cfg, w)
+    emb = np.zeros((48900, 1024), np.float32)
+    x = O.bf16_round(O.hash_normal_like((T, 196, 1024), 1500 + T))
+    idx = np.arange(T) * 3 % 600
+    toks = O.video_tokens(x, idx, cfg, w, emb, "bf16")
+    with O.accumulate_in(np.float64):
+        toks64 = O.video_tokens(x, idx, cfg, w, emb, "bf16")
+    mp = torch.zeros((10, 1024), device="cuda", dtype=torch.bfloat16)
+    fp = torch.zeros((9, 1024), device="cuda", dtype=torch.bfloat16)
+    got, info = arch.video_memory_tokens(model, to_dev(x), torch.from_numpy(idx), mp, fp, model.image_newline)
+    n = 1 if T <= 32 else 2
+    assert info["num_memories"] == n and got.shape[0] == toks.shape[0] == 10 + n * 1568 + 1 + 9 + min(32, T) * 196 + 1
+    assert O.rel_l2(to_np(got), toks) < chain_tol(O.rel_l2(toks64, toks))
+
+
+def test_fifo_saturation_full_width_vs_oracle():
+    """12 one-frame chunks at D=1024, M=8: the FIFO (cap 10) saturates, the evolution attends over 10 x 1568 keys and
+    the ring wraps (MemoryController.py:152-154).  Oldest-first order of the returned cache is checked too."""
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=16)
+    proj = make_projector(cfg, w)
+    segs = [O.bf16_round(O.hash_normal_like((1, 196, 1024), 1600 + t)) for t in range(12)]
+    ref = run_oracle_steps(cfg, w, "bf16", segs, np.float32)
+    alt = run_oracle_steps(cfg, w, "bf16", segs, np.float64)
+    proj.memory_cache = []
+    with torch.no_grad():
+        for seg in segs:
+            cache, scores = proj(to_dev(seg))
+    assert len(cache) == len(ref[-1][0]) == 10
+    for i in (0, 4, 9):
+        floor = O.rel_l2(alt[-1][0][i], ref[-1][0][i])
+        assert O.rel_l2(to_np(cache[i]), ref[-1][0][i]) < chain_tol(floor), i
+    assert len(proj.frame_attn_scores) == 12
+
+
+def test_config5_shape_fp16_128_memory_tokens_properties():
+    """BASELINE configs[4] shape on one GPU: 128 memory tokens, fp16 MFMA path.  Too large for the CPU oracle in a
+    test, so size-independent properties only."""
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=128, depth=2)
+    w = O.make_weights(cfg, seed=17, grid="fp16")
+    proj = make_projector(cfg, w, "fp16")
+    proj.memory_cache = []
+    with torch.no_grad():
+        for t in range(3):
+            seg = to_dev(O.fp16_round(O.hash_normal_like((32, 196, 1024), 1700 + t)), "fp16")
+            cache, scores = proj(seg)
+    assert len(cache) == 3 and tuple(cache[-1].shape) == (128, 196, 1024) and cache[-1].dtype == torch.float16
+    assert torch.isfinite(torch.stack(list(cache)).float()).all()
+    for s_ in scores[-3:]:
+        assert abs(float(s_.float().sum()) - 8 * 128) < 0.02 * 8 * 128      # sum_f score_f = H*R/P
