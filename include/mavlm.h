@@ -35,7 +35,7 @@ typedef struct mavlm_ctx mavlm_ctx;
 /* Hyper-parameters: `Config` (llava/model/memory_module/MemoryController.py:7-18) as overridden at
  * llava/model/llava_arch.py:117-129, plus the FIFO cap (MemoryController.py:153-154). */
 typedef struct mavlm_config {
-  int32_t hidden;           /* D, mm_hidden_size; multiple of 128; head_dim = D/heads <= 128 (D = 896, 1024 ...) */
+  int32_t hidden;           /* D, mm_hidden_size; multiple of 128; head_dim = D/heads <= 128 (D = 896, 1024 ...) or 448 (D = 3584) */
   int32_t heads;            /* H, mm_num_attention_heads (8) */
   int32_t patches;          /* P, patch_size (196) */
   int32_t mem_tokens;       /* M, num_memory_tokens (8) */
@@ -129,6 +129,13 @@ int mavlm_linear(const void* A, int32_t lda, const void* W, int32_t ldw, const f
 /* ctx[R,H*128] = softmax(Q K^T / sqrt(128)) V per head; lse2 [H,R] fp32 optional.  MemoryController.py:51-54 */
 int mavlm_attention(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                     int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream);
+/* same for wide heads: head h occupies columns [h*head_dim, (h+1)*head_dim); head_dim 448 (LLaVA-OneVision-7B: hidden
+ * 3584 / 8 heads, llava_arch.py:117-122) or 128 */
+int mavlm_attention_hd(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
+                       int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, int32_t head_dim, float scale,
+                       int32_t dtype, void* stream);
+int mavlm_attention_colsum_hd(const void* Q, int32_t ldq, const void* K, int32_t ldk, const float* lse2, float* part,
+                              int32_t R, int32_t S, int32_t H, int32_t head_dim, float scale, int32_t dtype, void* stream);
 /* part[H,S] fp32 = column sums over queries of the normalised probabilities.  MemoryController.py:135 */
 int mavlm_attention_colsum(const void* Q, int32_t ldq, const void* K, int32_t ldk, const float* lse2, float* part,
                            int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream);

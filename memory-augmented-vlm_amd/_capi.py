@@ -59,6 +59,8 @@ SIGNATURES = {
                                   C.POINTER(C.c_int64), vp]),
     "mavlm_linear": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mavlm_attention": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.c_float, i32, vp]),
+    "mavlm_attention_hd": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, C.c_float, i32, vp]),
+    "mavlm_attention_colsum_hd": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, C.c_float, i32, vp]),
     "mavlm_attention_colsum": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, i32, i32, C.c_float, i32, vp]),
     "mavlm_layernorm": (C.c_int, [vp, vp, i32, vp, vp, vp, i32, i32, C.c_float, i32, vp]),
     "mavlm_row_add": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

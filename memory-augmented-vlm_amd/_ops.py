@@ -56,33 +56,46 @@ def linear(x, weight, bias_f32, epilogue=capi.EPI_BIAS, residual=None, out=None)
     return out
 
 
-def attention(q, k, v, heads, want_lse=False, out=None):
-    """ctx = softmax(q k^T / sqrt(128)) v per head (head_dim 128).  q [R,>=H*128], k/v [S,...] may be column
-    slices of wider buffers.  Returns (ctx [R,H*128], lse2 [H,R] fp32 | None)."""
+def attention(q, k, v, heads, want_lse=False, out=None, head_dim=128, wide_kernel=False):
+    """ctx = softmax(q k^T / sqrt(head_dim)) v per head.  q [R,>=H*hd], k/v [S,...] may be column slices of wider
+    buffers.  head_dim 128 (default kernels) or 448 (wide-head kernel; `wide_kernel=True` forces that kernel at 128
+    for cross-checks).  Returns (ctx [R,H*hd], lse2 [H,R] fp32 | None)."""
     _need_gpu(q, k, v)
     R, _, ldq = _rows(q)
     S, _, ldk = _rows(k)
     S2, _, ldv = _rows(v)
-    if S2 != S or q.shape[1] < heads * 128 or k.shape[1] < heads * 128 or v.shape[1] < heads * 128:
-        raise capi.MavlmError("attention: operand mismatch (head_dim must be 128)")
+    W = heads * head_dim
+    if S2 != S or q.shape[1] < W or k.shape[1] < W or v.shape[1] < W or head_dim not in (128, 448):
+        raise capi.MavlmError("attention: operand mismatch (head_dim must be 128 or 448)")
     if out is None:
-        out = torch.empty((R, heads * 128), device=q.device, dtype=q.dtype)
+        out = torch.empty((R, W), device=q.device, dtype=q.dtype)
     lse = torch.empty((heads, R), device=q.device, dtype=torch.float32) if want_lse else None
-    capi.check(capi.lib().mavlm_attention(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(),
-                                          out.stride(0), lse.data_ptr() if want_lse else 0, R, S, heads,
-                                          1.0 / math.sqrt(128.0), dtype_code(q.dtype), stream_ptr()), "mavlm_attention")
+    lp = lse.data_ptr() if want_lse else 0
+    if head_dim == 128 and not wide_kernel:
+        capi.check(capi.lib().mavlm_attention(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(),
+                                              out.stride(0), lp, R, S, heads, 1.0 / math.sqrt(128.0), dtype_code(q.dtype),
+                                              stream_ptr()), "mavlm_attention")
+    else:
+        capi.check(capi.lib().mavlm_attention_hd(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(),
+                                                 out.stride(0), lp, R, S, heads, head_dim, 1.0 / math.sqrt(head_dim),
+                                                 dtype_code(q.dtype), stream_ptr()), "mavlm_attention_hd")
     return out, lse
 
 
-def attention_colsum(q, k, lse2, heads):
+def attention_colsum(q, k, lse2, heads, head_dim=128, wide_kernel=False):
     """part[h,s] = sum_q softmax probability of key s for head h (fp32)."""
     _need_gpu(q, k, lse2)
     R, _, ldq = _rows(q)
     S, _, ldk = _rows(k)
     part = torch.empty((heads, S), device=q.device, dtype=torch.float32)
-    capi.check(capi.lib().mavlm_attention_colsum(q.data_ptr(), ldq, k.data_ptr(), ldk, lse2.data_ptr(), part.data_ptr(),
-                                                 R, S, heads, 1.0 / math.sqrt(128.0), dtype_code(q.dtype), stream_ptr()),
-               "mavlm_attention_colsum")
+    if head_dim == 128 and not wide_kernel:
+        capi.check(capi.lib().mavlm_attention_colsum(q.data_ptr(), ldq, k.data_ptr(), ldk, lse2.data_ptr(), part.data_ptr(),
+                                                     R, S, heads, 1.0 / math.sqrt(128.0), dtype_code(q.dtype), stream_ptr()),
+                   "mavlm_attention_colsum")
+    else:
+        capi.check(capi.lib().mavlm_attention_colsum_hd(q.data_ptr(), ldq, k.data_ptr(), ldk, lse2.data_ptr(),
+                                                        part.data_ptr(), R, S, heads, head_dim, 1.0 / math.sqrt(head_dim),
+                                                        dtype_code(q.dtype), stream_ptr()), "mavlm_attention_colsum_hd")
     return part
 
 

@@ -34,9 +34,12 @@ bool cfg_ok(const mavlm_config* c) {
 // shapes the gfx950 kernels implement (DESIGN.md "Supported shapes"): head_dim <= 128 (heads are zero-padded to
 // 128 columns in the Q/K/V/ctx buffers and in the packed weights), D and I multiples of 128
 bool shape_ok(const mavlm_config* c) {
-  return c->hidden % 128 == 0 && c->hidden % c->heads == 0 && c->hidden / c->heads <= 128 && c->inter % 128 == 0;
+  if (c->hidden % 128 != 0 || c->hidden % c->heads != 0 || c->inter % 128 != 0) return false;
+  const int hd = c->hidden / c->heads;
+  return hd <= 128 || hd == 448;      // 448: wide-head kernels (attention_hd.hip), no padding
 }
-inline int padded_width(const mavlm_config& c) { return c.heads * 128; }
+inline bool wide_heads(const mavlm_config& c) { return c.hidden / c.heads > 128; }
+inline int padded_width(const mavlm_config& c) { return wide_heads(c) ? c.hidden : c.heads * 128; }
 inline float attn_scale(const mavlm_config& c) { return 1.0f / sqrtf((float)(c.hidden / c.heads)); }
 
 void carve(mavlm_ctx* x) {
@@ -82,7 +85,11 @@ int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const 
   mavlm_attn_args a;
   a.Q = ws(x, x->o_q); a.ldq = Dp; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = ws(x, x->o_ctx); a.ldo = Dp;
   a.lse2 = lse2; a.R = R; a.S = S; a.H = H; a.scale = attn_scale(c);
-  MAVLM_TRY(mavlm_launch_attention(a, dt, s));
+  if (wide_heads(c)) {
+    MAVLM_TRY(mavlm_launch_attention_hd(a, c.hidden / c.heads, dt, s));
+  } else {
+    MAVLM_TRY(mavlm_launch_attention(a, dt, s));
+  }
   // Residual: dense + bias in fp32 (GEMM epilogue), + residual and LayerNorm in the row kernel (MemoryController.py:26-29)
   MAVLM_TRY(gemm(dt, s, ws(x, x->o_ctx), Dp, aw.wo, Dp, aw.bo, ws(x, x->o_pre), D, R, D, Dp, MAVLM_EPI_F32));
   MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), xq, D, aw.ln_g, aw.ln_b, out, R, D, c.eps, dt, s));
@@ -223,7 +230,11 @@ int mavlm_step(mavlm_ctx* x, const void* seg, int32_t F, void* frame_scores, int
       mavlm_colsum_args ca;
       ca.Q = ws(x, x->o_q); ca.ldq = Dp; ca.K = Kl; ca.ldk = ldkv; ca.lse2 = lse; ca.part = (float*)ws(x, x->o_part);
       ca.R = R; ca.S = S; ca.H = H; ca.scale = attn_scale(c);
-      MAVLM_TRY(mavlm_launch_colsum(ca, dt, s));
+      if (wide_heads(c)) {
+        MAVLM_TRY(mavlm_launch_colsum_hd(ca, c.hidden / c.heads, dt, s));
+      } else {
+        MAVLM_TRY(mavlm_launch_colsum(ca, dt, s));
+      }
       MAVLM_TRY(mavlm_launch_frame_scores(ca.part, H, S, F, c.patches, frame_scores, scores_f32, dt, s));
     }
     // MLP: Linear(D,I)+ReLU -> Residual(I->D)  (MemoryController.py:63-67,71)
@@ -301,6 +312,28 @@ int mavlm_attention(const void* Q, int32_t ldq, const void* K, int32_t ldk, cons
   a.R = R; a.S = S; a.H = H; a.scale = scale;
   hipError_t e = mavlm_launch_attention(a, dtype, (hipStream_t)stream);
   return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int mavlm_attention_hd(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
+                       int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, int32_t head_dim, float scale,
+                       int32_t dtype, void* stream) {
+  if (!Q || !K || !V || !O || R <= 0 || S <= 0 || H <= 0 || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) ||
+      ldq < H * head_dim || ldk < head_dim || ldv < head_dim)
+    return MAVLM_E_ARG;
+  if (head_dim != 448 && head_dim != 128) return MAVLM_E_SHAPE;
+  mavlm_attn_args a;
+  a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.lse2 = lse2;
+  a.R = R; a.S = S; a.H = H; a.scale = scale;
+  return (int)mavlm_launch_attention_hd(a, head_dim, dtype, (hipStream_t)stream);
+}
+
+int mavlm_attention_colsum_hd(const void* Q, int32_t ldq, const void* K, int32_t ldk, const float* lse2, float* part,
+                              int32_t R, int32_t S, int32_t H, int32_t head_dim, float scale, int32_t dtype, void* stream) {
+  if (!Q || !K || !lse2 || !part || R <= 0 || S <= 0 || H <= 0 || (ldq & 7) || (ldk & 7)) return MAVLM_E_ARG;
+  if (head_dim != 448 && head_dim != 128) return MAVLM_E_SHAPE;
+  mavlm_colsum_args a;
+  a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.lse2 = lse2; a.part = part; a.R = R; a.S = S; a.H = H; a.scale = scale;
+  return (int)mavlm_launch_colsum_hd(a, head_dim, dtype, (hipStream_t)stream);
 }
 
 int mavlm_attention_colsum(const void* Q, int32_t ldq, const void* K, int32_t ldk, const float* lse2, float* part,

@@ -49,6 +49,9 @@ struct mavlm_colsum_args {
 };
 hipError_t mavlm_launch_colsum(const mavlm_colsum_args& a, int dtype, hipStream_t s);
 hipError_t mavlm_launch_colsum3(const mavlm_colsum_args& a, int dtype, hipStream_t s);   // pipelined (attention3.hip)
+// wide heads (attention_hd.hip): head_dim 448 (OV-7B), also 128 for cross-checks; columns of head h start at h*head_dim
+hipError_t mavlm_launch_attention_hd(const mavlm_attn_args& a, int head_dim, int dtype, hipStream_t s);
+hipError_t mavlm_launch_colsum_hd(const mavlm_colsum_args& a, int head_dim, int dtype, hipStream_t s);
 
 // frame_scores[f] = (1/P) * sum_{p<P} sum_h part[h][f*P+p]     (MemoryController.py:135-139)
 hipError_t mavlm_launch_frame_scores(const float* part, int H, int S, int F, int P, void* out, int out_f32, int dtype,

@@ -146,7 +146,8 @@ class _Engine:
         self.ctx = h
         R, D = self.c.mem_tokens * self.c.patches, self.c.hidden
         self.head_dim = D // self.c.heads
-        self.Dp = self.c.heads * 128                      # per-head columns zero-padded to 128 (attention kernel width)
+        # attention buffer width: heads zero-padded to 128 columns, or native for the wide-head kernel (448, OV-7B)
+        self.Dp = D if self.head_dim > 128 else self.c.heads * 128
         self.mem_ring = torch.empty((self.c.cache_cap, self.c.mem_tokens, self.c.patches, D), device=device, dtype=dtype)
         self.evo_kv = torch.empty((self.c.cache_cap, R, 2 * self.Dp), device=device, dtype=dtype)
         nbytes = lib.mavlm_workspace_bytes(self.c)
@@ -183,7 +184,7 @@ class _Engine:
         H, hd = self.c.heads, self.head_dim
 
         def pad_out(t):      # [H*hd, ...] -> [H*128, ...]: zero rows after each head (projection OUTPUT side)
-            if hd == 128:
+            if hd >= 128:
                 return t
             t = t.detach()
             shp = t.shape[1:]
@@ -192,7 +193,7 @@ class _Engine:
             return z.reshape((H * 128,) + tuple(shp))
 
         def pad_in(t):       # [D, H*hd] -> [D, H*128]: zero columns after each head (projection INPUT side)
-            if hd == 128:
+            if hd >= 128:
                 return t
             t = t.detach()
             z = torch.zeros((t.shape[0], H, 128), device=t.device, dtype=t.dtype)

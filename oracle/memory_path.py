@@ -329,8 +329,15 @@ RESCALE_LOG2 = 8.0    # deferred-rescale threshold of the kernel, log2 units (at
 WAVE_ROWS = 32        # queries per wave: the rescale decision is wave-uniform (any lane over threshold)
 
 
+def kernel_tiling(head_dim: int) -> Tuple[int, int]:
+    """(keys per tile, queries per wave) of the HIP attention kernel that serves this head_dim:
+    attention3.hip (<= 128, zero-padded to 128): 64 / 32;  attention_hd.hip (448): 32 / 16."""
+    return (KV_TILE, WAVE_ROWS) if head_dim <= 128 else (32, 16)
+
+
 def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mode: str = "fp32",
-                    want_colsum: bool = False, want_probs: bool = False, kv_tile: int = KV_TILE):
+                    want_colsum: bool = False, want_probs: bool = False, kv_tile: Optional[int] = None,
+                    wave_rows: Optional[int] = None):
     """softmax(Q K^T / sqrt(d)) V per head (MemoryController.py:51-54).  Returns
     (ctx [R,H*d] unrounded float32, lse2 [H,R] log2-domain log-sum-exp, colsum [H,Lk] | None, probs | None).
 
@@ -342,6 +349,10 @@ def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mod
     r = rounder(mode)
     R, Lk = Q.shape[0], K.shape[0]
     d = Q.shape[1] // heads
+    if kv_tile is None or wave_rows is None:
+        kt_, wr_ = kernel_tiling(d)
+        kv_tile = kv_tile or kt_
+        wave_rows = wave_rows or wr_
     scale = F32(1.0 / math.sqrt(d))
     ctx = np.empty((R, heads * d), dtype=F32)
     lse2 = np.empty((heads, R), dtype=F32)
@@ -363,9 +374,9 @@ def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mod
                 st = s[:, k0:k0 + kv_tile]
                 cand = np.maximum(m, st.max(axis=1, keepdims=True))
                 need = ((cand - m) * F32(1.4426950408889634) > F32(RESCALE_LOG2)).reshape(-1)
-                pad = (-R) % WAVE_ROWS
-                grp = np.concatenate([need, np.zeros(pad, bool)]).reshape(-1, WAVE_ROWS).any(axis=1)
-                move = np.repeat(grp, WAVE_ROWS)[:R].reshape(R, 1)
+                pad = (-R) % wave_rows
+                grp = np.concatenate([need, np.zeros(pad, bool)]).reshape(-1, wave_rows).any(axis=1)
+                move = np.repeat(grp, wave_rows)[:R].reshape(R, 1)
                 m_new = np.where(move, cand, m).astype(F32)
                 alpha = np.exp(m - m_new, dtype=F32)
                 pt = np.exp(st - m_new, dtype=F32)

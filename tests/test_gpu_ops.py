@@ -205,3 +205,40 @@ def test_pool_bilinear_vs_oracle_and_reference_golden(mode):
         feats = O.bf16_round(O.hash_normal_like((8, side * side, m["D"]), int(z["pool_in_seed"])))[:2]
         got3 = to_np(ops.pool_bilinear(to_dev(feats), side))
         assert O.rel_l2(got3, z["pooled_2"]) < 3e-3                            # bf16 output rounding vs fp32 reference
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("hd,R,S,H", [(128, 200, 300, 2), (448, 16, 32, 1), (448, 200, 300, 2), (448, 129, 97, 1),
+                                      (448, 392, 588, 8), (128, 1, 1, 1), (448, 1, 1, 1)])
+def test_attention_wide_heads_vs_oracle(mode, hd, R, S, H):
+    """attention_hd.hip: 16-query waves on 16x16x32 MFMA, head_dim 448 (LLaVA-OneVision-7B) and 128 (cross-check of
+    the same machinery); oracle emulation with that kernel's tiling (32-key tiles, 16-query waves)."""
+    r = O.rounder(mode)
+    W = H * hd
+    q = r(O.hash_normal_like((R, W), 81))
+    k = r(O.hash_normal_like((S, W), 82))
+    v = r(O.hash_normal_like((S, W), 83))
+    ctx, lse2, col, _ = O.attention_heads(q, k, v, H, mode, want_colsum=True, kv_tile=32, wave_rows=16)
+    got, lse = ops.attention(to_dev(q, mode), to_dev(k, mode), to_dev(v, mode), H, want_lse=True, head_dim=hd,
+                             wide_kernel=True)
+    assert O.rel_l2(to_np(got), r(ctx)) < TOL
+    np.testing.assert_allclose(to_np(lse), lse2, rtol=0, atol=3e-3)
+    part = ops.attention_colsum(to_dev(q, mode), to_dev(k, mode), lse, H, head_dim=hd, wide_kernel=True)
+    assert O.rel_l2(to_np(part), col) < TOL
+    assert abs(float(part.sum()) - H * R) < 1e-3 * H * R
+
+
+def test_attention_wide_heads_identity_v_and_rescale():
+    """One-hot V (ctx = probabilities: catches key/column permutation errors of the P.V operand mapping at 448) and a
+    late dominating key (forces the deferred-rescale branch)."""
+    R, S, H, hd = 48, 160, 1, 448
+    r = O.bf16_round
+    q = r(O.hash_normal_like((R, hd), 91) * 0.3)
+    k = r(O.hash_normal_like((S, hd), 92) * 0.3)
+    v = np.zeros((S, hd), np.float32)
+    v[np.arange(S), (np.arange(S) * 11 + 5) % hd] = 1.0
+    k[32 * 4 + 17] = r(q[5] * 6.0)
+    ctx, lse2, _, _ = O.attention_heads(q, k, v, H, "bf16", kv_tile=32, wave_rows=16)
+    got, lse = ops.attention(to_dev(q), to_dev(k), to_dev(v), H, want_lse=True, head_dim=hd)
+    assert O.rel_l2(to_np(got), r(ctx)) < TOL
+    np.testing.assert_allclose(to_np(lse), lse2, rtol=0, atol=5e-3)

@@ -60,9 +60,11 @@ def make_projector(cfg: O.PathConfig, w, mode="bf16", cache_cap=10):
 
 @pytest.mark.parametrize("mode,H,M,frames,hd", [("bf16", 8, 8, [3, 2, 3, 1], 128), ("fp16", 2, 4, [2, 1, 2], 128),
                                                  ("bf16", 1, 3, [1, 1], 128), ("bf16", 8, 8, [2, 3, 1], 112),
-                                                 ("fp16", 4, 2, [1, 2], 64)])
+                                                 ("fp16", 4, 2, [1, 2], 64), ("bf16", 2, 4, [2, 1, 2], 448),
+                                                 ("bf16", 8, 8, [2, 1], 448)])
 def test_recurrent_steps_vs_oracle(mode, H, M, frames, hd):
-    """hd = 112 is the Qwen2-0.5B shape (D = 896, the reference Config default): heads run zero-padded to 128."""
+    """hd = 112 is the Qwen2-0.5B shape (D = 896, the reference Config default): heads run zero-padded to 128.
+    hd = 448 is the LLaVA-OneVision-7B shape (D = 3584 with 8 heads): wide-head kernels, attention_hd.hip."""
     cfg = O.PathConfig(hidden=hd * H, heads=H, mem_tokens=M, depth=2)
     w = O.make_weights(cfg, seed=5, grid=mode)
     proj = make_projector(cfg, w, mode)

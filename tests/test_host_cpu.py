@@ -55,8 +55,13 @@ def test_config_validation_without_gpu(built_lib):
     h2 = capi.vp()
     assert lib.mavlm_create(q05, h2) == 0
     lib.mavlm_destroy(h2)
-    bad = capi.Config(hidden=3584, heads=8, patches=196, mem_tokens=8, depth=2, inter=14336, cache_cap=10,
-                      max_chunk_frames=32, dtype=0, eps=1e-12)               # OV-7B: head_dim 448, not implemented yet
+    ov7 = capi.Config(hidden=3584, heads=8, patches=196, mem_tokens=8, depth=2, inter=14336, cache_cap=10,
+                      max_chunk_frames=32, dtype=0, eps=1e-12)               # OV-7B: head_dim 448, wide-head kernels
+    h3 = capi.vp()
+    assert lib.mavlm_create(ov7, h3) == 0
+    lib.mavlm_destroy(h3)
+    bad = capi.Config(hidden=2048, heads=8, patches=196, mem_tokens=8, depth=2, inter=8192, cache_cap=10,
+                      max_chunk_frames=32, dtype=0, eps=1e-12)               # head_dim 256: no kernel for it
     assert lib.mavlm_create(bad, capi.vp()) == capi.E_SHAPE
     bad2 = capi.Config(hidden=1024, heads=8, patches=196, mem_tokens=0, depth=2, inter=4096, cache_cap=10,
                        max_chunk_frames=32, dtype=0, eps=1e-12)
