@@ -61,3 +61,20 @@ if what in ("gemm", "all"):
       res = torch.randn(M, N, device=dev).bfloat16() if epi == 3 else None
       out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi in (3, 4) else torch.bfloat16)
       timeit(lambda: ops.linear(a, w, b, epi, residual=res, out=out), 2.0 * M * N * K, f"gemm M={M} N={N} K={K} epi={epi}")
+if what in ("wide",):
+    Hh, hd = 8, 448
+    for (Rr, Ss) in ((1568, 6272), (12544, 6272)):
+        q = torch.randn(Rr, Hh * hd, device=dev).bfloat16()
+        kv = torch.randn(Ss, 2 * Hh * hd, device=dev).bfloat16()
+        timeit(lambda: ops.attention(q, kv[:, :Hh * hd], kv[:, Hh * hd:], Hh, want_lse=True, head_dim=hd), 4.0 * Rr * Ss * Hh * hd,
+               f"attn_hd448 R={Rr} S={Ss}")
+        _, lse = ops.attention(q, kv[:, :Hh * hd], kv[:, Hh * hd:], Hh, want_lse=True, head_dim=hd)
+        timeit(lambda: ops.attention_colsum(q, kv[:, :Hh * hd], lse, Hh, head_dim=hd), 2.0 * Rr * Ss * Hh * hd,
+               f"colsum_hd448 R={Rr} S={Ss}")
+    for (M, N, K, epi) in [(6272, 4 * 3584, 3584, 0), (1568, 3584, 3584, 4), (1568, 4 * 3584, 3584, 1), (1568, 3584, 4 * 3584, 4),
+                           (12544, 4 * 3584, 3584, 1)]:
+        a = torch.randn(M, K, device=dev).bfloat16()
+        w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
+        b = torch.randn(N, device=dev)
+        out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == 4 else torch.bfloat16)
+        timeit(lambda: ops.linear(a, w, b, epi, out=out), 2.0 * M * N * K, f"gemm M={M} N={N} K={K} epi={epi}")

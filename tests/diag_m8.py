@@ -1,0 +1,41 @@
+"""Diagnostic: throughput at the reference-default shape (M = 8 memory tokens) - eager / 2-3 videos in flight / hipGraph."""
+import os, sys, time, types
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+bench.MEM_TOKENS = M
+dev = torch.device("cuda", 0)
+model, arch = bench.build_model(dev)
+x = torch.randn(T, 196, 1024, device=dev).bfloat16()
+idx = torch.arange(T) % 600
+mp = torch.randn(10, 1024, device=dev).bfloat16(); fp = torch.randn(9, 1024, device=dev).bfloat16()
+
+def timed(fn, n=30):
+    for _ in range(5): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
+
+with torch.no_grad():
+    t1 = timed(lambda: arch.video_memory_tokens(model, x, idx, mp, fp, model.image_newline))
+    print(f"M={M} T={T} eager, 1 in flight : {t1*1e3:7.3f} ms/video  {T/t1:9.0f} frames/s")
+    for n in (2, 3):
+        pool = arch.MemoryPathPool(model, n)
+        tn = timed(lambda: pool.run([(x, idx)] * n, mp, fp, model.image_newline)) / n
+        print(f"M={M} T={T} eager, {n} in flight : {tn*1e3:7.3f} ms/video  {T/tn:9.0f} frames/s")
+    g = arch.GraphedVideoMemory(model, T, idx)
+    tg = timed(lambda: g(x, mp, fp, model.image_newline))
+    print(f"M={M} T={T} hipGraph, 1 in flight: {tg*1e3:7.3f} ms/video  {T/tg:9.0f} frames/s")
+    gs = [arch.GraphedVideoMemory(model, T, idx) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in gs]
+    def two():
+        for gg, st in zip(gs, streams):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                gg(x, mp, fp, model.image_newline)
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+    t2g = timed(two) / 2
+    print(f"M={M} T={T} hipGraph, 2 in flight: {t2g*1e3:7.3f} ms/video  {T/t2g:9.0f} frames/s")
