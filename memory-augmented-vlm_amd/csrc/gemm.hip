@@ -175,6 +175,9 @@ int g_mavlm_gemm_tile = 0;
 // 128^2 kernel (two workgroups per CU, 4x the tiles) fills the chip better.
 static bool use_256(const mavlm_gemm_args& g) {
   if (!mavlm_gemm256_supported(g)) return false;
+  // the 256^2 kernels store 16 bytes per lane (fp32: always; 16-bit: widened pairs): C rows must be 16-byte aligned
+  const bool f32out = g.epilogue == MAVLM_EPI_RES_F32 || g.epilogue == MAVLM_EPI_F32;
+  if (((uintptr_t)g.C & 15) || (f32out ? (g.ldc & 3) : (g.ldc & 7))) return false;
   if (g_mavlm_gemm_tile == 256 || g_mavlm_gemm_tile == 257) return true;
   if (g_mavlm_gemm_tile == 128) return false;
   const long tiles = (long)((g.M + 255) / 256) * (g.N / 256);

@@ -195,32 +195,40 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   if (!trailing) MAVLM_BAR();          // matches the trailing group's last barrier
 #undef MAVLM_QUADRANT
 
-  // ---- epilogue: lane holds C[m][n..n+3], m = m0 + wm*128 + 16 i + fr, n = n0 + wn*64 + 16 j + 4 fq
+  // ---- epilogue: lane holds C[m][n..n+3], m = m0 + wm*128 + 16 i + fr, n = n0 + wn*64 + 16 j + 4 fq.
+  // 16-bit outputs: column blocks (j, j+1) are exchanged between lane groups (widen_pair) so that every lane stores
+  // 16 contiguous bytes - half the store instructions, 64-byte instead of 32-byte row segments.
+  auto act = [&](float v) {
+    if (EPI == MAVLM_EPI_RELU) return fmaxf(v, 0.f);
+    if (EPI == MAVLM_EPI_GELU) return gelu_erf_fast(v);
+    return v;
+  };
+  f32x4 bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(bias + n0 + wn * 64 + j * 16 + fq * 4);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = m0 + wm * 128 + i * 16 + fr;
-    if (m >= M) continue;
+    if (EPI == MAVLM_EPI_RES_F32 || EPI == MAVLM_EPI_F32) {
+      if (m >= M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fq * 4;
-      const f32x4 bv = *(const f32x4*)(bias + n);
-      float v0 = acc[i][j][0] + bv[0], v1 = acc[i][j][1] + bv[1], v2 = acc[i][j][2] + bv[2],
-            v3 = acc[i][j][3] + bv[3];
-      if (EPI == MAVLM_EPI_RELU) {
-        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-      } else if (EPI == MAVLM_EPI_GELU) {
-        v0 = gelu_erf_fast(v0); v1 = gelu_erf_fast(v1); v2 = gelu_erf_fast(v2); v3 = gelu_erf_fast(v3);
-      }
-      if (EPI == MAVLM_EPI_RES_F32) {
-        const u16x4 rv = *(const u16x4*)(res + (size_t)m * ldr + n);
-        f32x4 o;
-        o[0] = v0 + T::to_f32(rv[0]); o[1] = v1 + T::to_f32(rv[1]);
-        o[2] = v2 + T::to_f32(rv[2]); o[3] = v3 + T::to_f32(rv[3]);
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + fq * 4;
+        f32x4 o = acc[i][j] + bv[j];
+        if (EPI == MAVLM_EPI_RES_F32) {
+          const u16x4 rv = *(const u16x4*)(res + (size_t)m * ldr + n);
+          o[0] += T::to_f32(rv[0]); o[1] += T::to_f32(rv[1]); o[2] += T::to_f32(rv[2]); o[3] += T::to_f32(rv[3]);
+        }
         *(f32x4*)((float*)Cout + (size_t)m * ldc + n) = o;
-      } else if (EPI == MAVLM_EPI_F32) {
-        *(f32x4*)((float*)Cout + (size_t)m * ldc + n) = f32x4{v0, v1, v2, v3};
-      } else {
-        *(u32x2*)((uint16_t*)Cout + (size_t)m * ldc + n) = pack4<T>(v0, v1, v2, v3);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {                     // (all lanes take part in the swaps; the store is masked)
+        const f32x4 x = acc[i][j] + bv[j], y = acc[i][j + 1] + bv[j + 1];
+        const u32x4 w = widen_pair(pack4<T>(act(x[0]), act(x[1]), act(x[2]), act(x[3])),
+                                   pack4<T>(act(y[0]), act(y[1]), act(y[2]), act(y[3])));
+        const int n = n0 + wn * 64 + 16 * (j + (fq & 1)) + 8 * (fq >> 1);
+        if (m < M) *(u32x4*)((uint16_t*)Cout + (size_t)m * ldc + n) = w;
       }
     }
   }

@@ -235,26 +235,32 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
     f32x4 bv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(bl + j * 16);
+    auto act = [&](float v) {
+      if (EPI == MAVLM_EPI_RELU) return fmaxf(v, 0.f);
+      if (EPI == MAVLM_EPI_GELU) return gelu_erf_fast(v);
+      return v;
+    };
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int m = m0c + wm * 128 + i * 16 + fr;
+      if (EPI == MAVLM_EPI_F32) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0c + wn * 64 + j * 16 + fq * 4;
-        float v0 = acc[i][j][0] + bv[j][0], v1 = acc[i][j][1] + bv[j][1], v2 = acc[i][j][2] + bv[j][2],
-              v3 = acc[i][j][3] + bv[j][3];
-        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (EPI == MAVLM_EPI_RELU) {
-          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-        } else if (EPI == MAVLM_EPI_GELU) {
-          v0 = gelu_erf_fast(v0); v1 = gelu_erf_fast(v1); v2 = gelu_erf_fast(v2); v3 = gelu_erf_fast(v3);
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0c + wn * 64 + j * 16 + fq * 4;
+          const f32x4 o = acc[i][j] + bv[j];
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (m < M) *(f32x4*)((float*)Cout + (size_t)m * ldc + n) = o;
         }
-        if (m < M) {
-          if (EPI == MAVLM_EPI_F32) {
-            *(f32x4*)((float*)Cout + (size_t)m * ldc + n) = f32x4{v0, v1, v2, v3};
-          } else {
-            *(u32x2*)((uint16_t*)Cout + (size_t)m * ldc + n) = pack4<T>(v0, v1, v2, v3);
-          }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {                   // 16 contiguous bytes per lane (widen_pair, mavlm_common.h)
+          const f32x4 x = acc[i][j] + bv[j], y = acc[i][j + 1] + bv[j + 1];
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[i][j + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const u32x4 w = widen_pair(pack4<T>(act(x[0]), act(x[1]), act(x[2]), act(x[3])),
+                                     pack4<T>(act(y[0]), act(y[1]), act(y[2]), act(y[3])));
+          const int n = n0c + wn * 64 + 16 * (j + (fq & 1)) + 8 * (fq >> 1);
+          if (m < M) *(u32x4*)((uint16_t*)Cout + (size_t)m * ldc + n) = w;
         }
       }
     }

@@ -127,6 +127,19 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   return x * (x < 0.f ? q : 1.0f - q);
 }
 
+// Widened 16-bit epilogue store (after cdna_hip_programming.md T21, with the 16-lane-row swap):
+// lane group fq = lane>>4 holds 4 consecutive 16-bit outputs (2 dwords) of column block j in `a` and of block j+1 in
+// `b`.  v_permlane16_swap exchanges the ODD rows of its first operand with the EVEN rows of its second, after which
+// {a, b} of every lane are 8 CONSECUTIVE outputs (16 bytes): fq 0 -> block j cols 0-7, fq 1 -> block j+1 cols 0-7,
+// fq 2 -> block j cols 8-15, fq 3 -> block j+1 cols 8-15.  One 16-byte store per lane replaces two 8-byte stores.
+__device__ __forceinline__ u32x4 widen_pair(u32x2 a, u32x2 b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a[0]), "+v"(b[0]));
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a[1]), "+v"(b[1]));
+  u32x4 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1];
+  return r;
+}
+
 // max(a, b, c) in ONE instruction.  fmaxf() on MFMA results makes hipcc emit a canonicalising v_max(x, x) per
 // operand first (3 instructions for what v_max3_f32 does in one); the asm form has no such prologue.
 __device__ __forceinline__ float max3_asm(float a, float b, float c) {
