@@ -120,14 +120,27 @@ def _device_indices(idx_cpu: torch.Tensor, device) -> torch.Tensor:
 
 
 @torch.no_grad()
+def video_token_rows(num_frames: int, mem_tokens: int, patches: int = 196, with_frames: bool = True, chunk: int = 32,
+                     fine_frames: int = 32, cache_cap: int = 10, n_mem_prompt: int = len(MEMORY_PROMPT_IDS),
+                     n_frame_prompt: int = len(FRAME_PROMPT_IDS)) -> int:
+    """Rows of the token block video_memory_tokens() produces for a T-frame video (host arithmetic only), so a caller
+    can allocate the final sequence once and have the block emitted in place."""
+    n = min(-(-num_frames // chunk), cache_cap)
+    rows = n_mem_prompt + n * mem_tokens * patches + 1
+    if with_frames:
+        rows += n_frame_prompt + min(fine_frames, num_frames) * patches + 1
+    return rows
+
+
 def video_memory_tokens(model, image: torch.Tensor, frame_idx_cpu: torch.Tensor, memory_prompt_embeds: torch.Tensor,
                         frame_prompt_embeds: torch.Tensor, image_newline: torch.Tensor, with_frames: bool = True,
-                        chunk: int = 32, fine_frames: int = 32):
+                        chunk: int = 32, fine_frames: int = 32, out: Optional[torch.Tensor] = None):
     """Per-video memory path.  `model` owns the four memory sub-modules; `image` = pooled frame tokens [T,196,D]
     on the GPU; `frame_idx_cpu` = original frame indices [T] (host).  Returns (tokens [rows,D], info dict).
 
     tokens = [mem_prompt ; fused memory (oldest first) ; newline ; frame_prompt ; fine frames ; newline]
-    (llava_arch.py:620-629,729-731); with_frames=False reproduces the frame-dropout branch (:720-725)."""
+    (llava_arch.py:620-629,729-731); with_frames=False reproduces the frame-dropout branch (:720-725).
+    `out`: optional contiguous [rows, D] destination (e.g. a slice of the final inputs_embeds buffer)."""
     if not image.is_cuda:
         raise capi.MavlmError("video_memory_tokens: frame tokens are not on a GPU (no CPU fallback)")
     pe: TemporalPositionalEncoding = model.positional_encoding
@@ -147,7 +160,10 @@ def video_memory_tokens(model, image: torch.Tensor, frame_idx_cpu: torch.Tensor,
     rows = memory_prompt_embeds.shape[0] + n * R + 1
     if with_frames:
         rows += frame_prompt_embeds.shape[0] + n_fine * P + 1
-    out = torch.empty((rows, D), device=image.device, dtype=image.dtype)
+    if out is None:
+        out = torch.empty((rows, D), device=image.device, dtype=image.dtype)
+    elif tuple(out.shape) != (rows, D) or out.dtype != image.dtype or not out.is_contiguous() or not out.is_cuda:
+        raise capi.MavlmError(f"video_memory_tokens: `out` must be a contiguous [{rows},{D}] {image.dtype} GPU tensor")
     mp = memory_prompt_embeds.to(image.dtype).contiguous()
     fp = frame_prompt_embeds.to(image.dtype).contiguous()
     nl = image_newline.to(device=image.device, dtype=image.dtype).contiguous()
@@ -324,9 +340,53 @@ class LlavaMetaForCausalLM:
         else:
             torch.rand(1)   # keep the reference's per-forward RNG draw; the broadcast cannot change the result here
             drop = False
+        # Step after the path.  Fast path = what the reference's memory branch supports anyway
+        # (batch 1, one image placeholder, llava_arch.py:436): the final [1, L, D] buffer is allocated once and the
+        # HIP path writes the video block straight into it; everything else goes through the general splice.
+        direct = self._direct_emit(model, pooled, idx_cpu, mem_prompt, frame_prompt, not drop, input_ids, position_ids,
+                                   attention_mask, past_key_values, labels)
+        if direct is not None:
+            return direct
         tokens, _ = video_memory_tokens(model, pooled, idx_cpu, mem_prompt, frame_prompt, model.image_newline,
                                         with_frames=not drop)
         return splice_into_text(self, model, [tokens], input_ids, position_ids, attention_mask, past_key_values, labels)
+
+    def _direct_emit(self, model, pooled, idx_cpu, mem_prompt, frame_prompt, with_frames, input_ids, position_ids,
+                     attention_mask, past_key_values, labels):
+        if input_ids.shape[0] != 1:
+            return None
+        mask = torch.ones_like(input_ids, dtype=torch.bool) if attention_mask is None else attention_mask.bool()
+        ids = input_ids[0][mask[0]]
+        pos = torch.where(ids == IMAGE_TOKEN_INDEX)[0].tolist()
+        if len(pos) != 1:
+            return None
+        p = pos[0]
+        rm = model.recurrent_memory_transformer
+        rows = video_token_rows(pooled.shape[0], rm.num_memory_tokens, rm.patch_size, with_frames,
+                                cache_cap=getattr(rm.config, "cache_cap", 10))
+        n_text = ids.shape[0] - 1
+        total = n_text + rows
+        max_tok = getattr(self.config, "tokenizer_model_max_length", None)
+        if max_tok is not None and total > max_tok:
+            return None                                    # truncation cuts into the block: general path
+        text = model.embed_tokens(torch.cat([ids[:p], ids[p + 1:]]))
+        emb = torch.empty((1, total, pooled.shape[-1]), device=pooled.device, dtype=pooled.dtype)
+        emb[0, :p] = text[:p].to(emb.dtype)
+        emb[0, p + rows:] = text[p:].to(emb.dtype)
+        video_memory_tokens(model, pooled, idx_cpu, mem_prompt, frame_prompt, model.image_newline, with_frames,
+                            out=emb[0, p:p + rows])
+        if text.dtype != emb.dtype:
+            emb = emb.to(text.dtype)
+        out_labels = None
+        if labels is not None:
+            lab = labels[0][mask[0]]
+            out_labels = torch.cat([lab[:p], torch.full((rows,), IGNORE_INDEX, device=lab.device, dtype=lab.dtype),
+                                    lab[p + 1:]])[None]
+        out_mask = None if attention_mask is None else torch.ones((1, total), device=attention_mask.device,
+                                                                  dtype=attention_mask.dtype)
+        out_pos = None if position_ids is None else torch.arange(total, device=position_ids.device,
+                                                                 dtype=position_ids.dtype)[None]
+        return None, out_pos, out_mask, past_key_values, emb, out_labels
 
 
 def splice_into_text(lm, model, image_features: List[torch.Tensor], input_ids, position_ids, attention_mask,

@@ -331,10 +331,11 @@ class TransformerProjector(nn.Module):
             e.version = v
         return e
 
-    def _apply(self, fn, *a, **k):   # .to() / .cuda() / .half(): parameters move, packed views are stale
+    def _apply(self, fn, *a, **k):   # .to() / .cuda() / .half(): parameters move, packed pointers would dangle
         out = super()._apply(fn, *a, **k)
-        if getattr(self, "_engine", None) is not None and not self._engine.steps:
-            self._engine = None
+        if getattr(self, "_engine", None) is not None:
+            self._engine = None           # also ends a video in progress: its FIFO lived in the old engine
+            self._memory_cache = []
         return out
 
     def spawn_replica(self) -> "TransformerProjector":

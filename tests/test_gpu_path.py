@@ -330,6 +330,15 @@ def test_prepare_inputs_end_to_end_vs_oracle():
                                 O.bf16_round(emb), max_len=32768)
     assert tuple(embeds.shape) == e.shape
     assert O.rel_l2(to_np(embeds)[0, 2:-2], e[0, 2:-2]) < chain_tol(O.rel_l2(toks64, toks))
+    # the in-place emit used above (batch 1, one placeholder) equals the general splice path bit for bit
+    with torch.no_grad():
+        tokens2, _ = arch.video_memory_tokens(model, lm.get_2dPool(table[torch.from_numpy(idx).cuda()]),
+                                              torch.from_numpy(idx), model.embed_tokens(torch.tensor(O.MEM_PROMPT_IDS, device="cuda")),
+                                              model.embed_tokens(torch.tensor(O.FRAME_PROMPT_IDS, device="cuda")),
+                                              model.image_newline)
+        gen = arch.splice_into_text(lm, model, [tokens2], ids, None, am, None, labels)
+    assert torch.equal(gen[4], embeds) and torch.equal(gen[5], labs) and torch.equal(gen[2], mask)
+    assert arch.video_token_rows(64, 8) == tokens2.shape[0]
     np.testing.assert_array_equal(labs.cpu().numpy(), lab)
     assert bool(mask.all())
 
