@@ -153,6 +153,34 @@ int mavlm_row_add(const void* x, const int64_t* src, const void* table, const in
 int mavlm_pool_bilinear(const void* x, void* out, const void* pe_table, const int64_t* idx, int32_t F, int32_t side,
                         int32_t stride, int32_t D, int32_t dtype, void* stream);
 
+/* ---- backward pass of the path.  The reference differentiates the same modules with torch
+ * autograd (training scripts: train.py:1708-1724); these are the device ops an autograd.Function calls.
+ *
+ * Attention backward, head_dim 128 (MemoryController.py:48-54): recomputes P = exp2(S*c - lse2) per tile.
+ * O = forward output, dO its gradient, lse2 [H,R] from mavlm_attention, delta [H,R] fp32 scratch.
+ * Any of dQ / dK / dV may be null (not computed: the frame features carry no gradient, llava_arch.py:302). */
+int mavlm_attention_bwd(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, const void* O,
+                        int32_t ldo, const void* dO, int32_t lddo, const float* lse2, float* delta, void* dQ,
+                        int32_t lddq, void* dK, int32_t lddk, void* dV, int32_t lddv, int32_t R, int32_t S, int32_t H,
+                        float scale, int32_t dtype, void* stream);
+/* C[M,N] 16-bit = A[M,K] . W[N,K]^T, contraction split over `splits` workgroup planes; ws = splits*M*N fp32;
+ * zero_bias = N fp32 zeros.  For dW = dY^T X, whose contraction runs over all rows of the activations. */
+int mavlm_linear_splitk(const void* A, int32_t lda, const void* W, int32_t ldw, void* C, int32_t M, int32_t N, int32_t K,
+                        int32_t splits, float* ws, const float* zero_bias, int32_t dtype, void* stream);
+/* LayerNorm(x + res) backward: dz (16-bit [rows,D]) is the gradient of BOTH x and res; dgamma/dbeta fp32 [D];
+ * ws = mavlm_layernorm_bwd_ws_floats(D) fp32 scratch.  MemoryController.py:24,26-28 */
+int64_t mavlm_layernorm_bwd_ws_floats(int32_t D);
+int mavlm_layernorm_bwd(const void* dy, const float* x, const void* res, int32_t ldr, const float* gamma, void* dz,
+                        float* dgamma, float* dbeta, float* ws, int32_t rows, int32_t D, float eps, int32_t dtype,
+                        void* stream);
+/* out[cols, ldo] = in[rows, cols]^T for 16-bit elements; columns rows..roundup(rows,64)-1 of out are zero-filled. */
+int mavlm_transpose(const void* in, int32_t ldi, int32_t rows, int32_t cols, void* out, int32_t ldo, void* stream);
+/* out[r] fp32 = sum_c in[r, c] (bias gradient from dY^T). */
+int mavlm_rowsum(const void* in, int32_t ld, int32_t rows, int32_t cols, float* out, int32_t dtype, void* stream);
+/* elementwise over n (multiple of 8) 16-bit values: kind 0 out = gelu(x); 1 out = dy*gelu'(x) (x = pre-activation);
+ * 2 out = x > 0 ? dy : 0 (x = ReLU output).  llava_arch.py:134; MemoryController.py:64 */
+int mavlm_act(int32_t kind, const void* x, const void* dy, void* out, int64_t n, int32_t dtype, void* stream);
+
 /* tuning hook: force the GEMM kernel (128 = 128^2 tile, 256 = 256^2 non-persistent, 257 = 256^2 persistent;
  * 0 = automatic choice by grid size and epilogue).  Results are identical
  * up to fp32 summation order. */

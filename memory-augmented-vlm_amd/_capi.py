@@ -65,6 +65,14 @@ SIGNATURES = {
     "mavlm_layernorm": (C.c_int, [vp, vp, i32, vp, vp, vp, i32, i32, C.c_float, i32, vp]),
     "mavlm_row_add": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mavlm_pool_bilinear": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mavlm_attention_bwd": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, i32,
+                                      i32, i32, i32, C.c_float, i32, vp]),
+    "mavlm_linear_splitk": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp]),
+    "mavlm_layernorm_bwd_ws_floats": (C.c_int64, [i32]),
+    "mavlm_layernorm_bwd": (C.c_int, [vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, C.c_float, i32, vp]),
+    "mavlm_transpose": (C.c_int, [vp, i32, i32, i32, vp, i32, vp]),
+    "mavlm_rowsum": (C.c_int, [vp, i32, i32, i32, vp, i32, vp]),
+    "mavlm_act": (C.c_int, [i32, vp, vp, vp, C.c_int64, i32, vp]),
     "mavlm_set_gemm_tile": (C.c_int, [i32]),
     "mavlm_set_attention_impl": (C.c_int, [i32]),
     "mavlm_prof_enable": (C.c_int, [i32]),

@@ -151,3 +151,116 @@ def pool_bilinear(x, side, stride=2, pe_table=None, idx=None, out=None):
                                               idx.data_ptr() if idx is not None else 0, F, side, stride, D,
                                               dtype_code(x.dtype), stream_ptr()), "mavlm_pool_bilinear")
     return out
+
+
+# ---- backward-pass ops -----------------------------------------------------------------------
+def attention_bwd(q, k, v, o, do, lse2, heads, need_dq=True, need_dk=True, need_dv=True):
+    """Gradients of `attention` (head_dim 128): returns (dq | None, dk | None, dv | None), each [rows, H*128]."""
+    _need_gpu(q, k, v, o, do, lse2)
+    R, _, ldq = _rows(q)
+    S, _, ldk = _rows(k)
+    _, _, ldv = _rows(v)
+    _, _, ldo = _rows(o)
+    _, _, lddo = _rows(do)
+    W = heads * 128
+    if o.shape != (R, W) or do.shape != (R, W) or lse2.shape != (heads, R) or lse2.dtype != torch.float32 \
+            or not lse2.is_contiguous() or v.shape[0] != S or do.dtype != q.dtype:
+        raise capi.MavlmError("attention_bwd: operand mismatch")
+    dq = torch.empty((R, W), device=q.device, dtype=q.dtype) if need_dq else None
+    dk = torch.empty((S, W), device=q.device, dtype=q.dtype) if need_dk else None
+    dv = torch.empty((S, W), device=q.device, dtype=q.dtype) if need_dv else None
+    delta = torch.empty((heads, R), device=q.device, dtype=torch.float32)
+    p = lambda t: t.data_ptr() if t is not None else 0
+    capi.check(capi.lib().mavlm_attention_bwd(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, o.data_ptr(), ldo,
+                                              do.data_ptr(), lddo, lse2.data_ptr(), delta.data_ptr(), p(dq), W, p(dk), W,
+                                              p(dv), W, R, S, heads, 1.0 / math.sqrt(128.0), dtype_code(q.dtype),
+                                              stream_ptr()), "mavlm_attention_bwd")
+    return dq, dk, dv
+
+
+def transpose(x, pad_to=64):
+    """[rows, cols] 16-bit -> [cols, roundup(rows, 64)] with a zero-filled pad (the K-contiguous operand form of
+    the contract-over-rows products)."""
+    _need_gpu(x)
+    rows, cols, ld = _rows(x)
+    rp = -(-rows // pad_to) * pad_to
+    out = torch.empty((cols, rp), device=x.device, dtype=x.dtype)
+    capi.check(capi.lib().mavlm_transpose(x.data_ptr(), ld, rows, cols, out.data_ptr(), rp, stream_ptr()),
+               "mavlm_transpose")
+    return out
+
+
+def rowsum(x, cols=None):
+    """fp32 row sums of a 16-bit [rows, >=cols] tensor."""
+    _need_gpu(x)
+    rows, c, ld = _rows(x)
+    out = torch.empty((rows,), device=x.device, dtype=torch.float32)
+    capi.check(capi.lib().mavlm_rowsum(x.data_ptr(), ld, rows, cols if cols is not None else c, out.data_ptr(),
+                                       dtype_code(x.dtype), stream_ptr()), "mavlm_rowsum")
+    return out
+
+
+_ZERO_BIAS = {}
+
+
+def zero_bias(n, device):
+    z = _ZERO_BIAS.get((n, device))
+    if z is None:
+        z = _ZERO_BIAS[(n, device)] = torch.zeros(n, device=device, dtype=torch.float32)
+    return z
+
+
+def matmul_nt(a, b):
+    """a [M,K] . b [N,K]^T -> [M,N] 16-bit (no bias)."""
+    return linear(a, b, zero_bias(b.shape[0], a.device))
+
+
+def matmul_nt_splitk(a, b, splits=None):
+    """As matmul_nt for long contractions with few output tiles (dW = dY^T X): split-K with fp32 partials."""
+    _need_gpu(a, b)
+    M, K, lda = _rows(a)
+    N, K2, ldb = _rows(b)
+    if K2 != K or a.dtype != b.dtype:
+        raise capi.MavlmError("matmul_nt_splitk: operand mismatch")
+    tiles = -(-M // 128) * (N // 128)
+    if splits is None:
+        splits = max(1, min(K // 64, -(-512 // tiles)))
+    out = torch.empty((M, N), device=a.device, dtype=a.dtype)
+    ws = torch.empty((splits, M, N), device=a.device, dtype=torch.float32)
+    capi.check(capi.lib().mavlm_linear_splitk(a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(), M, N, K, splits,
+                                              ws.data_ptr(), zero_bias(N, a.device).data_ptr(), dtype_code(a.dtype),
+                                              stream_ptr()), "mavlm_linear_splitk")
+    return out
+
+
+def layernorm_bwd(dy, x_f32, residual, gamma_f32, eps):
+    """Backward of `layernorm`: returns (dz [rows,D] 16-bit = grad of x and of residual, dgamma fp32, dbeta fp32)."""
+    _need_gpu(dy, x_f32, residual, gamma_f32)
+    rows, D = x_f32.shape
+    if dy.shape != x_f32.shape or not dy.is_contiguous() or not x_f32.is_contiguous() or x_f32.dtype != torch.float32:
+        raise capi.MavlmError("layernorm_bwd: operand mismatch")
+    dz = torch.empty((rows, D), device=dy.device, dtype=dy.dtype)
+    dg = torch.empty((D,), device=dy.device, dtype=torch.float32)
+    db = torch.empty((D,), device=dy.device, dtype=torch.float32)
+    ws = torch.empty((capi.lib().mavlm_layernorm_bwd_ws_floats(D),), device=dy.device, dtype=torch.float32)
+    rp, ldr = 0, 0
+    if residual is not None:
+        _, _, ldr = _rows(residual)
+        rp = residual.data_ptr()
+    capi.check(capi.lib().mavlm_layernorm_bwd(dy.data_ptr(), x_f32.data_ptr(), rp, ldr, gamma_f32.data_ptr(), dz.data_ptr(),
+                                              dg.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, D, float(eps),
+                                              dtype_code(dy.dtype), stream_ptr()), "mavlm_layernorm_bwd")
+    return dz, dg, db
+
+
+ACT_GELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2
+
+
+def act(kind, x, dy=None):
+    _need_gpu(x, dy)
+    if not x.is_contiguous() or (dy is not None and (not dy.is_contiguous() or dy.shape != x.shape)):
+        raise capi.MavlmError("act: contiguous operands of one shape expected")
+    out = torch.empty_like(x)
+    capi.check(capi.lib().mavlm_act(kind, x.data_ptr(), dy.data_ptr() if dy is not None else 0, out.data_ptr(), x.numel(),
+                                    dtype_code(x.dtype), stream_ptr()), "mavlm_act")
+    return out

@@ -1,0 +1,288 @@
+// Row-wise / layout kernels of the backward pass of the memory path.  All HBM-bound.
+//
+//   layernorm_bwd_kernel   backward of Residual's LayerNorm(x + res) (MemoryController.py:24,28): recomputes the
+//                          normalised row from the saved fp32 GEMM output and the residual, writes dz (the gradient
+//                          of BOTH the dense output and the residual) and per-wave partial sums of dgamma / dbeta
+//   colsum_partials_kernel [P][cols] fp32 partials -> [cols] (deterministic second stage)
+//   transpose_kernel       16-bit [rows, cols] -> [cols, rows_pad] (zero-filled pad): turns the "contract over rows"
+//                          products of the backward (dW = dY^T X) into the K-contiguous form the MFMA GEMMs read
+//   rowsum_kernel          bias gradient: row sums of dY^T
+//   act_kernel             GELU forward on a stored pre-activation, GELU / ReLU backward
+//   splitk_reduce_kernel   fp32 split-K partials -> 16-bit
+#include "mavlm_common.h"
+#include "mavlm_kernels.h"
+
+namespace {
+
+constexpr int LNB_PART = 1024;   // partial rows of dgamma/dbeta = 256 workgroups x 4 waves
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __restrict__ dy,
+                                                            const float* __restrict__ x,
+                                                            const uint16_t* __restrict__ res, int ldr,
+                                                            const float* __restrict__ gamma, uint16_t* __restrict__ dz,
+                                                            float* __restrict__ part, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  const int nvec = D >> 2;
+  f32x4 g[NV], ag[NV], ab[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = i * 64 + lane;
+    g[i] = j < nvec ? ((const f32x4*)gamma)[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float invD = 1.0f / (float)D;
+  for (int row = wv; row < rows; row += nw) {
+    f32x4 v[NV], d[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int j = i * 64 + lane;
+      if (j < nvec) {
+        v[i] = ((const f32x4*)(x + (size_t)row * D))[j];
+        if (res != nullptr) {
+          const u16x4 rv = *(const u16x4*)(res + (size_t)row * ldr + 4 * j);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[i][e] += T::to_f32(rv[e]);
+        }
+        const u16x4 dv = *(const u16x4*)(dy + (size_t)row * D + 4 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[i][e] = T::to_f32(dv[e]);
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      } else {
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float mean = wave_sum(s) * invD;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int j = i * 64 + lane;
+      if (j < nvec) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[i][e] -= mean;
+          ss += v[i][e] * v[i][e];
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) * invD + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = v[i][e] * rstd;
+        const float gd = d[i][e] * g[i][e];
+        ag[i][e] += d[i][e] * xh;
+        ab[i][e] += d[i][e];
+        v[i][e] = xh;
+        d[i][e] = gd;
+        s1 += gd;
+        s2 += gd * xh;
+      }
+    }
+    const float m1 = wave_sum(s1) * invD, m2 = wave_sum(s2) * invD;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int j = i * 64 + lane;
+      if (j < nvec)
+        *(u32x2*)(dz + (size_t)row * D + 4 * j) =
+            pack4<T>(rstd * (d[i][0] - m1 - v[i][0] * m2), rstd * (d[i][1] - m1 - v[i][1] * m2),
+                     rstd * (d[i][2] - m1 - v[i][2] * m2), rstd * (d[i][3] - m1 - v[i][3] * m2));
+    }
+  }
+  float* pg = part + (size_t)wv * 2 * D;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = i * 64 + lane;
+    if (j < nvec) {
+      ((f32x4*)pg)[j] = ag[i];
+      ((f32x4*)(pg + D))[j] = ab[i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, int nparts, int cols,
+                                                              float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * cols + c];
+  out[c] = s;
+}
+
+// 64x64 tile through LDS; 8-byte global accesses on both sides.
+__global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restrict__ in, int ldi, int rows, int cols,
+                                                        uint16_t* __restrict__ out, int ldo, int rows_pad) {
+  __shared__ uint16_t tile[64][68];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int v = tid + 256 * k;
+    const int rr = v >> 4, cv = v & 15;
+    u16x4 d = u16x4{0, 0, 0, 0};
+    if (r0 + rr < rows && c0 + 4 * cv < cols) d = *(const u16x4*)(in + (size_t)(r0 + rr) * ldi + c0 + 4 * cv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[4 * cv + j][rr] = d[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int v = tid + 256 * k;
+    const int cc = v >> 4, rv = v & 15;
+    if (c0 + cc < cols && r0 + 4 * rv < rows_pad)
+      *(u16x4*)(out + (size_t)(c0 + cc) * ldo + r0 + 4 * rv) = *(const u16x4*)&tile[cc][4 * rv];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rowsum_kernel(const uint16_t* __restrict__ in, int ld, int rows, int cols,
+                                                     float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const uint16_t* p = in + (size_t)row * ld;
+  float s = 0.f;
+  for (int j = lane * 8; j < cols; j += 512) {
+    if (j + 8 <= cols) {
+      const u16x8 v = *(const u16x8*)(p + j);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += T::to_f32(v[e]);
+    } else {
+      for (int e = j; e < cols; ++e) s += T::to_f32(p[e]);
+    }
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+
+// kind 0: out = gelu(x)   1: out = dy * gelu'(x)   2: out = x > 0 ? dy : 0   (x = the ReLU OUTPUT)
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void act_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                  uint16_t* __restrict__ out, size_t nvec) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    const u16x8 a = ((const u16x8*)x)[i];
+    u16x8 b = a, o;
+    if (KIND != 0) b = ((const u16x8*)dy)[i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xv = T::to_f32(a[e]);
+      float r;
+      if (KIND == 0) {
+        r = gelu_erf_fast(xv);
+      } else if (KIND == 1) {
+        const float cdf = 0.5f * (1.0f + erff(xv * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * __expf(-0.5f * xv * xv);
+        r = T::to_f32(b[e]) * (cdf + xv * pdf);
+      } else {
+        r = xv > 0.f ? T::to_f32(b[e]) : 0.f;
+      }
+      o[e] = T::from_f32(r);
+    }
+    ((u16x8*)out)[i] = o;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, size_t n4,
+                                                            uint16_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    f32x4 s = ((const f32x4*)part)[i];
+    for (int k = 1; k < splits; ++k) {
+      const f32x4 v = ((const f32x4*)part)[(size_t)k * n4 + i];
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    ((u32x2*)out)[i] = pack4<T>(s[0], s[1], s[2], s[3]);
+  }
+}
+
+template <typename T>
+hipError_t launch_ln_bwd(const uint16_t* dy, const float* x, const uint16_t* res, int ldr, const float* gamma,
+                         uint16_t* dz, float* part, int rows, int D, float eps, hipStream_t s) {
+  const dim3 grid(LNB_PART / 4), block(256);
+  const int nv = (D / 4 + 63) / 64;
+#define LNB(NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), grid, block, 0, s, dy, x, res, ldr, gamma, dz, part, rows, D, eps)
+  if (nv <= 1) LNB(1);
+  else if (nv <= 2) LNB(2);
+  else if (nv <= 4) LNB(4);
+  else if (nv <= 8) LNB(8);
+  else if (nv <= 16) LNB(16);
+  else return hipErrorInvalidValue;
+#undef LNB
+  return hipGetLastError();
+}
+
+}  // namespace
+
+size_t mavlm_layernorm_bwd_partial_floats(int D) { return (size_t)(LNB_PART + 1) * 2 * D; }
+
+hipError_t mavlm_launch_layernorm_bwd(const void* dy, const float* x, const void* res, int ldr, const float* gamma,
+                                      void* dz, float* dgamma, float* dbeta, float* part, int rows, int D, float eps,
+                                      int dtype, hipStream_t s) {
+  if (rows <= 0 || (D & 3) || D > 4096) return hipErrorInvalidValue;
+  mavlm_prof_scope prof(MAVLM_K_LN, 0.0, 12.0 * rows * (double)D, s);
+  hipError_t e = dtype == MAVLM_F16
+                     ? launch_ln_bwd<F16>((const uint16_t*)dy, x, (const uint16_t*)res, ldr, gamma, (uint16_t*)dz, part, rows, D, eps, s)
+                     : launch_ln_bwd<BF16>((const uint16_t*)dy, x, (const uint16_t*)res, ldr, gamma, (uint16_t*)dz, part, rows, D, eps, s);
+  if (e != hipSuccess) return e;
+  // partial rows are [wave][2][D]: view as [LNB_PART][2D] and sum down the columns; dgamma = cols [0,D), dbeta = [D,2D)
+  // of a 2D-wide result; write through a small two-step so that dgamma / dbeta may be separate allocations
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, s, part, LNB_PART, 2 * D,
+                     part + (size_t)LNB_PART * 2 * D);
+  e = hipMemcpyAsync(dgamma, part + (size_t)LNB_PART * 2 * D, sizeof(float) * D, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return e;
+  return hipMemcpyAsync(dbeta, part + (size_t)LNB_PART * 2 * D + D, sizeof(float) * D, hipMemcpyDeviceToDevice, s);
+}
+
+hipError_t mavlm_launch_transpose(const void* in, int ldi, int rows, int cols, void* out, int ldo, hipStream_t s) {
+  if (rows <= 0 || cols <= 0 || (cols & 3) || (ldi & 3) || (ldo & 3)) return hipErrorInvalidValue;
+  const int rows_pad = (rows + 63) / 64 * 64;
+  if (ldo < rows_pad) return hipErrorInvalidValue;
+  mavlm_prof_scope prof(MAVLM_K_MISC, 0.0, 4.0 * rows * (double)cols, s);
+  hipLaunchKernelGGL(transpose_kernel, dim3(rows_pad / 64, (cols + 63) / 64), dim3(256), 0, s, (const uint16_t*)in, ldi,
+                     rows, cols, (uint16_t*)out, ldo, rows_pad);
+  return hipGetLastError();
+}
+
+hipError_t mavlm_launch_rowsum(const void* in, int ld, int rows, int cols, float* out, int dtype, hipStream_t s) {
+  if (rows <= 0 || cols <= 0 || (ld & 7)) return hipErrorInvalidValue;
+  mavlm_prof_scope prof(MAVLM_K_MISC, 0.0, 2.0 * rows * (double)cols, s);
+  if (dtype == MAVLM_F16)
+    hipLaunchKernelGGL(rowsum_kernel<F16>, dim3((rows + 3) / 4), dim3(256), 0, s, (const uint16_t*)in, ld, rows, cols, out);
+  else
+    hipLaunchKernelGGL(rowsum_kernel<BF16>, dim3((rows + 3) / 4), dim3(256), 0, s, (const uint16_t*)in, ld, rows, cols, out);
+  return hipGetLastError();
+}
+
+hipError_t mavlm_launch_act(int kind, const void* x, const void* dy, void* out, size_t n, int dtype, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  if ((n & 7) || kind < 0 || kind > 2 || (kind != 0 && dy == nullptr)) return hipErrorInvalidValue;
+  const size_t nvec = n >> 3;
+  const int blocks = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
+  mavlm_prof_scope prof(MAVLM_K_MISC, 0.0, (kind == 0 ? 4.0 : 6.0) * n, s);
+#define ACT(TT, KK) hipLaunchKernelGGL((act_kernel<TT, KK>), dim3(blocks), dim3(256), 0, s, (const uint16_t*)x, (const uint16_t*)dy, (uint16_t*)out, nvec)
+  if (dtype == MAVLM_F16) {
+    if (kind == 0) ACT(F16, 0); else if (kind == 1) ACT(F16, 1); else ACT(F16, 2);
+  } else {
+    if (kind == 0) ACT(BF16, 0); else if (kind == 1) ACT(BF16, 1); else ACT(BF16, 2);
+  }
+#undef ACT
+  return hipGetLastError();
+}
+
+hipError_t mavlm_launch_splitk_reduce(const float* part, int splits, size_t n, void* out, int dtype, hipStream_t s) {
+  if (n & 3) return hipErrorInvalidValue;
+  const size_t n4 = n >> 2;
+  const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  if (dtype == MAVLM_F16)
+    hipLaunchKernelGGL(splitk_reduce_kernel<F16>, dim3(blocks), dim3(256), 0, s, part, splits, n4, (uint16_t*)out);
+  else
+    hipLaunchKernelGGL(splitk_reduce_kernel<BF16>, dim3(blocks), dim3(256), 0, s, part, splits, n4, (uint16_t*)out);
+  return hipGetLastError();
+}

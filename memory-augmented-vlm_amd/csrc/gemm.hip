@@ -29,8 +29,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const uint16_t* __restr
                                                          const uint16_t* __restrict__ W, int ldw,
                                                          const float* __restrict__ bias,
                                                          const uint16_t* __restrict__ res, int ldr,
-                                                         void* __restrict__ Cout, int ldc, int M, int N, int K) {
+                                                         void* __restrict__ Cout, int ldc, int M, int N, int K,
+                                                         int ksplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // split-K (backward dW = dY^T X, contraction over tens of thousands of rows with only (N/128)^2 output tiles):
+  // blockIdx.y owns K range [y*ksplit, (y+1)*ksplit) and its own fp32 partial plane (EPI_F32 only)
+  if (ksplit > 0) {
+    const int kz = blockIdx.y * ksplit;
+    A += kz;
+    W += kz;
+    K = (K - kz < ksplit) ? K - kz : ksplit;
+    Cout = (float*)Cout + (size_t)blockIdx.y * M * ldc;
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -151,7 +161,22 @@ hipError_t launch(const mavlm_gemm_args& g, hipStream_t s) {
   }
   const int ntm = (g.M + BM - 1) / BM, ntn = g.N / BN;
   hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(256), GEMM_LDS, s, (const uint16_t*)g.A, g.lda, (const uint16_t*)g.W,
-                     g.ldw, g.bias, (const uint16_t*)g.res, g.ldr, g.C, g.ldc, g.M, g.N, g.K);
+                     g.ldw, g.bias, (const uint16_t*)g.res, g.ldr, g.C, g.ldc, g.M, g.N, g.K, 0);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_splitk(const mavlm_gemm_args& g, int splits, int ksplit, hipStream_t s) {
+  auto kern = gemm_tn_kernel<T, MAVLM_EPI_F32>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int ntm = (g.M + BM - 1) / BM, ntn = g.N / BN;
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn, splits), dim3(256), GEMM_LDS, s, (const uint16_t*)g.A, g.lda,
+                     (const uint16_t*)g.W, g.ldw, g.bias, (const uint16_t*)nullptr, 0, g.C, g.ldc, g.M, g.N, g.K, ksplit);
   return hipGetLastError();
 }
 
@@ -170,6 +195,30 @@ hipError_t launch_epi(const mavlm_gemm_args& g, hipStream_t s) {
 }  // namespace
 
 int g_mavlm_gemm_tile = 0;
+
+// C16[M,N] = A[M,K] . W[N,K]^T with the contraction split over `splits` workgroup planes (fp32 partials in `ws`,
+// [splits][M][N]) and a deterministic reduction.  `zero_bias`: N fp32 zeros (the kernel's epilogue adds a bias).
+hipError_t mavlm_launch_gemm_splitk(const mavlm_gemm_args& g0, int splits, float* ws, const float* zero_bias, int dtype,
+                                    hipStream_t s) {
+  if (g0.M <= 0) return hipSuccess;
+  if (g0.N % BN != 0 || g0.K % BK != 0 || g0.K <= 0 || (g0.lda & 7) || (g0.ldw & 7) || (g0.ldc & 3) || splits < 1 ||
+      g0.ldc != g0.N)
+    return hipErrorInvalidValue;
+  const int nk = g0.K / BK;
+  if (splits > nk) splits = nk;
+  const int ksplit = ((nk + splits - 1) / splits) * BK;
+  splits = (g0.K + ksplit - 1) / ksplit;
+  mavlm_prof_scope prof(MAVLM_K_GEMM, 2.0 * g0.M * (double)g0.N * g0.K,
+                        2.0 * ((double)g0.M * g0.K + (double)g0.N * g0.K) + (4.0 * splits + 2.0) * g0.M * (double)g0.N, s);
+  mavlm_gemm_args g = g0;
+  void* out16 = g0.C;
+  g.C = ws;
+  g.bias = zero_bias;
+  g.epilogue = MAVLM_EPI_F32;
+  hipError_t e = dtype == MAVLM_F16 ? launch_splitk<F16>(g, splits, ksplit, s) : launch_splitk<BF16>(g, splits, ksplit, s);
+  if (e != hipSuccess) return e;
+  return mavlm_launch_splitk_reduce(ws, splits, (size_t)g0.M * g0.N, out16, dtype, s);
+}
 
 // Tile choice: the 256^2 kernel runs one workgroup per CU, so it wants >= ~1 full wave of 256 tiles; below that the
 // 128^2 kernel (two workgroups per CU, 4x the tiles) fills the chip better.

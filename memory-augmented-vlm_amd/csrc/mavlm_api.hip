@@ -362,4 +362,67 @@ int mavlm_row_add(const void* xin, const int64_t* src, const void* table, const 
   return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
 }
 
+// ---- backward pass ------------------------------------------------------------------------
+int mavlm_attention_bwd(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, const void* O,
+                        int32_t ldo, const void* dO, int32_t lddo, const float* lse2, float* delta, void* dQ,
+                        int32_t lddq, void* dK, int32_t lddk, void* dV, int32_t lddv, int32_t R, int32_t S, int32_t H,
+                        float scale, int32_t dtype, void* stream) {
+  if (!Q || !K || !V || !O || !dO || !lse2 || !delta || R <= 0 || S <= 0 || H <= 0) return MAVLM_E_ARG;
+  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7) || (lddo & 7) || (lddq & 3) || (lddk & 3) || (lddv & 3))
+    return MAVLM_E_ARG;
+  const int w = H * 128;
+  if (ldq < w || ldk < w || ldv < w || ldo < w || lddo < w || (dQ && lddq < w) || (dK && lddk < w) || (dV && lddv < w))
+    return MAVLM_E_ARG;
+  if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)dO) & 15) return MAVLM_E_ARG;
+  mavlm_attn_bwd_args a;
+  a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.dO = dO; a.lddo = lddo;
+  a.lse2 = lse2; a.delta = delta; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
+  a.R = R; a.S = S; a.H = H; a.scale = scale;
+  const double units = (dQ ? 3.0 : 0.0) + (dK ? 3.0 : 0.0) + (dV ? 2.0 : 0.0);
+  mavlm_prof_scope prof(MAVLM_K_ATTN, units * 2.0 * R * (double)S * H * 128.0, 2.0 * 128.0 * H * (4.0 * R + 4.0 * S),
+                        (hipStream_t)stream);
+  hipError_t e = mavlm_launch_attention_bwd(a, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int mavlm_linear_splitk(const void* A, int32_t lda, const void* W, int32_t ldw, void* C, int32_t M, int32_t N, int32_t K,
+                        int32_t splits, float* ws, const float* zero_bias, int32_t dtype, void* stream) {
+  if (!A || !W || !C || !ws || !zero_bias || M < 0 || splits < 1) return MAVLM_E_ARG;
+  if (N % 128 || K % 64 || N <= 0 || K <= 0) return MAVLM_E_SHAPE;
+  mavlm_gemm_args g;
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = zero_bias; g.res = nullptr; g.ldr = 0; g.C = C; g.ldc = N;
+  g.M = M; g.N = N; g.K = K; g.epilogue = MAVLM_EPI_F32;
+  hipError_t e = mavlm_launch_gemm_splitk(g, splits, ws, zero_bias, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int64_t mavlm_layernorm_bwd_ws_floats(int32_t D) { return (int64_t)mavlm_layernorm_bwd_partial_floats(D); }
+
+int mavlm_layernorm_bwd(const void* dy, const float* xin, const void* res, int32_t ldr, const float* gamma, void* dz,
+                        float* dgamma, float* dbeta, float* ws, int32_t rows, int32_t D, float eps, int32_t dtype,
+                        void* stream) {
+  if (!dy || !xin || !gamma || !dz || !dgamma || !dbeta || !ws) return MAVLM_E_ARG;
+  hipError_t e = mavlm_launch_layernorm_bwd(dy, xin, res, ldr, gamma, dz, dgamma, dbeta, ws, rows, D, eps, dtype,
+                                            (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int mavlm_transpose(const void* in, int32_t ldi, int32_t rows, int32_t cols, void* out, int32_t ldo, void* stream) {
+  if (!in || !out) return MAVLM_E_ARG;
+  hipError_t e = mavlm_launch_transpose(in, ldi, rows, cols, out, ldo, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int mavlm_rowsum(const void* in, int32_t ld, int32_t rows, int32_t cols, float* out, int32_t dtype, void* stream) {
+  if (!in || !out) return MAVLM_E_ARG;
+  hipError_t e = mavlm_launch_rowsum(in, ld, rows, cols, out, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int mavlm_act(int32_t kind, const void* xin, const void* dy, void* out, int64_t n, int32_t dtype, void* stream) {
+  if (!xin || !out || n < 0) return MAVLM_E_ARG;
+  hipError_t e = mavlm_launch_act(kind, xin, dy, out, (size_t)n, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
 }  // extern "C"

@@ -22,6 +22,9 @@ hipError_t mavlm_launch_gemm256(const mavlm_gemm_args& g, int dtype, hipStream_t
 // persistent 256x256x64 kernel (gemm256p.hip): no residual epilogue, K >= 128
 bool mavlm_gemm256p_supported(const mavlm_gemm_args& g);
 hipError_t mavlm_launch_gemm256p(const mavlm_gemm_args& g, int dtype, hipStream_t s);
+// split-K form for the long contractions of the backward (gemm.hip); ws = [splits][M][N] fp32, ldc must equal N
+hipError_t mavlm_launch_gemm_splitk(const mavlm_gemm_args& g, int splits, float* ws, const float* zero_bias, int dtype,
+                                    hipStream_t s);
 extern int g_mavlm_gemm_tile;   // 0 = auto, 128 / 256 = forced non-persistent, 257 = forced persistent (tuning hook)
 
 struct mavlm_attn_args {
@@ -37,6 +40,33 @@ hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream
 // software-pipelined LDS-DMA variant (attention3.hip); mavlm_launch_attention dispatches to it
 hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStream_t s);
 extern int g_mavlm_attn_impl;   // 0 = auto, 2 = register-staged kernel, 3 = pipelined kernel (tuning hook)
+
+// backward of the head_dim-128 attention (attention_bwd.hip); any of dQ / dK / dV may be null (skipped)
+struct mavlm_attn_bwd_args {
+  const void* Q; int ldq;
+  const void* K; int ldk;
+  const void* V; int ldv;
+  const void* O; int ldo;        // forward output [R, H*128]
+  const void* dO; int lddo;      // its gradient
+  const float* lse2;             // [H, R] from the forward
+  float* delta;                  // [H, R] fp32 scratch (written here)
+  void* dQ; int lddq;
+  void* dK; int lddk;
+  void* dV; int lddv;
+  int R, S, H;
+  float scale;
+};
+hipError_t mavlm_launch_attention_bwd(const mavlm_attn_bwd_args& a, int dtype, hipStream_t s);
+
+// backward.hip
+size_t mavlm_layernorm_bwd_partial_floats(int D);
+hipError_t mavlm_launch_layernorm_bwd(const void* dy, const float* x, const void* res, int ldr, const float* gamma,
+                                      void* dz, float* dgamma, float* dbeta, float* part, int rows, int D, float eps,
+                                      int dtype, hipStream_t s);
+hipError_t mavlm_launch_transpose(const void* in, int ldi, int rows, int cols, void* out, int ldo, hipStream_t s);
+hipError_t mavlm_launch_rowsum(const void* in, int ld, int rows, int cols, float* out, int dtype, hipStream_t s);
+hipError_t mavlm_launch_act(int kind, const void* x, const void* dy, void* out, size_t n, int dtype, hipStream_t s);
+hipError_t mavlm_launch_splitk_reduce(const float* part, int splits, size_t n, void* out, int dtype, hipStream_t s);
 
 // column sums of the normalised probabilities: part[h][k] = sum_q exp2(s*c - lse2[h][q])
 struct mavlm_colsum_args {

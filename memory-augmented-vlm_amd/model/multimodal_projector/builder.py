@@ -1,0 +1,58 @@
+"""Step before the path: the vision projector that feeds `get_2dPool`.
+
+Mirrors `llava/model/multimodal_projector/builder.py:32-65` for the projector types the memory path is trained with
+(`mlp{N}x_gelu`, `linear`, `identity`).  State-dict keys are those of the reference's `nn.Sequential`
+(`0.weight, 0.bias, 2.weight, ...`), so a LLaVA-OneVision `mm_projector.*` checkpoint loads unchanged; forward runs on
+the MFMA GEMMs of the HIP library with the exact-erf GELU fused into the producing epilogue.  `pooler` and the
+`res` variants are not used by the memory-path configurations and raise.
+"""
+import re
+
+import torch.nn as nn
+
+from ... import _capi as capi
+from ... import _ops as ops
+
+
+class IdentityMap(nn.Module):
+    def forward(self, x, *args, **kwargs):
+        return x
+
+    @property
+    def config(self):
+        return {"mm_projector_type": "identity"}
+
+
+class MlpGeluProjector(nn.Sequential):
+    """Linear(mm_hidden, D) [GELU Linear(D, D)]*(depth-1); forward only (the reference detaches its output,
+    llava_arch.py:302)."""
+
+    def __init__(self, mm_hidden: int, hidden: int, depth: int):
+        mods = [nn.Linear(mm_hidden, hidden)]
+        for _ in range(1, depth):
+            mods += [nn.GELU(), nn.Linear(hidden, hidden)]
+        super().__init__(*mods)
+
+    def forward(self, x):
+        lin = [m for m in self if isinstance(m, nn.Linear)]
+        y = x.reshape(-1, x.shape[-1])
+        if not y.is_contiguous():
+            y = y.contiguous()
+        for i, m in enumerate(lin):
+            last = i == len(lin) - 1
+            y = ops.linear(y, m.weight, m.bias.float(), capi.EPI_BIAS if last else capi.EPI_GELU)
+        return y.reshape(*x.shape[:-1], y.shape[-1])
+
+
+def build_vision_projector(config, delay_load=False, **kwargs):
+    kind = getattr(config, "mm_projector_type", "linear")
+    if kind == "linear":
+        return MlpGeluProjector(config.mm_hidden_size, config.hidden_size, 1)
+    m = re.match(r"^mlp(\d+)x_gelu$", kind)
+    if m:
+        return MlpGeluProjector(config.mm_hidden_size, config.hidden_size, int(m.group(1)))
+    if kind == "identity":
+        return IdentityMap()
+    if kind == "pooler" or re.match(r"^mlp(\d+)x_res(\d+)x_gelu$", kind):
+        raise NotImplementedError(f"mm_projector_type {kind!r}: not used by the memory-path configurations")
+    raise ValueError(f"Unknown projector type: {kind}")

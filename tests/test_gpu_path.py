@@ -463,3 +463,27 @@ def test_config5_shape_fp16_128_memory_tokens_properties():
     assert torch.isfinite(torch.stack(list(cache)).float()).all()
     for s_ in scores[-3:]:
         assert abs(float(s_.float().sum()) - 8 * 128) < 0.02 * 8 * 128      # sum_f score_f = H*R/P
+
+
+@pytest.mark.gpu
+def test_vision_projector_mlp2x_gelu_matches_oracle():
+    """§8f rank 1, first half: mm_projector (builder.py:41-48) = Linear(1152,D) GELU Linear(D,D) on the HIP GEMMs,
+    state-dict keys of the reference's nn.Sequential; checked against the oracle's linear/gelu with bf16 rounding."""
+    import types
+    from memory_augmented_vlm_amd.model.multimodal_projector import build_vision_projector
+    torch.manual_seed(5)
+    cfg = types.SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=1152, hidden_size=1024)
+    proj = build_vision_projector(cfg).cuda().to(torch.bfloat16)
+    assert sorted(proj.state_dict()) == ["0.bias", "0.weight", "2.bias", "2.weight"]
+    x = (torch.randn(3, 729, 1152, device="cuda") * 0.5).to(torch.bfloat16)
+    with torch.no_grad():
+        y = proj(x)
+    assert tuple(y.shape) == (3, 729, 1024)
+    w = {"memory_fuser.0.weight": to_np(proj[0].weight), "memory_fuser.0.bias": to_np(proj[0].bias),
+         "memory_fuser.2.weight": to_np(proj[2].weight), "memory_fuser.2.bias": to_np(proj[2].bias)}
+    ref = O.fuser_mlp(to_np(x), w, "bf16")
+    assert O.rel_l2(to_np(y), ref) < 1e-3
+    with pytest.raises(NotImplementedError):
+        build_vision_projector(types.SimpleNamespace(mm_projector_type="pooler", mm_hidden_size=8, hidden_size=8))
+    with pytest.raises(ValueError):
+        build_vision_projector(types.SimpleNamespace(mm_projector_type="bogus", mm_hidden_size=8, hidden_size=8))
