@@ -1,0 +1,170 @@
+"""Training path of the memory modules: torch.autograd.Function wrappers whose forward AND
+backward are the HIP kernels of this library.  The reference trains the same modules with plain autograd
+(`recurrent_model` / `larimar_model` are the trainable parts, train.py:1708-1724); autograd here only records the
+graph and routes gradients - every product, softmax, normalisation and activation runs in csrc/.
+
+The forward of each Function issues exactly the kernel sequence of the fused inference step (`mavlm_step`,
+csrc/mavlm_api.hip), so training-mode activations are bit-identical to inference-mode ones (tested).
+Gradients are produced in the parameter dtype (bf16 / fp16), as autograd does for the reference under
+`--bf16 True`; reductions (dW contraction, bias / LayerNorm-affine sums) accumulate in fp32 before the one rounding.
+"""
+import math
+
+import torch
+
+from . import _capi as capi
+from . import _ops as ops
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _weight_grads(dy, x):
+    """dW = dy^T x and db = column sums of dy, both through the transposed (contraction-contiguous) operands."""
+    dyT = ops.transpose(dy)                     # [N, Mpad], zero pad
+    xT = ops.transpose(x)                       # [K, Mpad]
+    return ops.matmul_nt_splitk(dyT, xT), ops.rowsum(dyT, dy.shape[0])
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b)   (nn.Linear + ReLU / GELU; MemoryController.py:37-39,48-50,63-64; llava_arch.py:132-136)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        b32 = bias.detach().float()
+        x = _c(x.detach())
+        w = weight.detach()
+        if act == ACT_GELU:
+            # the pre-activation is stored (its derivative needs it); the forward value is gelu(16-bit pre-activation),
+            # i.e. one rounding more than the inference epilogue - the reference's bf16 graph rounds there as well
+            pre = ops.linear(x, w, b32, capi.EPI_BIAS)
+            y = ops.act(ops.ACT_GELU, pre)
+            ctx.save_for_backward(x, w, pre)
+        elif act == ACT_RELU:
+            y = ops.linear(x, w, b32, capi.EPI_RELU)
+            ctx.save_for_backward(x, w, y)
+        else:
+            y = ops.linear(x, w, b32, capi.EPI_BIAS)
+            ctx.save_for_backward(x, w)
+        ctx.act = act
+        ctx.bias_dtype = bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        saved = ctx.saved_tensors
+        x, w = saved[0], saved[1]
+        dy = _c(dy)
+        if ctx.act == ACT_GELU:
+            dy = ops.act(ops.ACT_GELU_BWD, saved[2], dy)
+        elif ctx.act == ACT_RELU:
+            dy = ops.act(ops.ACT_RELU_BWD, saved[2], dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.matmul_nt(dy, ops.transpose(w))          # dy [M,N] . (W^T [K,N])^T
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw, db = _weight_grads(dy, x)
+            db = db.to(ctx.bias_dtype)
+        return dx, dw, db, None
+
+
+class DenseResidualNormFn(torch.autograd.Function):
+    """y = LayerNorm(x W^T + b + res)   (`Residual`, MemoryController.py:20-29): fp32 GEMM output -> fused
+    residual-add + LayerNorm kernel, as in the inference step."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, gamma, beta, eps):
+        x, res, w = _c(x.detach()), _c(res.detach()), weight.detach()
+        g32 = gamma.detach().float()
+        z = ops.linear(x, w, bias.detach().float(), capi.EPI_F32)
+        y = ops.layernorm(z, g32, beta.detach().float(), eps, x.dtype, residual=res)
+        ctx.save_for_backward(x, w, z, res, g32)
+        ctx.eps = eps
+        ctx.dtypes = (bias.dtype, gamma.dtype, beta.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, z, res, g32 = ctx.saved_tensors
+        dz, dg, dbeta = ops.layernorm_bwd(_c(dy), z, res, g32, ctx.eps)
+        dx = ops.matmul_nt(dz, ops.transpose(w)) if ctx.needs_input_grad[0] else None
+        dw, db = _weight_grads(dz, x)
+        bd, gd, btd = ctx.dtypes
+        return dx, dw, db.to(bd), (dz if ctx.needs_input_grad[3] else None), dg.to(gd), dbeta.to(btd), None
+
+
+class AttentionFn(torch.autograd.Function):
+    """ctx = softmax(q k^T * scale) v per head (MemoryController.py:51-54), heads of 128 columns (narrower heads are
+    zero-padded by the caller).  Saves O and the log-sum-exp; the backward recomputes the probabilities per tile."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale):
+        q, k, v = q.detach(), k.detach(), v.detach()
+        o, lse = ops.attention(q, k, v, heads, want_lse=True, scale=scale)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.heads, ctx.scale = heads, scale
+        ctx.mark_non_differentiable(lse)
+        return o, lse
+
+    @staticmethod
+    def backward(ctx, do, _dlse):
+        q, k, v, o, lse = ctx.saved_tensors
+        n = ctx.needs_input_grad
+        dq, dk, dv = ops.attention_bwd(q, k, v, o, _c(do), lse, ctx.heads, n[0], n[1], n[2], scale=ctx.scale)
+        return dq, dk, dv, None, None
+
+
+def pad_heads_out(t, heads, hd):
+    """[H*hd, ...] -> [H*128, ...]: zero rows after each head (projection OUTPUT side); autograd-transparent."""
+    if hd == 128:
+        return t
+    tail = t.shape[1:]
+    return torch.nn.functional.pad(t.reshape(heads, hd, -1), (0, 0, 0, 128 - hd)).reshape(heads * 128, *tail)
+
+
+def pad_heads_in(t, heads, hd):
+    """[D, H*hd] -> [D, H*128]: zero columns after each head (projection INPUT side)."""
+    if hd == 128:
+        return t
+    return torch.nn.functional.pad(t.reshape(t.shape[0], heads, hd), (0, 128 - hd)).reshape(t.shape[0], heads * 128)
+
+
+def attention_block(attn, q_in, kv_in, want_stats=False):
+    """`Attention.forward` (MemoryController.py:47-56) on 2-D [rows, D] operands; returns (out, (q, k, lse) | None)."""
+    H = attn.num_attention_heads
+    hd = attn.attention_head_size
+    if hd > 128:
+        raise NotImplementedError("training the memory path with head_dim > 128 (OV-7B shape) is not implemented: the "
+                                  "backward attention kernel is head_dim-128; inference supports it")
+    scale = ops.attn_scale(hd)
+    q = LinearFn.apply(q_in, pad_heads_out(attn.q_proj.weight, H, hd), pad_heads_out(attn.q_proj.bias, H, hd), ACT_NONE)
+    k = LinearFn.apply(kv_in, pad_heads_out(attn.k_proj.weight, H, hd), pad_heads_out(attn.k_proj.bias, H, hd), ACT_NONE)
+    v = LinearFn.apply(kv_in, pad_heads_out(attn.v_proj.weight, H, hd), pad_heads_out(attn.v_proj.bias, H, hd), ACT_NONE)
+    ctxv, lse = AttentionFn.apply(q, k, v, H, scale)
+    d = attn.residual
+    out = DenseResidualNormFn.apply(ctxv, pad_heads_in(d.dense.weight, H, hd), d.dense.bias, q_in, d.layernorm.weight,
+                                    d.layernorm.bias, d.layernorm.eps)
+    return out, ((q, k, lse) if want_stats else None)
+
+
+def mlp_block(layer, a):
+    """TransformerLayer's MLP + Residual (MemoryController.py:63-67,71)."""
+    up = layer.mlp[0]
+    h = LinearFn.apply(a, up.weight, up.bias, ACT_RELU)
+    d = layer.residual
+    return DenseResidualNormFn.apply(h, d.dense.weight, d.dense.bias, a, d.layernorm.weight, d.layernorm.bias,
+                                     d.layernorm.eps)
+
+
+def fuser_mlp(fuser, x, type_row=None):
+    """memory_fuser = Linear GELU Linear (llava_arch.py:132-136,546); `type_row` (token_type_embedding row 0) rides in
+    the second bias so the add costs no extra rounding (as the inference epilogue, :548-553)."""
+    shp = x.shape
+    u = LinearFn.apply(x.reshape(-1, shp[-1]), fuser[0].weight, fuser[0].bias, ACT_GELU)
+    b2 = fuser[2].bias.float()
+    if type_row is not None:
+        b2 = b2 + type_row.float()
+    return LinearFn.apply(u, fuser[2].weight, b2, ACT_NONE).reshape(shp)

@@ -16,6 +16,13 @@ def dtype_code(dt: torch.dtype) -> int:
                           "the reference runs this path in the model dtype (bf16 in training, fp16/bf16 in eval)")
 
 
+def attn_scale(head_dim: int) -> float:
+    """1/sqrt(head_dim) exactly as the C side computes it (`1.0f / sqrtf((float)hd)`, csrc/mavlm_api.hip): float32
+    square root, float32 division - so the training path and the fused inference step hand the kernels the same bits."""
+    import numpy as np
+    return float(np.float32(1.0) / np.sqrt(np.float32(head_dim)))
+
+
 def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -56,7 +63,7 @@ def linear(x, weight, bias_f32, epilogue=capi.EPI_BIAS, residual=None, out=None)
     return out
 
 
-def attention(q, k, v, heads, want_lse=False, out=None, head_dim=128, wide_kernel=False):
+def attention(q, k, v, heads, want_lse=False, out=None, head_dim=128, wide_kernel=False, scale=None):
     """ctx = softmax(q k^T / sqrt(head_dim)) v per head.  q [R,>=H*hd], k/v [S,...] may be column slices of wider
     buffers.  head_dim 128 (default kernels) or 448 (wide-head kernel; `wide_kernel=True` forces that kernel at 128
     for cross-checks).  Returns (ctx [R,H*hd], lse2 [H,R] fp32 | None)."""
@@ -73,8 +80,9 @@ def attention(q, k, v, heads, want_lse=False, out=None, head_dim=128, wide_kerne
     lp = lse.data_ptr() if want_lse else 0
     if head_dim == 128 and not wide_kernel:
         capi.check(capi.lib().mavlm_attention(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(),
-                                              out.stride(0), lp, R, S, heads, 1.0 / math.sqrt(128.0), dtype_code(q.dtype),
-                                              stream_ptr()), "mavlm_attention")
+                                              out.stride(0), lp, R, S, heads,
+                                              1.0 / math.sqrt(128.0) if scale is None else float(scale),
+                                              dtype_code(q.dtype), stream_ptr()), "mavlm_attention")
     else:
         capi.check(capi.lib().mavlm_attention_hd(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(),
                                                  out.stride(0), lp, R, S, heads, head_dim, 1.0 / math.sqrt(head_dim),
@@ -82,7 +90,7 @@ def attention(q, k, v, heads, want_lse=False, out=None, head_dim=128, wide_kerne
     return out, lse
 
 
-def attention_colsum(q, k, lse2, heads, head_dim=128, wide_kernel=False):
+def attention_colsum(q, k, lse2, heads, head_dim=128, wide_kernel=False, scale=None):
     """part[h,s] = sum_q softmax probability of key s for head h (fp32)."""
     _need_gpu(q, k, lse2)
     R, _, ldq = _rows(q)
@@ -90,7 +98,8 @@ def attention_colsum(q, k, lse2, heads, head_dim=128, wide_kernel=False):
     part = torch.empty((heads, S), device=q.device, dtype=torch.float32)
     if head_dim == 128 and not wide_kernel:
         capi.check(capi.lib().mavlm_attention_colsum(q.data_ptr(), ldq, k.data_ptr(), ldk, lse2.data_ptr(), part.data_ptr(),
-                                                     R, S, heads, 1.0 / math.sqrt(128.0), dtype_code(q.dtype), stream_ptr()),
+                                                     R, S, heads, 1.0 / math.sqrt(128.0) if scale is None else float(scale),
+                                                     dtype_code(q.dtype), stream_ptr()),
                    "mavlm_attention_colsum")
     else:
         capi.check(capi.lib().mavlm_attention_colsum_hd(q.data_ptr(), ldq, k.data_ptr(), ldk, lse2.data_ptr(),
@@ -154,7 +163,7 @@ def pool_bilinear(x, side, stride=2, pe_table=None, idx=None, out=None):
 
 
 # ---- backward-pass ops -----------------------------------------------------------------------
-def attention_bwd(q, k, v, o, do, lse2, heads, need_dq=True, need_dk=True, need_dv=True):
+def attention_bwd(q, k, v, o, do, lse2, heads, need_dq=True, need_dk=True, need_dv=True, scale=None):
     """Gradients of `attention` (head_dim 128): returns (dq | None, dk | None, dv | None), each [rows, H*128]."""
     _need_gpu(q, k, v, o, do, lse2)
     R, _, ldq = _rows(q)
@@ -173,8 +182,9 @@ def attention_bwd(q, k, v, o, do, lse2, heads, need_dq=True, need_dk=True, need_
     p = lambda t: t.data_ptr() if t is not None else 0
     capi.check(capi.lib().mavlm_attention_bwd(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, o.data_ptr(), ldo,
                                               do.data_ptr(), lddo, lse2.data_ptr(), delta.data_ptr(), p(dq), W, p(dk), W,
-                                              p(dv), W, R, S, heads, 1.0 / math.sqrt(128.0), dtype_code(q.dtype),
-                                              stream_ptr()), "mavlm_attention_bwd")
+                                              p(dv), W, R, S, heads,
+                                              1.0 / math.sqrt(128.0) if scale is None else float(scale),
+                                              dtype_code(q.dtype), stream_ptr()), "mavlm_attention_bwd")
     return dq, dk, dv
 
 

@@ -119,7 +119,6 @@ def _device_indices(idx_cpu: torch.Tensor, device) -> torch.Tensor:
     return t
 
 
-@torch.no_grad()
 def video_token_rows(num_frames: int, mem_tokens: int, patches: int = 196, with_frames: bool = True, chunk: int = 32,
                      fine_frames: int = 32, cache_cap: int = 10, n_mem_prompt: int = len(MEMORY_PROMPT_IDS),
                      n_frame_prompt: int = len(FRAME_PROMPT_IDS)) -> int:
@@ -153,6 +152,9 @@ def video_memory_tokens(model, image: torch.Tensor, frame_idx_cpu: torch.Tensor,
     rm.memory_cache = []                                                                  # :532
     for i in range(len(bounds) - 1):                                                      # :534-537
         rm(x[bounds[i]:bounds[i + 1]])
+    if rm._cache_mode == "autograd":
+        return _video_memory_tokens_autograd(model, rm, x, fine_cpu, memory_prompt_embeds, frame_prompt_embeds,
+                                             image_newline, with_frames, out)
     eng = rm.engine(image.device, image.dtype)
     n = len(rm.memory_cache)
     R = rm.num_memory_tokens * P
@@ -178,6 +180,33 @@ def video_memory_tokens(model, image: torch.Tensor, frame_idx_cpu: torch.Tensor,
     return out, info
 
 
+def _video_memory_tokens_autograd(model, rm, x, fine_cpu, memory_prompt_embeds, frame_prompt_embeds, image_newline,
+                                  with_frames, out):
+    """Training-mode tail of video_memory_tokens (llava_arch.py:545-554,620-629): the fuser MLP runs as HIP autograd
+    Functions; the type-embedding adds and the concatenation are torch ops so that autograd routes the gradients of
+    token_type_embedding, the prompt embeddings and image_newline exactly as in the reference."""
+    from .. import _autograd as ag
+    P, D = x.shape[1], x.shape[2]
+    dt = x.dtype
+    temb = model.token_type_embedding.weight
+    mem = torch.cat(rm.memory_cache, dim=0)                                               # :545
+    fused = ag.fuser_mlp(model.memory_fuser, mem, temb[0]).reshape(-1, D)                  # :546-553
+    nl = image_newline.to(device=x.device, dtype=dt).reshape(1, D)
+    parts = [memory_prompt_embeds.to(dt), fused, nl]
+    n = len(rm.memory_cache)
+    R = rm.num_memory_tokens * P
+    if with_frames:
+        fine = x[_device_indices(fine_cpu, x.device)] + temb[1].to(dt)                     # :513-524,554
+        parts += [frame_prompt_embeds.to(dt), fine.reshape(-1, D), nl]
+    tokens = torch.cat(parts, dim=0)
+    if out is not None:
+        raise capi.MavlmError("video_memory_tokens: `out=` is an inference-path feature (no autograd through a "
+                              "caller-owned buffer)")
+    mp_rows = memory_prompt_embeds.shape[0]
+    info = {"num_memories": n, "pe_frames": x, "fine_idx": fine_cpu, "memory_rows": (mp_rows, mp_rows + n * R)}
+    return tokens, info
+
+
 class MemoryPathPool:
     """Keeps `n` videos in flight on `n` HIP streams over ONE set of weights.
 
@@ -195,6 +224,7 @@ class MemoryPathPool:
         self.slots = [model] + [_ReplicaView(model, rm.spawn_replica()) for _ in range(n - 1)]
         self.streams = None
 
+    @torch.no_grad()           # inference feature: the replicas' FIFOs are ring views, not autograd tensors
     def run(self, videos, memory_prompt_embeds, frame_prompt_embeds, image_newline, with_frames: bool = True):
         if self.streams is None:
             self.streams = [torch.cuda.Stream() for _ in self.slots]
@@ -224,6 +254,7 @@ class GraphedVideoMemory:
     The returned tensor is the graph's static output buffer (valid until the next call).  A new shape (T, indices,
     with_frames) needs a new instance."""
 
+    @torch.no_grad()
     def __init__(self, model, T: int, frame_idx_cpu: torch.Tensor, with_frames: bool = True, slot=None):
         rm = model.recurrent_memory_transformer
         self.view = slot if slot is not None else _ReplicaView(model, rm.spawn_replica())
@@ -246,6 +277,7 @@ class GraphedVideoMemory:
         with torch.cuda.graph(self.graph):
             self.out, _ = video_memory_tokens(self.view, self.x, self.idx, self.mp, self.fp, self.nl, with_frames)
 
+    @torch.no_grad()
     def __call__(self, frames, memory_prompt_embeds, frame_prompt_embeds, image_newline):
         self.x.copy_(frames)
         self.mp.copy_(memory_prompt_embeds)
@@ -355,6 +387,8 @@ class LlavaMetaForCausalLM:
                      attention_mask, past_key_values, labels):
         if input_ids.shape[0] != 1:
             return None
+        if torch.is_grad_enabled() and any(p.requires_grad for p in model.recurrent_memory_transformer.parameters()):
+            return None                                    # training: tokens must stay in the autograd graph
         mask = torch.ones_like(input_ids, dtype=torch.bool) if attention_mask is None else attention_mask.bool()
         ids = input_ids[0][mask[0]]
         pos = torch.where(ids == IMAGE_TOKEN_INDEX)[0].tolist()

@@ -280,6 +280,7 @@ class TransformerProjector(nn.Module):
         self.frame_attn_scores: List[torch.Tensor] = []
         self.compute_frame_scores = True      # API parity default; False skips the column-sum pass
         self._memory_cache: List[torch.Tensor] = []
+        self._cache_mode = "engine"           # "engine": ring views (inference); "autograd": graph tensors (training)
         self._engine = None
         self._fuser_refs = None               # (memory_fuser, token_type_embedding) bound by the glue
 
@@ -295,6 +296,7 @@ class TransformerProjector(nn.Module):
             raise capi.MavlmError("memory_cache can only be reset to [] from outside (llava_arch.py:532); "
                                   "its entries are views into the module's ring buffer")
         self._memory_cache = value
+        self._cache_mode = "engine"
         if self._engine is not None:
             capi.check(capi.lib().mavlm_reset(self._engine.ctx), "mavlm_reset")
 
@@ -356,12 +358,15 @@ class TransformerProjector(nn.Module):
             raise capi.MavlmError("TransformerProjector expects [F, P, D]")
         if not image_features.is_cuda:
             raise capi.MavlmError("TransformerProjector: input is not on a GPU; the HIP path has no CPU fallback")
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("the HIP memory path is forward-only (SURVEY.md §8f rank 3: backward is a "
-                                      "later row); call it under torch.no_grad() / in eval mode")
         F, P, D = image_features.shape
         if P != self.patch_size or D != self.hidden_size:
             raise capi.MavlmError(f"expected [F,{self.patch_size},{self.hidden_size}], got {tuple(image_features.shape)}")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_autograd(image_features)
+        if self._cache_mode == "autograd" and self._memory_cache:
+            raise capi.MavlmError("memory_cache holds autograd tensors of a training-mode video: reset it "
+                                  "(`memory_cache = []`) before running the inference path")
+        self._cache_mode = "engine"
         eng = self.engine(image_features.device, image_features.dtype, F)
         x = image_features.contiguous()
         scores = torch.empty(F, device=x.device, dtype=x.dtype) if self.compute_frame_scores else None
@@ -374,4 +379,43 @@ class TransformerProjector(nn.Module):
             self._memory_cache = self._memory_cache[-cap:]
         if scores is not None:
             self.frame_attn_scores.append(scores)                                    # :156-157
+        return self._memory_cache, self.frame_attn_scores
+
+    def _forward_autograd(self, image_features: torch.Tensor):
+        """Training path (the reference runs the same forward under autograd, BPTT through the
+        un-detached memory_cache, :125-127,152): the step is composed of autograd Functions whose forward and backward
+        are the HIP kernels (_autograd.py), in the kernel order of the fused inference step - the activations are
+        bit-identical to mavlm_step's.  The FIFO holds graph-carrying tensors instead of ring views."""
+        from ... import _autograd as ag
+        if self._cache_mode == "engine" and self._memory_cache:
+            raise capi.MavlmError("memory_cache holds ring views of an inference-mode video: reset it "
+                                  "(`memory_cache = []`) before running the training path")
+        self._cache_mode = "autograd"
+        F, P, D = image_features.shape
+        R = self.num_memory_tokens * P
+        dt = image_features.dtype
+        frames = image_features.detach().reshape(F * P, D)         # frame features carry no gradient (llava_arch.py:302)
+        if self._memory_cache:                                      # :125-127, 89-97
+            last = self._memory_cache[-1].reshape(R, D)
+            kv = torch.cat(self._memory_cache, dim=0).reshape(-1, D)
+            m, _ = ag.attention_block(self.memory_update_attention, last, kv)
+        else:
+            m = (self.initial_memory + self.memory_pos_embed).to(dt).reshape(R, D)      # :123-124
+        stats = None
+        for li, layer in enumerate(self.layers):                   # :132-133
+            last_layer = li == len(self.layers) - 1
+            a, stats = ag.attention_block(layer.memory_segment_fusion_attention, m, frames,
+                                          want_stats=last_layer and self.compute_frame_scores)
+            m = ag.mlp_block(layer, a)
+        self._memory_cache.append(m.reshape(self.num_memory_tokens, P, D))             # :152
+        cap = int(getattr(self.config, "cache_cap", 10))
+        if len(self._memory_cache) > cap:
+            self._memory_cache = self._memory_cache[-cap:]
+        if stats is not None:                                      # :135-139,156 (detached statistics)
+            with torch.no_grad():
+                q, k, lse = stats
+                att = self.layers[-1].memory_segment_fusion_attention
+                part = ops.attention_colsum(q, k, lse, att.num_attention_heads,
+                                            scale=ops.attn_scale(att.attention_head_size))
+                self.frame_attn_scores.append(part.sum(dim=0).view(F, P).mean(dim=1).to(dt))
         return self._memory_cache, self.frame_attn_scores

@@ -331,8 +331,56 @@ def g7():
     save("g7_fullsize.npz", meta=meta(hidden=1024, wseed=71, segseed0=700, stride=997), **res)
 
 
+# --------------------------------------------------------------------------- G8 (gradients)
+G8_CASES = {"d256": (256, 7), "d1024": (1024, 61)}      # hidden (8 heads: the reference's dead reshape needs H = M = 8), stride
+
+
+def g8_case(dtype, hidden, stride):
+    """3 recurrent steps of the reference TransformerProjector under autograd (BPTT through the un-detached
+    memory_cache, MemoryController.py:125-127,152), loss = sum_t <cache[t], G_t>; gradients of every parameter."""
+    cfg = O.PathConfig(hidden=hidden, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=81)
+    m = ref_projector(cfg, w, dtype).train()
+    m.memory_cache = []
+    m.frame_attn_scores = []
+    frames = [2, 1, 2]
+    with torch.enable_grad():
+        for t, f in enumerate(frames):
+            seg = O.bf16_round(O.hash_normal_like((f, 196, hidden), 800 + t))
+            cache, _ = m(T(seg).to(dtype))
+        loss = 0.0
+        for t, c in enumerate(cache):
+            g = O.bf16_round(O.hash_normal_like(tuple(c.shape), 850 + t, 0.05))
+            loss = loss + (c.float() * T(g)).sum()
+        loss.backward()
+    out = {"loss": np.array(float(loss))}
+    for name, p in m.named_parameters():
+        g = p.grad.float().numpy().reshape(-1)
+        out["g_" + name + "_sample"] = g[::stride].copy()
+        out["g_" + name + "_norm"] = np.array(np.linalg.norm(g.astype(np.float64)))
+    return cfg, frames, out
+
+
+def g8():
+    for tag, (hidden, stride) in G8_CASES.items():
+        cfg, frames, ref = g8_case(torch.float32, hidden, stride)
+        _, _, bf = g8_case(torch.bfloat16, hidden, stride)
+        # the reference's own bf16-vs-fp32 distance per parameter gradient (on the stored samples): the envelope the
+        # 16-bit HIP backward is judged against
+        env = {}
+        for k in ref:
+            if k.endswith("_sample"):
+                env["env_" + k[2:-7]] = np.array(O.rel_l2(bf[k], ref[k]))
+        save(f"g8_grads_{tag}.npz", meta=meta(hidden=hidden, heads=8, mem_tokens=8, depth=2, frames=frames, wseed=81,
+                                              segseed0=800, gseed0=850, gstd=0.05, stride=stride), **ref, **env)
+        print(tag, "reference bf16-vs-fp32 gradient envelope: max", max(float(v) for v in env.values()),
+              "median", float(np.median([float(v) for v in env.values()])))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g56", "g7"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g56", "g7", "g8"]
+    if "g8" in which:
+        g8()
     if "g1" in which:
         g1_g2()
     if "g3" in which:

@@ -1,0 +1,195 @@
+"""-m gpu: training path of the memory modules - forward under autograd and the gradients of
+every parameter, HIP kernels on both sides, against
+
+  * the inference path (activations must be bit-identical),
+  * gradients the imported reference produced (tests/golden/g8_grads_*.npz) - gate: inside the reference's own
+    bf16-vs-fp32 distance, stored per parameter in the same file,
+  * oracle/torch_path.py (torch restatement + autograd on CPU, pinned to that golden) on further shapes.
+"""
+import numpy as np
+import pytest
+import torch
+
+import memory_augmented_vlm_amd  # noqa: F401
+from memory_augmented_vlm_amd import _capi as capi
+from memory_augmented_vlm_amd.model import llava_arch as arch
+from oracle import memory_path as O
+from oracle import torch_path as TP
+from conftest import load_golden
+from gpu_util import to_dev, to_np, DT
+from test_gpu_path import make_projector, _tiny_host
+
+pytestmark = pytest.mark.gpu
+
+
+def _segs(cfg, frames, seed0):
+    return [O.bf16_round(O.hash_normal_like((f, 196, cfg.hidden), seed0 + t)) for t, f in enumerate(frames)]
+
+
+def _cotangents(cfg, n, seed0, std):
+    return [O.bf16_round(O.hash_normal_like((cfg.mem_tokens, cfg.patches, cfg.hidden), seed0 + t, std)) for t in range(n)]
+
+
+def _hip_grads(rm, segs, cots, mode):
+    rm.zero_grad(set_to_none=True)
+    rm.memory_cache = []
+    for s in segs:
+        cache, _ = rm(to_dev(s, mode))
+    loss = sum((c.float() * torch.from_numpy(g).cuda()).sum() for c, g in zip(cache, cots))
+    loss.backward()
+    out = {k: (None if p.grad is None else to_np(p.grad)) for k, p in rm.named_parameters()}
+    rm.memory_cache = []
+    return float(loss.detach()), out, [c.detach() for c in cache]
+
+
+@pytest.mark.parametrize("mode,H,hd,frames", [("bf16", 8, 128, [2, 1, 2]), ("fp16", 2, 64, [1, 2]), ("bf16", 8, 112, [2, 1])])
+def test_training_forward_bit_identical_to_inference(mode, H, hd, frames):
+    cfg = O.PathConfig(hidden=H * hd, heads=H, mem_tokens=4, depth=2)
+    w = O.make_weights(cfg, seed=5)
+    rm = make_projector(cfg, w, mode)
+    segs = _segs(cfg, frames, 900)
+    with torch.no_grad():
+        rm.memory_cache = []
+        for s in segs:
+            cache, scores = rm(to_dev(s, mode))
+        ref = [c.clone() for c in cache]
+        ref_scores = [s.clone() for s in scores[-len(frames):]]
+    rm.memory_cache = []
+    rm.train()
+    for s in segs:
+        cache, scores = rm(to_dev(s, mode))
+    assert all(c.requires_grad for c in cache)
+    for a, b in zip(cache, ref):
+        assert torch.equal(a.detach(), b)
+    for a, b in zip(scores[-len(frames):], ref_scores):
+        assert torch.equal(a, b) and not a.requires_grad
+    # switching paths in the middle of a video is refused, a reset clears it
+    with torch.no_grad(), pytest.raises(capi.MavlmError, match="reset"):
+        rm(to_dev(segs[0], mode))
+    rm.memory_cache = []
+    with torch.no_grad():
+        rm(to_dev(segs[0], mode))
+    with pytest.raises(capi.MavlmError, match="reset"):
+        rm(to_dev(segs[0], mode))
+    rm.memory_cache = []
+
+
+@pytest.mark.parametrize("tag", ["d256", "d1024"])
+def test_gradients_inside_reference_bf16_envelope(tag):
+    """3 recurrent steps with BPTT through the memory cache; every parameter gradient against the reference's fp32
+    autograd.  Yardstick: the reference's OWN bf16-vs-fp32 distance for that gradient (1.6-6 %, one sample of its
+    rounding noise, stored in the golden file).  Gate: every parameter <= 1.5x its envelope and the median ratio
+    <= 1 (measured: 0.43-1.45, median 0.85 - the 16-bit HIP backward is as close to fp32 as the reference's own
+    bf16 autograd; both are dominated by the bf16 forward activations)."""
+    z, meta = load_golden(f"g8_grads_{tag}.npz")
+    cfg = O.PathConfig(hidden=meta["hidden"], heads=meta["heads"], mem_tokens=meta["mem_tokens"], depth=meta["depth"])
+    w = O.make_weights(cfg, seed=meta["wseed"])
+    rm = make_projector(cfg, w, "bf16").train()
+    segs = _segs(cfg, meta["frames"], meta["segseed0"])
+    cots = _cotangents(cfg, len(segs), meta["gseed0"], meta["gstd"])
+    loss, g, _ = _hip_grads(rm, segs, cots, "bf16")
+    assert abs(loss - float(z["loss"])) <= 2e-2 * abs(float(z["loss"]))
+    scale = max(float(z[k]) for k in z.files if k.endswith("_norm"))
+    worst, ratios = 0.0, []
+    for name, grad in g.items():
+        got = grad.reshape(-1)[::meta["stride"]]
+        ref = z["g_" + name + "_sample"]
+        if name.endswith("k_proj.bias"):      # true gradient is 0 (softmax shift invariance)
+            assert np.linalg.norm(grad) <= 2e-3 * scale, name
+            continue
+        err, env = O.rel_l2(got, ref), float(z["env_" + name])
+        worst = max(worst, err / env)
+        ratios.append(err / env)
+        assert err <= 1.5 * env, (name, err, env)
+    print(f"{tag}: HIP-bf16 gradient error / reference-bf16 envelope: worst {worst:.2f}, median {np.median(ratios):.2f}")
+    assert np.median(ratios) <= 1.0
+
+
+@pytest.mark.parametrize("mode,H,hd,M,frames,cap", [("bf16", 2, 128, 3, [1, 2, 1, 1], 2), ("fp16", 4, 64, 2, [2, 1], 10),
+                                                    ("bf16", 1, 128, 5, [3], 10)])
+def test_gradients_vs_torch_oracle(mode, H, hd, M, frames, cap):
+    """Other shapes against oracle/torch_path.py (float64 autograd on the same 16-bit weights and inputs): FIFO
+    eviction under BPTT (cap 2), zero-padded heads (hd 64), fp16, a single step (no evolution).
+    Gate per parameter gradient: 6e-2 in bf16 (the reference's own bf16 autograd sits at 1.6-6e-2 on the golden
+    case, 3 steps; measured here 2-3e-2 over 4 steps), 2e-2 in fp16 (finer grid; ReLU gates flipping on near-zero pre-activations keep mlp.0 at 1.4e-2)."""
+    tol = 6e-2 if mode == "bf16" else 2e-2
+    cfg = O.PathConfig(hidden=H * hd, heads=H, mem_tokens=M, depth=2)
+    w = O.make_weights(cfg, seed=17, grid=mode)
+    rm = make_projector(cfg, w, mode, cache_cap=cap).train()
+    segs = _segs(cfg, frames, 950)
+    n = min(len(frames), cap)
+    cots = _cotangents(cfg, n, 970, 0.05)
+    loss, g, _ = _hip_grads(rm, [O.rounder(mode)(s) for s in segs], cots, mode)
+    p = TP.params_from(w)
+    cache = TP.run_steps(p, cfg, [O.rounder(mode)(s) for s in segs], cache_cap=cap)
+    tl = sum((c * torch.from_numpy(gc).double()).sum() for c, gc in zip(cache, cots))
+    ref = TP.grads(p, tl)
+    assert abs(loss - float(tl.detach())) <= 2e-2 * abs(float(tl.detach())) + 1e-3
+    scale = max(np.linalg.norm(v) for v in ref.values())
+    for name, grad in g.items():
+        r = ref[TP.PFX + "." + name]
+        if len(frames) == 1 and name.startswith("memory_update_attention"):
+            assert grad is None or not grad.any()                   # evolution never ran
+        elif name.endswith("k_proj.bias"):
+            assert np.linalg.norm(grad) <= 2e-3 * scale, name
+        else:
+            assert O.rel_l2(grad, r) < tol, (name, O.rel_l2(grad, r))
+
+
+def test_full_token_block_gradients():
+    """video_memory_tokens under autograd on the toy host: PE add -> 2 chunks -> fuser MLP + type rows + concat; the
+    gradients of the fuser, the token-type embedding, image_newline and the recurrent module against the torch oracle."""
+    cfg = O.PathConfig(hidden=256, heads=8, mem_tokens=2, depth=2)    # LlavaMetaModel hard-codes 8 heads (llava_arch.py:121)
+    w = O.make_weights(cfg, seed=23)
+    model, _ = _tiny_host(cfg, w)
+    model.train()
+    rows = sorted(set(O.MEM_PROMPT_IDS + O.FRAME_PROMPT_IDS))
+    emb = np.zeros((48900, 256), np.float32)
+    emb[rows] = O.bf16_round(O.hash_normal_like((len(rows), 256), 81, 0.02))
+    with torch.no_grad():
+        model.embed_tokens.weight.copy_(to_dev(emb))
+        model.image_newline.copy_(to_dev(w["image_newline"]))
+    T = 36
+    x = O.bf16_round(O.hash_normal_like((T, 196, 256), 83))
+    idx = O.subsample_indices(40)[:T]
+    mp = model.embed_tokens(torch.tensor(O.MEM_PROMPT_IDS, device="cuda"))
+    fp = model.embed_tokens(torch.tensor(O.FRAME_PROMPT_IDS, device="cuda"))
+    toks, info = arch.video_memory_tokens(model, to_dev(x), torch.from_numpy(idx), mp, fp, model.image_newline)
+    assert toks.requires_grad and toks.shape[0] == arch.video_token_rows(T, 2)
+    cot = O.bf16_round(O.hash_normal_like(tuple(toks.shape), 84, 0.05))
+    loss = (toks.float() * torch.from_numpy(cot).cuda()).sum()
+    loss.backward()
+    # forward equals the inference path up to the one extra rounding of the GELU pre-activation
+    with torch.no_grad():
+        ref_toks, _ = arch.video_memory_tokens(model, to_dev(x), torch.from_numpy(idx), mp.detach(), fp.detach(),
+                                               model.image_newline)
+    assert O.rel_l2(to_np(toks), to_np(ref_toks)) < 2e-3
+    a, b = info["memory_rows"]
+    assert torch.equal(toks[:a].detach(), ref_toks[:a]) and torch.equal(toks[b:].detach(), ref_toks[b:])
+
+    # ---- torch oracle of the same block
+    p = TP.params_from(w)
+    xpe = O.pe_add(x, idx, w["positional_encoding.frame_embed"], "bf16")
+    bounds = O.uniform_segment_variant(T, 32)
+    cache = TP.run_steps(p, cfg, [xpe[bounds[i]:bounds[i + 1]] for i in range(len(bounds) - 1)])
+    fused = TP.fuse(p, cache)
+    fine = torch.from_numpy(xpe[O.fine_frame_indices(T)]).double() + p["token_type_embedding.weight"][1]
+    nl = p["image_newline"].reshape(1, -1)
+    e = torch.from_numpy(emb).double()
+    t_toks = torch.cat([e[list(O.MEM_PROMPT_IDS)], fused, nl, e[list(O.FRAME_PROMPT_IDS)], fine.reshape(-1, 256), nl])
+    t_loss = (t_toks * torch.from_numpy(cot).double()).sum()
+    ref = TP.grads(p, t_loss)
+    assert abs(float(loss.detach()) - float(t_loss.detach())) <= 2e-2 * abs(float(t_loss.detach())) + 1e-2
+    named = dict(model.named_parameters())
+    checked = 0
+    for name, r in ref.items():
+        if name.endswith("k_proj.bias") or name not in named:
+            continue
+        got = to_np(named[name].grad)
+        # 0.1 for the recurrent parameters: a 2-token memory at D = 256 is a small, noisy sample (memory_pos_embed is a
+        # sum over 196 partly cancelling rows: 8e-2); the larger golden cases above carry the tight gates
+        tol = 1e-1 if name.startswith(TP.PFX) else (6e-2 if name.startswith("memory_fuser") else 1e-2)
+        assert O.rel_l2(got, r) < tol, (name, O.rel_l2(got, r))
+        checked += 1
+    assert checked >= len(ref) - 4
+    assert "token_type_embedding.weight" in named and "image_newline" in named

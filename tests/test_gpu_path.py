@@ -21,6 +21,14 @@ TOL = 1e-3            # GPU vs oracle in operand-rounding-emulation mode (primar
 TOL_REF_FP32 = 1.2e-2  # GPU bf16 vs the reference's own fp32 run; the reference's bf16 run sits at 4.8e-3..8.4e-3
 
 
+@pytest.fixture(autouse=True)
+def _inference_path():
+    """This file tests the inference path; with grad enabled the modules take the autograd (training) path, which
+    tests/test_gpu_backward_path.py covers."""
+    with torch.no_grad():
+        yield
+
+
 def chain_tol(floor):
     """Tolerance for a CHAIN of 16-bit-rounded stages.  Single stages match the oracle to ~1e-4 (see
     test_gpu_ops.py and test_step_stagewise_teacher_forced); along a chain two correct implementations
@@ -479,9 +487,9 @@ def test_vision_projector_mlp2x_gelu_matches_oracle():
     with torch.no_grad():
         y = proj(x)
     assert tuple(y.shape) == (3, 729, 1024)
-    w = {"memory_fuser.0.weight": to_np(proj[0].weight), "memory_fuser.0.bias": to_np(proj[0].bias),
-         "memory_fuser.2.weight": to_np(proj[2].weight), "memory_fuser.2.bias": to_np(proj[2].bias)}
-    ref = O.fuser_mlp(to_np(x), w, "bf16")
+    r = O.rounder("bf16")
+    u = r(O.gelu_erf(O.linear(to_np(x).reshape(-1, 1152), to_np(proj[0].weight), to_np(proj[0].bias))))
+    ref = r(O.linear(u, to_np(proj[2].weight), to_np(proj[2].bias))).reshape(3, 729, 1024)
     assert O.rel_l2(to_np(y), ref) < 1e-3
     with pytest.raises(NotImplementedError):
         build_vision_projector(types.SimpleNamespace(mm_projector_type="pooler", mm_hidden_size=8, hidden_size=8))
