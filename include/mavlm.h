@@ -191,9 +191,10 @@ int mavlm_set_attention_impl(int32_t impl);
 
 /* --- measurement hooks (bench.py only; new - the reference has no profiling) ------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on its own stream.  Kinds: 0 GEMM, 1 attention
- * forward, 2 attention column-sum, 3 LayerNorm, 4 row-add, 5 misc.  Not re-entrant, not graph-capturable. */
+ * forward, 2 attention column-sum, 3 LayerNorm (forward and backward), 4 row-add, 5 misc, 6 attention backward,
+ * 7 split-K GEMM, 8 transpose.  Not re-entrant, not graph-capturable. */
 int mavlm_prof_enable(int32_t on);
-/* host arrays of length nkinds >= 6: total milliseconds, launches, algorithmic flops, algorithmic bytes per kind */
+/* host arrays of length nkinds >= 9: total milliseconds, launches, algorithmic flops, algorithmic bytes per kind */
 int mavlm_prof_read(double* ms, int64_t* launches, double* flops, double* bytes, int32_t nkinds);
 
 #ifdef __cplusplus

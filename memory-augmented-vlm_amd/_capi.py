@@ -80,7 +80,8 @@ SIGNATURES = {
                                   C.POINTER(C.c_double), i32]),
 }
 
-KERNEL_KINDS = ("gemm", "attention_fwd", "attention_colsum", "layernorm", "row_add", "misc")
+KERNEL_KINDS = ("gemm", "attention_fwd", "attention_colsum", "layernorm", "row_add", "misc", "attention_bwd",
+                "gemm_splitk", "transpose")
 
 _lib = None
 

@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int LNB_PART = 1024;   // partial rows of dgamma/dbeta = 256 workgroups x 4 waves
+constexpr int LNB_BLOCKS = 512;  // workgroups of the LayerNorm backward = partial rows of dgamma/dbeta (one per workgroup)
 
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __restrict__ dy,
@@ -96,24 +96,53 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
                      rstd * (d[i][2] - m1 - v[i][2] * m2), rstd * (d[i][3] - m1 - v[i][3] * m2));
     }
   }
-  float* pg = part + (size_t)wv * 2 * D;
+  // the 4 waves of the workgroup add their sums through LDS (fixed order: deterministic), one partial row per workgroup
+  extern __shared__ __attribute__((aligned(16))) float red[];      // [3][2][D]: waves 1..3
+  const int w = threadIdx.x >> 6;
+  if (w > 0) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int j = i * 64 + lane;
-    if (j < nvec) {
-      ((f32x4*)pg)[j] = ag[i];
-      ((f32x4*)(pg + D))[j] = ab[i];
+    for (int i = 0; i < NV; ++i) {
+      const int j = i * 64 + lane;
+      if (j < nvec) {
+        ((f32x4*)(red + (size_t)(w - 1) * 2 * D))[j] = ag[i];
+        ((f32x4*)(red + (size_t)(w - 1) * 2 * D + D))[j] = ab[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (w == 0) {
+    float* pg = part + (size_t)blockIdx.x * 2 * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int j = i * 64 + lane;
+      if (j < nvec) {
+        f32x4 a = ag[i], b = ab[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const f32x4 ra = ((const f32x4*)(red + (size_t)k * 2 * D))[j];
+          const f32x4 rb = ((const f32x4*)(red + (size_t)k * 2 * D + D))[j];
+          a[0] += ra[0]; a[1] += ra[1]; a[2] += ra[2]; a[3] += ra[3];
+          b[0] += rb[0]; b[1] += rb[1]; b[2] += rb[2]; b[3] += rb[3];
+        }
+        ((f32x4*)pg)[j] = a;
+        ((f32x4*)(pg + D))[j] = b;
+      }
     }
   }
 }
 
+// out[c] = sum_p part[p][c]; a workgroup owns 64 columns, its 4 waves take every 4th partial row (fixed order)
 __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, int nparts, int cols,
                                                               float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * cols + c];
-  out[c] = s;
+  if (c < cols)
+    for (int p = w; p < nparts; p += 4) s += part[(size_t)p * cols + c];
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < cols) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // 64x64 tile through LDS; 8-byte global accesses on both sides.
@@ -205,9 +234,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 template <typename T>
 hipError_t launch_ln_bwd(const uint16_t* dy, const float* x, const uint16_t* res, int ldr, const float* gamma,
                          uint16_t* dz, float* part, int rows, int D, float eps, hipStream_t s) {
-  const dim3 grid(LNB_PART / 4), block(256);
+  const dim3 grid(LNB_BLOCKS), block(256);
   const int nv = (D / 4 + 63) / 64;
-#define LNB(NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), grid, block, 0, s, dy, x, res, ldr, gamma, dz, part, rows, D, eps)
+  const size_t lds = (size_t)3 * 2 * D * sizeof(float);
+#define LNB(NV)                                                                                                     \
+  do {                                                                                                              \
+    static bool attr_done = false;                                                                                  \
+    if (!attr_done && lds > 65536) {                                                                                \
+      hipError_t ae = hipFuncSetAttribute((const void*)layernorm_bwd_kernel<T, NV>,                                 \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 4096 * 4);            \
+      if (ae != hipSuccess) return ae;                                                                              \
+      attr_done = true;                                                                                             \
+    }                                                                                                               \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), grid, block, lds, s, dy, x, res, ldr, gamma, dz, part, rows,   \
+                       D, eps);                                                                                     \
+  } while (0)
   if (nv <= 1) LNB(1);
   else if (nv <= 2) LNB(2);
   else if (nv <= 4) LNB(4);
@@ -220,7 +261,7 @@ hipError_t launch_ln_bwd(const uint16_t* dy, const float* x, const uint16_t* res
 
 }  // namespace
 
-size_t mavlm_layernorm_bwd_partial_floats(int D) { return (size_t)(LNB_PART + 1) * 2 * D; }
+size_t mavlm_layernorm_bwd_partial_floats(int D) { return (size_t)(LNB_BLOCKS + 1) * 2 * D; }
 
 hipError_t mavlm_launch_layernorm_bwd(const void* dy, const float* x, const void* res, int ldr, const float* gamma,
                                       void* dz, float* dgamma, float* dbeta, float* part, int rows, int D, float eps,
@@ -231,20 +272,20 @@ hipError_t mavlm_launch_layernorm_bwd(const void* dy, const float* x, const void
                      ? launch_ln_bwd<F16>((const uint16_t*)dy, x, (const uint16_t*)res, ldr, gamma, (uint16_t*)dz, part, rows, D, eps, s)
                      : launch_ln_bwd<BF16>((const uint16_t*)dy, x, (const uint16_t*)res, ldr, gamma, (uint16_t*)dz, part, rows, D, eps, s);
   if (e != hipSuccess) return e;
-  // partial rows are [wave][2][D]: view as [LNB_PART][2D] and sum down the columns; dgamma = cols [0,D), dbeta = [D,2D)
+  // partial rows are [workgroup][2][D]: view as [LNB_BLOCKS][2D] and sum down the columns; dgamma = cols [0,D), dbeta = [D,2D)
   // of a 2D-wide result; write through a small two-step so that dgamma / dbeta may be separate allocations
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, s, part, LNB_PART, 2 * D,
-                     part + (size_t)LNB_PART * 2 * D);
-  e = hipMemcpyAsync(dgamma, part + (size_t)LNB_PART * 2 * D, sizeof(float) * D, hipMemcpyDeviceToDevice, s);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, part, LNB_BLOCKS, 2 * D,
+                     part + (size_t)LNB_BLOCKS * 2 * D);
+  e = hipMemcpyAsync(dgamma, part + (size_t)LNB_BLOCKS * 2 * D, sizeof(float) * D, hipMemcpyDeviceToDevice, s);
   if (e != hipSuccess) return e;
-  return hipMemcpyAsync(dbeta, part + (size_t)LNB_PART * 2 * D + D, sizeof(float) * D, hipMemcpyDeviceToDevice, s);
+  return hipMemcpyAsync(dbeta, part + (size_t)LNB_BLOCKS * 2 * D + D, sizeof(float) * D, hipMemcpyDeviceToDevice, s);
 }
 
 hipError_t mavlm_launch_transpose(const void* in, int ldi, int rows, int cols, void* out, int ldo, hipStream_t s) {
   if (rows <= 0 || cols <= 0 || (cols & 3) || (ldi & 3) || (ldo & 3)) return hipErrorInvalidValue;
   const int rows_pad = (rows + 63) / 64 * 64;
   if (ldo < rows_pad) return hipErrorInvalidValue;
-  mavlm_prof_scope prof(MAVLM_K_MISC, 0.0, 4.0 * rows * (double)cols, s);
+  mavlm_prof_scope prof(MAVLM_K_TRANSPOSE, 0.0, 4.0 * rows * (double)cols, s);
   hipLaunchKernelGGL(transpose_kernel, dim3(rows_pad / 64, (cols + 63) / 64), dim3(256), 0, s, (const uint16_t*)in, ldi,
                      rows, cols, (uint16_t*)out, ldo, rows_pad);
   return hipGetLastError();

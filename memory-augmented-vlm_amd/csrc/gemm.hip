@@ -208,7 +208,7 @@ hipError_t mavlm_launch_gemm_splitk(const mavlm_gemm_args& g0, int splits, float
   if (splits > nk) splits = nk;
   const int ksplit = ((nk + splits - 1) / splits) * BK;
   splits = (g0.K + ksplit - 1) / ksplit;
-  mavlm_prof_scope prof(MAVLM_K_GEMM, 2.0 * g0.M * (double)g0.N * g0.K,
+  mavlm_prof_scope prof(MAVLM_K_GEMM_SPLITK, 2.0 * g0.M * (double)g0.N * g0.K,
                         2.0 * ((double)g0.M * g0.K + (double)g0.N * g0.K) + (4.0 * splits + 2.0) * g0.M * (double)g0.N, s);
   mavlm_gemm_args g = g0;
   void* out16 = g0.C;

@@ -379,7 +379,7 @@ int mavlm_attention_bwd(const void* Q, int32_t ldq, const void* K, int32_t ldk, 
   a.lse2 = lse2; a.delta = delta; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
   a.R = R; a.S = S; a.H = H; a.scale = scale;
   const double units = (dQ ? 3.0 : 0.0) + (dK ? 3.0 : 0.0) + (dV ? 2.0 : 0.0);
-  mavlm_prof_scope prof(MAVLM_K_ATTN, units * 2.0 * R * (double)S * H * 128.0, 2.0 * 128.0 * H * (4.0 * R + 4.0 * S),
+  mavlm_prof_scope prof(MAVLM_K_ATTN_BWD, units * 2.0 * R * (double)S * H * 128.0, 2.0 * 128.0 * H * (4.0 * R + 4.0 * S),
                         (hipStream_t)stream);
   hipError_t e = mavlm_launch_attention_bwd(a, dtype, (hipStream_t)stream);
   return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
