@@ -130,7 +130,8 @@ int mavlm_linear(const void* A, int32_t lda, const void* W, int32_t ldw, const f
 int mavlm_attention(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                     int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream);
 /* same for wide heads: head h occupies columns [h*head_dim, (h+1)*head_dim); head_dim 448 (LLaVA-OneVision-7B: hidden
- * 3584 / 8 heads, llava_arch.py:117-122) or 128 */
+ * 3584 / 8 heads, llava_arch.py:117-122), 128, or 256 / 224 (the 4-head TransformerEncoder of the inactive
+ * MemoryFuser variant, memory_module/MemoryFuser.py:12-19; forward only, no column-sum pass) */
 int mavlm_attention_hd(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                        int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, int32_t head_dim, float scale,
                        int32_t dtype, void* stream);

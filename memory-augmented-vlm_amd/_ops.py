@@ -72,8 +72,8 @@ def attention(q, k, v, heads, want_lse=False, out=None, head_dim=128, wide_kerne
     S, _, ldk = _rows(k)
     S2, _, ldv = _rows(v)
     W = heads * head_dim
-    if S2 != S or q.shape[1] < W or k.shape[1] < W or v.shape[1] < W or head_dim not in (128, 448):
-        raise capi.MavlmError("attention: operand mismatch (head_dim must be 128 or 448)")
+    if S2 != S or q.shape[1] < W or k.shape[1] < W or v.shape[1] < W or head_dim not in (128, 224, 256, 448):
+        raise capi.MavlmError("attention: operand mismatch (head_dim must be 128, 224, 256 or 448)")
     if out is None:
         out = torch.empty((R, W), device=q.device, dtype=q.dtype)
     lse = torch.empty((heads, R), device=q.device, dtype=torch.float32) if want_lse else None
@@ -85,7 +85,8 @@ def attention(q, k, v, heads, want_lse=False, out=None, head_dim=128, wide_kerne
                                               dtype_code(q.dtype), stream_ptr()), "mavlm_attention")
     else:
         capi.check(capi.lib().mavlm_attention_hd(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(),
-                                                 out.stride(0), lp, R, S, heads, head_dim, 1.0 / math.sqrt(head_dim),
+                                                 out.stride(0), lp, R, S, heads, head_dim,
+                                                 1.0 / math.sqrt(head_dim) if scale is None else float(scale),
                                                  dtype_code(q.dtype), stream_ptr()), "mavlm_attention_hd")
     return out, lse
 

@@ -336,6 +336,9 @@ hipError_t mavlm_launch_attention_hd(const mavlm_attn_args& a, int head_dim, int
   const bool f16 = dtype == MAVLM_F16;
   if (head_dim == 448) return f16 ? launch_fwd_hd<F16, 448>(a, s) : launch_fwd_hd<BF16, 448>(a, s);
   if (head_dim == 128) return f16 ? launch_fwd_hd<F16, 128>(a, s) : launch_fwd_hd<BF16, 128>(a, s);
+  // 4-head encoder of the inactive MemoryFuser variant (MemoryFuser.py:12-19): hidden 1024 / 896 over nhead = 4
+  if (head_dim == 256) return f16 ? launch_fwd_hd<F16, 256>(a, s) : launch_fwd_hd<BF16, 256>(a, s);
+  if (head_dim == 224) return f16 ? launch_fwd_hd<F16, 224>(a, s) : launch_fwd_hd<BF16, 224>(a, s);
   return hipErrorInvalidValue;
 }
 

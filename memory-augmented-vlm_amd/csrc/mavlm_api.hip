@@ -320,7 +320,7 @@ int mavlm_attention_hd(const void* Q, int32_t ldq, const void* K, int32_t ldk, c
   if (!Q || !K || !V || !O || R <= 0 || S <= 0 || H <= 0 || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) ||
       ldq < H * head_dim || ldk < head_dim || ldv < head_dim)
     return MAVLM_E_ARG;
-  if (head_dim != 448 && head_dim != 128) return MAVLM_E_SHAPE;
+  if (head_dim != 448 && head_dim != 128 && head_dim != 256 && head_dim != 224) return MAVLM_E_SHAPE;
   mavlm_attn_args a;
   a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.lse2 = lse2;
   a.R = R; a.S = S; a.H = H; a.scale = scale;

@@ -28,14 +28,32 @@ with torch.no_grad():
     g = arch.GraphedVideoMemory(model, T, idx)
     tg = timed(lambda: g(x, mp, fp, model.image_newline))
     print(f"M={M} T={T} hipGraph, 1 in flight: {tg*1e3:7.3f} ms/video  {T/tg:9.0f} frames/s")
-    gs = [arch.GraphedVideoMemory(model, T, idx) for _ in range(2)]
-    streams = [torch.cuda.Stream() for _ in gs]
-    def two():
-        for gg, st in zip(gs, streams):
-            st.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(st):
-                gg(x, mp, fp, model.image_newline)
-        for st in streams:
-            torch.cuda.current_stream().wait_stream(st)
-    t2g = timed(two) / 2
-    print(f"M={M} T={T} hipGraph, 2 in flight: {t2g*1e3:7.3f} ms/video  {T/t2g:9.0f} frames/s")
+    for ng in (2, 3, 4, 6):
+        gs = [arch.GraphedVideoMemory(model, T, idx) for _ in range(ng)]
+        streams = [torch.cuda.Stream() for _ in gs]
+        def many():
+            for gg, st in zip(gs, streams):
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    gg(x, mp, fp, model.image_newline)
+            for st in streams:
+                torch.cuda.current_stream().wait_stream(st)
+        tg = timed(many) / ng
+        print(f"M={M} T={T} hipGraph, {ng} in flight: {tg*1e3:7.3f} ms/video  {T/tg:9.0f} frames/s")
+
+# per-kernel-kind breakdown of one video (HIP events around every launch)
+import ctypes
+from memory_augmented_vlm_amd import _capi as capi
+lib = capi.lib(); nk = len(capi.KERNEL_KINDS)
+ms = (ctypes.c_double * nk)(); ln = (ctypes.c_int64 * nk)(); fl = (ctypes.c_double * nk)(); by = (ctypes.c_double * nk)()
+with torch.no_grad():
+    lib.mavlm_prof_enable(1)
+    for _ in range(10):
+        arch.video_memory_tokens(model, x, idx, mp, fp, model.image_newline)
+    torch.cuda.synchronize()
+    capi.check(lib.mavlm_prof_read(ms, ln, fl, by, nk), "prof"); lib.mavlm_prof_enable(0)
+for i, name in enumerate(capi.KERNEL_KINDS):
+    if ln[i]:
+        print(f"{name:18s} launches/video {ln[i]/10:5.1f}  ms/video {ms[i]/10:7.3f}  avg {ms[i]/ln[i]*1e3:7.1f} us"
+              + (f"  {fl[i]/(ms[i]*1e-3)/1e12:6.1f} TF" if fl[i] else ""))
+print(f"sum {sum(ms)/10:.3f} ms/video")

@@ -377,8 +377,28 @@ def g8():
               "median", float(np.median([float(v) for v in env.values()])))
 
 
+# --------------------------------------------------------------------------- G9 (inactive variants)
+def g9():
+    from oracle import variants as V
+    MF = load_ref_file("MemoryFuser")
+    out = {}
+    cases = {"d512": (512, 150), "d1024": (1024, 300), "d896": (896, 70)}
+    for tag, (D, N) in cases.items():
+        w = V.fuser_weights(D, seed=91)
+        m = MF.MemoryFuser(D, num_layers=2, num_heads=4, device="cpu").eval()
+        m.load_state_dict({k: T(v) for k, v in w.items()}, strict=True)
+        x = O.bf16_round(O.hash_normal_like((2, N, D), 910))
+        y = m(T(x))
+        out[tag + "_out"] = y.numpy()[:, ::3, :].copy()
+        out[tag + "_sum"] = np.array(y.double().sum().item())
+    save("g9_variants.npz", meta=meta(cases={k: list(v) for k, v in cases.items()}, wseed=91, xseed=910, rowstride=3,
+                                      heads=4, layers=2), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g56", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g56", "g7", "g8", "g9"]
+    if "g9" in which:
+        g9()
     if "g8" in which:
         g8()
     if "g1" in which:

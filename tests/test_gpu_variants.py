@@ -1,0 +1,65 @@
+"""-m gpu: the inactive variants of the reference on the HIP kernels, against
+oracle/variants.py (pinned to the imported reference, tests/golden/g9_variants.npz)."""
+import numpy as np
+import pytest
+import torch
+
+import memory_augmented_vlm_amd  # noqa: F401
+from memory_augmented_vlm_amd import _capi as capi
+from memory_augmented_vlm_amd.model.memory_module.MemoryFuser import MemoryFuser
+from oracle import memory_path as O
+from oracle import variants as V
+from conftest import load_golden
+from gpu_util import to_dev, to_np, DT
+
+pytestmark = pytest.mark.gpu
+
+
+def _module(D, w, mode):
+    m = MemoryFuser(D, num_layers=2, num_heads=4).eval()
+    sd = m.state_dict()
+    assert sorted(sd) == sorted(w)                                   # the reference class's keys
+    m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()}, strict=True)
+    return m.cuda().to(DT[mode])
+
+
+@pytest.mark.parametrize("mode,D,N", [("bf16", 1024, 300), ("bf16", 896, 70), ("fp16", 512, 150), ("bf16", 512, 1)])
+def test_transformer_fuser_variant(mode, D, N):
+    """head_dim 256 / 224 / 128 on attention_hd.hip.  Gates: every layer teacher-forced on the oracle's input
+    <= 1e-3; the whole module against the oracle with a tolerance calibrated by the oracle's own fp32-vs-fp64
+    accumulation distance (the chain decorrelates in 16-bit storage)."""
+    w = V.fuser_weights(D, seed=7, grid=mode)
+    m = _module(D, w, mode)
+    x = O.rounder(mode)(O.hash_normal_like((2, N, D), 71))
+    got = m(to_dev(x, mode))
+    assert tuple(got.shape) == (2, N, D)
+    for b in range(2):
+        ref, stages = V.transformer_fuser(x[b], w, 4, mode, return_stages=True)
+        with O.accumulate_in(np.float64):
+            ref64 = V.transformer_fuser(x[b], w, 4, mode)
+        floor = O.rel_l2(ref64, ref)
+        assert O.rel_l2(to_np(got[b]), ref) < max(1e-3, 3 * floor), (O.rel_l2(to_np(got[b]), ref), floor)
+        for l, lyr in enumerate(m.transformer_encoder.layers):       # teacher-forced layers
+            y = m._layer(to_dev(stages[l], mode), lyr)
+            assert O.rel_l2(to_np(y), stages[l + 1]) < 1e-3, (l, O.rel_l2(to_np(y), stages[l + 1]))
+
+
+def test_transformer_fuser_variant_vs_reference_golden():
+    """HIP bf16 against the reference's fp32 output (g9): inside a bf16 envelope of 2e-2 (two post-norm layers)."""
+    z, meta = load_golden("g9_variants.npz")
+    for tag, (D, N) in meta["cases"].items():
+        w = V.fuser_weights(D, seed=meta["wseed"])
+        m = _module(D, w, "bf16")
+        x = O.bf16_round(O.hash_normal_like((2, N, D), meta["xseed"]))
+        got = to_np(m(to_dev(x)))
+        assert O.rel_l2(got[:, ::meta["rowstride"]], z[tag + "_out"]) < 2e-2, tag
+
+
+def test_transformer_fuser_variant_errors():
+    with pytest.raises(capi.MavlmError, match="head_dim"):
+        MemoryFuser(640)                                             # 160-wide heads: no kernel
+    m = _module(512, V.fuser_weights(512, seed=7), "bf16")
+    with pytest.raises(capi.MavlmError, match="not on a GPU"):
+        m(torch.zeros(1, 4, 512, dtype=torch.bfloat16))
+    with pytest.raises(capi.MavlmError):
+        m(torch.zeros(4, 512, device="cuda", dtype=torch.bfloat16))

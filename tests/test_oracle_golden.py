@@ -140,3 +140,15 @@ def test_g7_fullsize_samples(tag, M, F, steps):
         assert O.rel_l2(mem[::m["stride"]], z[f"{tag}_s{t}_sample"]) < 2 * TOL
         assert abs(np.linalg.norm(mem.astype(np.float64)) / float(z[f"{tag}_s{t}_norm"]) - 1) < 1e-5
         assert O.rel_l2(scores[-1], z[f"{tag}_s{t}_scores"]) < 2 * TOL
+
+
+def test_g9_transformer_fuser_variant_matches_reference():
+    """Inactive MemoryFuser variant (MemoryFuser.py:4-30): oracle/variants.py against the imported reference class."""
+    from oracle import variants as V
+    z, meta = load_golden("g9_variants.npz")
+    for tag, (D, N) in meta["cases"].items():
+        w = V.fuser_weights(D, seed=meta["wseed"])
+        x = O.bf16_round(O.hash_normal_like((2, N, D), meta["xseed"]))
+        for b in range(2):
+            y = V.transformer_fuser(x[b], w, heads=meta["heads"], mode="fp32", layers=meta["layers"])
+            assert O.rel_l2(y[::meta["rowstride"]], z[tag + "_out"][b]) < 2e-5, tag
