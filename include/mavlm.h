@@ -182,6 +182,19 @@ int mavlm_rowsum(const void* in, int32_t ld, int32_t rows, int32_t cols, float* 
  * 2 out = x > 0 ? dy : 0 (x = ReLU output).  llava_arch.py:134; MemoryController.py:64 */
 int mavlm_act(int32_t kind, const void* x, const void* dy, void* out, int64_t n, int32_t dtype, void* stream);
 
+/* ---- inactive variants of the reference (dead code there, forward only here) ----------------
+ * v[f,:] = mean over the P patch rows of x[f,:,:] (16-bit and/or fp32 output).  bigru.py:50; segment.py:268 */
+int mavlm_frame_mean(const void* x, void* out16, float* out32, int32_t F, int32_t P, int32_t D, int32_t dtype,
+                     void* stream);
+/* out[i] = cosine_similarity(v[i], v[i+1], eps) for i < n-1, v fp32 [n, D] (torch semantics:
+ * x.y / (max(|x|,eps) max(|y|,eps))).  segment.py:33 */
+int mavlm_adjacent_cosine(const float* v, float* out, int32_t n, int32_t D, float eps, void* stream);
+/* recurrent half of nn.GRU over F steps, ndir directions (1 or 2; direction 1 runs backwards): xg fp32 [F, ndir*3H] =
+ * W_ih x + b_ih (gate order r,z,n), whh 16-bit [ndir,3H,H], bhh fp32 [ndir,3H], out 16-bit [F, ndir*H]; H <= 512.
+ * bigru.py:26-32,68 */
+int mavlm_gru_sequence(const float* xg, const void* whh, const float* bhh, void* out, int32_t F, int32_t H, int32_t ndir,
+                       int32_t dtype, void* stream);
+
 /* tuning hook: force the GEMM kernel (128 = 128^2 tile, 256 = 256^2 non-persistent, 257 = 256^2 persistent;
  * 0 = automatic choice by grid size and epilogue).  Results are identical
  * up to fp32 summation order. */

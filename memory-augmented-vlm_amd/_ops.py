@@ -275,3 +275,43 @@ def act(kind, x, dy=None):
     capi.check(capi.lib().mavlm_act(kind, x.data_ptr(), dy.data_ptr() if dy is not None else 0, out.data_ptr(), x.numel(),
                                     dtype_code(x.dtype), stream_ptr()), "mavlm_act")
     return out
+
+
+# ---- inactive variants (SURVEY.md §8f rank 4) ----------------------------------------------------------------------
+def frame_mean(x, want_f32=False):
+    """[F,P,D] 16-bit -> per-frame mean over the patches: [F,D] in x.dtype (and fp32 when asked)."""
+    _need_gpu(x)
+    if x.dim() != 3 or not x.is_contiguous():
+        raise capi.MavlmError("frame_mean: contiguous [F,P,D] expected")
+    F, P, D = x.shape
+    o16 = torch.empty((F, D), device=x.device, dtype=x.dtype)
+    o32 = torch.empty((F, D), device=x.device, dtype=torch.float32) if want_f32 else None
+    capi.check(capi.lib().mavlm_frame_mean(x.data_ptr(), o16.data_ptr(), o32.data_ptr() if want_f32 else 0, F, P, D,
+                                           dtype_code(x.dtype), stream_ptr()), "mavlm_frame_mean")
+    return (o16, o32) if want_f32 else o16
+
+
+def adjacent_cosine(v_f32, eps):
+    """cosine_similarity(v[:-1], v[1:], eps) for fp32 rows -> fp32 [n-1]."""
+    _need_gpu(v_f32)
+    if v_f32.dim() != 2 or v_f32.dtype != torch.float32 or not v_f32.is_contiguous() or v_f32.shape[0] < 2:
+        raise capi.MavlmError("adjacent_cosine: contiguous fp32 [n>=2, D] expected")
+    n, D = v_f32.shape
+    out = torch.empty((n - 1,), device=v_f32.device, dtype=torch.float32)
+    capi.check(capi.lib().mavlm_adjacent_cosine(v_f32.data_ptr(), out.data_ptr(), n, D, float(eps), stream_ptr()),
+               "mavlm_adjacent_cosine")
+    return out
+
+
+def gru_sequence(xg_f32, whh, bhh_f32, hidden, ndir):
+    """Recurrent half of nn.GRU: xg fp32 [F, ndir*3H], whh [ndir,3H,H] 16-bit, bhh fp32 [ndir,3H] -> [F, ndir*H]."""
+    _need_gpu(xg_f32, whh, bhh_f32)
+    F = xg_f32.shape[0]
+    if xg_f32.shape != (F, ndir * 3 * hidden) or tuple(whh.shape) != (ndir, 3 * hidden, hidden) or \
+            tuple(bhh_f32.shape) != (ndir, 3 * hidden) or not (xg_f32.is_contiguous() and whh.is_contiguous()
+                                                              and bhh_f32.is_contiguous()):
+        raise capi.MavlmError("gru_sequence: operand mismatch")
+    out = torch.empty((F, ndir * hidden), device=whh.device, dtype=whh.dtype)
+    capi.check(capi.lib().mavlm_gru_sequence(xg_f32.data_ptr(), whh.data_ptr(), bhh_f32.data_ptr(), out.data_ptr(), F,
+                                             hidden, ndir, dtype_code(whh.dtype), stream_ptr()), "mavlm_gru_sequence")
+    return out

@@ -425,4 +425,25 @@ int mavlm_act(int32_t kind, const void* xin, const void* dy, void* out, int64_t 
   return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
 }
 
+// ---- inactive variants of the reference -------------------------------------------------------
+int mavlm_frame_mean(const void* xin, void* out16, float* out32, int32_t F, int32_t P, int32_t D, int32_t dtype,
+                     void* stream) {
+  if (!xin || (!out16 && !out32)) return MAVLM_E_ARG;
+  hipError_t e = mavlm_launch_frame_mean(xin, out16, out32, F, P, D, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int mavlm_adjacent_cosine(const float* v, float* out, int32_t n, int32_t D, float eps, void* stream) {
+  if (!v || !out) return MAVLM_E_ARG;
+  hipError_t e = mavlm_launch_adjacent_cosine(v, out, n, D, eps, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int mavlm_gru_sequence(const float* xg, const void* whh, const float* bhh, void* out, int32_t F, int32_t H, int32_t ndir,
+                       int32_t dtype, void* stream) {
+  if (!xg || !whh || !bhh || !out) return MAVLM_E_ARG;
+  hipError_t e = mavlm_launch_gru_seq(xg, whh, bhh, out, F, H, ndir, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_SHAPE : (int)e;
+}
+
 }  // extern "C"

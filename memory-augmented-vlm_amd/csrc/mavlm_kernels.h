@@ -68,6 +68,12 @@ hipError_t mavlm_launch_rowsum(const void* in, int ld, int rows, int cols, float
 hipError_t mavlm_launch_act(int kind, const void* x, const void* dy, void* out, size_t n, int dtype, hipStream_t s);
 hipError_t mavlm_launch_splitk_reduce(const float* part, int splits, size_t n, void* out, int dtype, hipStream_t s);
 
+// variants.hip (inactive variants of the reference)
+hipError_t mavlm_launch_frame_mean(const void* x, void* out16, float* out32, int F, int P, int D, int dtype, hipStream_t s);
+hipError_t mavlm_launch_adjacent_cosine(const float* v, float* out, int n, int D, float eps, hipStream_t s);
+hipError_t mavlm_launch_gru_seq(const float* xg, const void* whh, const float* bhh, void* out, int F, int H, int ndir,
+                                int dtype, hipStream_t s);
+
 // column sums of the normalised probabilities: part[h][k] = sum_q exp2(s*c - lse2[h][q])
 struct mavlm_colsum_args {
   const void* Q; int ldq;

@@ -391,8 +391,38 @@ def g9():
         y = m(T(x))
         out[tag + "_out"] = y.numpy()[:, ::3, :].copy()
         out[tag + "_sum"] = np.array(y.double().sum().item())
+    # TemporalGRUEncoder (bigru.py)
+    BG = load_ref_file("bigru")
+    gru_cases = {"gru896": (896, 448, 20, 6, False), "gru896pe": (896, 448, 9, 4, True), "gru1024": (1024, 512, 33, 3, False)}
+    for tag, (D, H, Fn, P, pe) in gru_cases.items():
+        w = V.gru_weights(D, H, seed=95)
+        m = BG.TemporalGRUEncoder(input_dim=D, hidden_size=H, use_positional_encoding=pe).eval()
+        sd = {k: T(v) for k, v in w.items()}
+        if pe:
+            sd["temporal_pe"] = m.temporal_pe
+        m.load_state_dict(sd, strict=True)
+        x = O.bf16_round(O.hash_normal_like((Fn, P, D), 950))
+        out[tag] = m(T(x)).numpy()
+    # scene segmentation / sampling (segment.py)
+    seg_cases = {"s40": (40, 10, 32, None, 0.3), "s120": (120, 15, 32, None, 0.3), "s100many": (100, 2, 32, None, 0.3),
+                 "s64k": (64, 8, 16, 5, 0.5), "s33": (33, 33, 32, None, 0.3), "s200": (200, 7, 32, None, 0.0)}
+    for tag, (Tn, slen, num, k, alpha) in seg_cases.items():
+        feats = T(V.scene_features(Tn, 4, 64, slen, 970))
+        means = feats.mean(dim=1)
+        sims = torch.cosine_similarity(means[:-1], means[1:], eps=1e-2)
+        b, depth = SEG.segment(means, alpha=alpha, k=k)
+        torch.manual_seed(4242)
+        idx = SEG.sample_scenes_priority(feats, sample_num=num, alpha=alpha, k=k)
+        out[tag + "_sims"] = sims.numpy()
+        out[tag + "_depth"] = depth.numpy()
+        out[tag + "_bounds"] = np.array(b, dtype=np.int64)
+        out[tag + "_idx"] = np.array(idx, dtype=np.int64)
+    out["uniform_segment"] = np.array([len(SEG.uniform_segment(torch.zeros(t, 1), d=32)) for t in range(1, 140)], dtype=np.int64)
+    out["uniform_segment_70"] = np.array(SEG.uniform_segment(torch.zeros(70, 1), d=32), dtype=np.int64)
     save("g9_variants.npz", meta=meta(cases={k: list(v) for k, v in cases.items()}, wseed=91, xseed=910, rowstride=3,
-                                      heads=4, layers=2), **out)
+                                      heads=4, layers=2, gru_cases={k: list(v) for k, v in gru_cases.items()},
+                                      gru_wseed=95, gru_xseed=950, seg_cases={k: list(v) for k, v in seg_cases.items()},
+                                      seg_seed=970, seg_rng=4242, seg_P=4, seg_D=64), **out)
 
 
 if __name__ == "__main__":

@@ -161,3 +161,23 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_scene_segmentation_host_logic_matches_reference():
+    """Inactive variant: the integer half of segment / sample_scenes_priority / uniform_segment
+    (segment.py:3-53,130-166,252-337) fed the reference's own similarity scores reproduces the reference's
+    boundaries, depth scores and sampled frame indices exactly (tests/golden/g9_variants.npz)."""
+    import torch
+    from memory_augmented_vlm_amd.model.memory_module import segment as S
+    z, meta = load_golden("g9_variants.npz")
+    for tag, (Tn, slen, num, k, alpha) in meta["seg_cases"].items():
+        sims = torch.from_numpy(z[tag + "_sims"].copy())
+        bounds, depth = S.segment_from_similarity(sims, Tn, alpha=alpha, k=k)
+        assert bounds == z[tag + "_bounds"].tolist(), tag
+        assert np.array_equal(depth.numpy(), z[tag + "_depth"]), tag
+        torch.manual_seed(meta["seg_rng"])
+        idx = S.scenes_priority_from_boundaries(bounds, depth, Tn, num)
+        assert idx == z[tag + "_idx"].tolist(), tag
+        assert len(idx) == min(num, Tn) and len(set(idx)) == len(idx)
+    assert [len(S.uniform_segment(t, 32)) for t in range(1, 140)] == z["uniform_segment"].tolist()
+    assert S.uniform_segment(70, 32) == z["uniform_segment_70"].tolist()

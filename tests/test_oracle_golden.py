@@ -152,3 +152,23 @@ def test_g9_transformer_fuser_variant_matches_reference():
         for b in range(2):
             y = V.transformer_fuser(x[b], w, heads=meta["heads"], mode="fp32", layers=meta["layers"])
             assert O.rel_l2(y[::meta["rowstride"]], z[tag + "_out"][b]) < 2e-5, tag
+
+
+def test_g9_gru_encoder_variant_matches_reference():
+    """Inactive TemporalGRUEncoder (bigru.py:14-75): oracle/variants.py against the imported reference class."""
+    from oracle import variants as V
+    z, meta = load_golden("g9_variants.npz")
+    for tag, (D, H, Fn, P, pe) in meta["gru_cases"].items():
+        w = V.gru_weights(D, H, seed=meta["gru_wseed"])
+        x = O.bf16_round(O.hash_normal_like((Fn, P, D), meta["gru_xseed"]))
+        y = V.gru_encoder(x, w, H, "fp32", use_pe=bool(pe))
+        assert O.rel_l2(y, z[tag]) < 1e-5, tag
+
+
+def test_g9_scene_similarity_oracle_matches_reference():
+    from oracle import variants as V
+    z, meta = load_golden("g9_variants.npz")
+    for tag, (Tn, slen, num, k, alpha) in meta["seg_cases"].items():
+        feats = V.scene_features(Tn, meta["seg_P"], meta["seg_D"], slen, meta["seg_seed"])
+        sims = V.adjacent_cosine(V.frame_means(feats))
+        np.testing.assert_allclose(sims, z[tag + "_sims"], atol=2e-6)
