@@ -495,3 +495,29 @@ def test_vision_projector_mlp2x_gelu_matches_oracle():
         build_vision_projector(types.SimpleNamespace(mm_projector_type="pooler", mm_hidden_size=8, hidden_size=8))
     with pytest.raises(ValueError):
         build_vision_projector(types.SimpleNamespace(mm_projector_type="bogus", mm_hidden_size=8, hidden_size=8))
+
+
+def test_config3_shape_long_video_ov7b_hipgraph():
+    """BASELINE configs[2] shape on one GPU: a 256-frame video in 32-frame chunks at the LLaVA-OneVision-7B width
+    (D = 3584, 8 heads of 448 -> wide-head kernels), the whole per-video update captured in ONE hipGraph.
+    Too large for the CPU oracle in a test: graph replay == eager launches bit for bit, FIFO of 8 memories, finite
+    tokens, and the frame-score identity sum_f score_f = H*R/P on every chunk."""
+    D, T = 3584, 256
+    cfg = O.PathConfig(hidden=D, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=19)
+    model, _ = _tiny_host(cfg, w)
+    idx = torch.arange(T)
+    mp = (torch.randn((10, D), device="cuda") * 0.02).bfloat16()
+    fp = (torch.randn((9, D), device="cuda") * 0.02).bfloat16()
+    x = to_dev(O.bf16_round(O.hash_normal_like((T, 196, D), 1900)))
+    rm = model.recurrent_memory_transformer
+    n_scores = len(rm.frame_attn_scores)
+    eager, info = arch.video_memory_tokens(model, x, idx, mp, fp, model.image_newline)
+    assert info["num_memories"] == 8 and len(rm.memory_cache) == 8
+    assert eager.shape == (arch.video_token_rows(T, 8), D) and torch.isfinite(eager.float()).all()
+    for s_ in rm.frame_attn_scores[n_scores:]:
+        assert s_.shape == (32,) and abs(float(s_.float().sum()) - 8 * 8) < 0.02 * 64
+    g = arch.GraphedVideoMemory(model, T, idx)
+    out = g(x, mp, fp, model.image_newline)
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
