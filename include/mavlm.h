@@ -129,6 +129,14 @@ int mavlm_linear(const void* A, int32_t lda, const void* W, int32_t ldw, const f
 /* ctx[R,H*128] = softmax(Q K^T / sqrt(128)) V per head; lse2 [H,R] fp32 optional.  MemoryController.py:51-54 */
 int mavlm_attention(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                     int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream);
+/* As mavlm_attention, with the split-KV path for grids too small to fill the chip (ceil(R/128)*H < 320 workgroups,
+ * e.g. the reference's default 8 memory tokens): the keys are split over up to 8 workgroup planes that write normalised
+ * fp32 partials into `ws` (mavlm_attention_ws_floats(R,S,H) floats; 0 = this shape does not split), a second kernel
+ * merges them.  The plan is a pure function of (R,S,H) - mavlm_step uses the same one, so both produce the same bits. */
+int64_t mavlm_attention_ws_floats(int32_t R, int32_t S, int32_t H);
+int mavlm_attention_ws(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
+                       int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, float* ws,
+                       int64_t ws_floats, int32_t dtype, void* stream);
 /* same for wide heads: head h occupies columns [h*head_dim, (h+1)*head_dim); head_dim 448 (LLaVA-OneVision-7B: hidden
  * 3584 / 8 heads, llava_arch.py:117-122), 128, or 256 / 224 (the 4-head TransformerEncoder of the inactive
  * MemoryFuser variant, memory_module/MemoryFuser.py:12-19; forward only, no column-sum pass) */

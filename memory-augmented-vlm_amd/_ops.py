@@ -79,10 +79,14 @@ def attention(q, k, v, heads, want_lse=False, out=None, head_dim=128, wide_kerne
     lse = torch.empty((heads, R), device=q.device, dtype=torch.float32) if want_lse else None
     lp = lse.data_ptr() if want_lse else 0
     if head_dim == 128 and not wide_kernel:
-        capi.check(capi.lib().mavlm_attention(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(),
-                                              out.stride(0), lp, R, S, heads,
-                                              1.0 / math.sqrt(128.0) if scale is None else float(scale),
-                                              dtype_code(q.dtype), stream_ptr()), "mavlm_attention")
+        lib = capi.lib()
+        nws = lib.mavlm_attention_ws_floats(R, S, heads)     # > 0: small grid, the keys are split (same plan as mavlm_step)
+        ws = torch.empty((nws,), device=q.device, dtype=torch.float32) if nws else None
+        capi.check(lib.mavlm_attention_ws(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(),
+                                          out.stride(0), lp, R, S, heads,
+                                          1.0 / math.sqrt(128.0) if scale is None else float(scale),
+                                          ws.data_ptr() if nws else 0, nws, dtype_code(q.dtype), stream_ptr()),
+                   "mavlm_attention_ws")
     else:
         capi.check(capi.lib().mavlm_attention_hd(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(),
                                                  out.stride(0), lp, R, S, heads, head_dim,

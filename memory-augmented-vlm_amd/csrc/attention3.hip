@@ -33,8 +33,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
                                                            const uint16_t* __restrict__ K, int ldk,
                                                            const uint16_t* __restrict__ V, int ldv,
                                                            uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
-                                                           int R, int S, int H, float c) {
+                                                           int R, int S, int H, float c, float* __restrict__ Opart,
+                                                           float* __restrict__ lse_part, int tps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // split-KV (small grids, tps > 0): blockIdx.y owns the keys [y*tps*64, (y+1)*tps*64) and writes a NORMALISED fp32
+  // partial + its log-sum-exp; attn_combine_kernel merges the splits.  The body below is unchanged: only the K/V
+  // base and the key count move.
+  const int split = blockIdx.y;
+  if (tps > 0) {
+    const int k0 = split * tps * KT3;
+    K += (size_t)k0 * ldk;
+    V += (size_t)k0 * ldv;
+    S = (S - k0 < tps * KT3) ? S - k0 : tps * KT3;
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -307,22 +318,99 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
   const float inv = 1.0f / l_tot;
   const int q = q0 + r;
   if (q < R) {
-    uint16_t* op = O + (size_t)q * ldo + h * HD3 + 4 * hh;
+    if (tps > 0) {
+      float* pp = Opart + ((size_t)split * R + q) * (H * HD3) + h * HD3 + 4 * hh;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+      for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *(u32x2*)(op + 32 * db + 8 * g) = pack4<T>(ot[db][4 * g] * inv, ot[db][4 * g + 1] * inv,
-                                                   ot[db][4 * g + 2] * inv, ot[db][4 * g + 3] * inv);
-    if (lse2 != nullptr && hh == 0) lse2[(size_t)h * R + q] = m_run * c + log2f(l_tot);
+        for (int g = 0; g < 4; ++g)
+          *(f32x4*)(pp + 32 * db + 8 * g) = f32x4{ot[db][4 * g] * inv, ot[db][4 * g + 1] * inv, ot[db][4 * g + 2] * inv,
+                                                  ot[db][4 * g + 3] * inv};
+      if (hh == 0) lse_part[((size_t)split * H + h) * R + q] = m_run * c + log2f(l_tot);
+    } else {
+      uint16_t* op = O + (size_t)q * ldo + h * HD3 + 4 * hh;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(u32x2*)(op + 32 * db + 8 * g) = pack4<T>(ot[db][4 * g] * inv, ot[db][4 * g + 1] * inv,
+                                                     ot[db][4 * g + 2] * inv, ot[db][4 * g + 3] * inv);
+      if (lse2 != nullptr && hh == 0) lse2[(size_t)h * R + q] = m_run * c + log2f(l_tot);
+    }
+  }
+}
+
+// O[q, h*128+d] = sum_s w_s Opart[s][q][h*128+d], w_s = 2^(lse_s - lse), lse = log2 sum_s 2^lse_s.  One wave per query
+// row, 16 columns per lane and 1024-column chunk (8 lanes per head).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ Opart, const float* __restrict__ lse_part,
+                                                           uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
+                                                           int R, int H, int ns) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= R) return;
+  const int W = H * HD3;
+  for (int c0 = 0; c0 < W; c0 += 1024) {
+    const int col = c0 + lane * 16;
+    if (col >= W) continue;
+    const int h = col / HD3;
+    float mx = -INFINITY;
+    for (int sp = 0; sp < ns; ++sp) mx = fmaxf(mx, lse_part[((size_t)sp * H + h) * R + q]);
+    float den = 0.f;
+    for (int sp = 0; sp < ns; ++sp) den += __builtin_amdgcn_exp2f(lse_part[((size_t)sp * H + h) * R + q] - mx);
+    const float lse = mx + log2f(den);
+    float acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int sp = 0; sp < ns; ++sp) {
+      const float wgt = __builtin_amdgcn_exp2f(lse_part[((size_t)sp * H + h) * R + q] - lse);
+      const float* pp = Opart + ((size_t)sp * R + q) * W + col;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const f32x4 x = *(const f32x4*)(pp + 4 * v);
+        acc[4 * v] += wgt * x[0]; acc[4 * v + 1] += wgt * x[1]; acc[4 * v + 2] += wgt * x[2]; acc[4 * v + 3] += wgt * x[3];
+      }
+    }
+    uint16_t* op = O + (size_t)q * ldo + col;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) *(u32x2*)(op + 4 * v) = pack4<T>(acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]);
+    if (lse2 != nullptr && (lane & 7) == 0) lse2[(size_t)h * R + q] = lse;
   }
 }
 
 }  // namespace
 
+// Split-KV plan: grids that fill less than ~60 % of the 512 workgroup slots (2 per CU) split the keys over
+// blockIdx.y.  Deterministic function of the shape: the fused step and the stand-alone operator take the same path.
+int mavlm_attention_splits(int R, int S, int H, int* tiles_per_split) {
+  const int items = ((R + 127) / 128) * H;
+  const int nt = (S + KT3 - 1) / KT3;
+  int ns = 1;
+  if (items < 320 && nt >= 16) {
+    ns = 512 / items;
+    if (ns > 8) ns = 8;
+    if (ns > nt / 8) ns = nt / 8;
+    if (ns < 2) ns = 1;
+  }
+  int tps = (nt + ns - 1) / ns;
+  ns = (nt + tps - 1) / tps;
+  if (tiles_per_split) *tiles_per_split = ns > 1 ? tps : 0;
+  return ns;
+}
+
+size_t mavlm_attention_split_ws_floats(int R, int S, int H) {
+  const int ns = mavlm_attention_splits(R, S, H, nullptr);
+  return ns > 1 ? (size_t)ns * R * H * HD3 + (size_t)ns * H * R : 0;
+}
+
 hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStream_t s) {
   const float c = a.scale * 1.44269504088896340736f;
-  dim3 grid(((a.R + 127) / 128) * a.H);
+  int tps = 0;
+  int ns = a.split_ws != nullptr ? mavlm_attention_splits(a.R, a.S, a.H, &tps) : 1;
+  if (ns <= 1) { ns = 1; tps = 0; }
+  float* opart = a.split_ws;
+  float* lpart = ns > 1 ? a.split_ws + (size_t)ns * a.R * a.H * HD3 : nullptr;
+  dim3 grid(((a.R + 127) / 128) * a.H, ns);
   static bool done[2] = {false, false};
   if (dtype == MAVLM_F16) {
     if (!done[1]) {
@@ -331,7 +419,10 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
       done[1] = true;
     }
     hipLaunchKernelGGL(attn_fwd3_kernel<F16>, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
-                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c);
+                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps);
+    if (ns > 1)
+      hipLaunchKernelGGL(attn_combine_kernel<F16>, dim3((a.R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
+                         a.lse2, a.R, a.H, ns);
   } else {
     if (!done[0]) {
       hipError_t e = hipFuncSetAttribute((const void*)attn_fwd3_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN3_LDS);
@@ -339,7 +430,10 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
       done[0] = true;
     }
     hipLaunchKernelGGL(attn_fwd3_kernel<BF16>, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
-                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c);
+                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps);
+    if (ns > 1)
+      hipLaunchKernelGGL(attn_combine_kernel<BF16>, dim3((a.R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
+                         a.lse2, a.R, a.H, ns);
   }
   return hipGetLastError();
 }

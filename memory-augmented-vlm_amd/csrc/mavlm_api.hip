@@ -15,7 +15,7 @@ struct mavlm_ctx {
   bool has_w = false, has_b = false;
   int steps = 0;
   // workspace carve (byte offsets)
-  size_t o_kv, o_q, o_ctx, o_a, o_h, o_pre, o_mA, o_mB, o_lse, o_part, total;
+  size_t o_kv, o_q, o_ctx, o_a, o_h, o_pre, o_mA, o_mB, o_lse, o_part, o_split, total;
 };
 
 namespace {
@@ -57,6 +57,13 @@ void carve(mavlm_ctx* x) {
   x->o_mB = o;   o += al(R * D * 2);
   x->o_lse = o;  o += al(H * R * 4);
   x->o_part = o; o += al(H * S * 4);
+  // split-KV partials of the attention (small grids only: mavlm_attention_splits): worst case over the key count
+  x->o_split = o;
+  if (!wide_heads(c)) {
+    const size_t items = ((R + 127) / 128) * H;
+    const size_t cap = items < 320 ? (512 / items > 8 ? 8 : 512 / items) : 0;
+    if (cap >= 2) o += al(cap * (R * H * 128 + H * R) * 4);
+  }
   x->total = o;
 }
 
@@ -85,6 +92,7 @@ int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const 
   mavlm_attn_args a;
   a.Q = ws(x, x->o_q); a.ldq = Dp; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = ws(x, x->o_ctx); a.ldo = Dp;
   a.lse2 = lse2; a.R = R; a.S = S; a.H = H; a.scale = attn_scale(c);
+  a.split_ws = (!wide_heads(c) && x->total > x->o_split) ? (float*)ws(x, x->o_split) : nullptr;
   if (wide_heads(c)) {
     MAVLM_TRY(mavlm_launch_attention_hd(a, c.hidden / c.heads, dt, s));
   } else {
@@ -310,6 +318,25 @@ int mavlm_attention(const void* Q, int32_t ldq, const void* K, int32_t ldk, cons
   mavlm_attn_args a;
   a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.lse2 = lse2;
   a.R = R; a.S = S; a.H = H; a.scale = scale;
+  hipError_t e = mavlm_launch_attention(a, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int64_t mavlm_attention_ws_floats(int32_t R, int32_t S, int32_t H) {
+  return (R > 0 && S > 0 && H > 0) ? (int64_t)mavlm_attention_split_ws_floats(R, S, H) : 0;
+}
+
+int mavlm_attention_ws(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
+                       int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, float* ws,
+                       int64_t ws_floats, int32_t dtype, void* stream) {
+  mavlm_attn_args a;
+  a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.lse2 = lse2;
+  a.R = R; a.S = S; a.H = H; a.scale = scale;
+  if (R > 0 && S > 0 && H > 0) {
+    const int64_t need = (int64_t)mavlm_attention_split_ws_floats(R, S, H);
+    if (need > 0 && (!ws || ws_floats < need)) return MAVLM_E_ARG;     // the plan is part of the result: no silent change
+    a.split_ws = need > 0 ? ws : nullptr;
+  }
   hipError_t e = mavlm_launch_attention(a, dtype, (hipStream_t)stream);
   return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
 }

@@ -35,8 +35,12 @@ struct mavlm_attn_args {
   float* lse2;                   // [H, R] fp32 (log2-domain log-sum-exp) or null
   int R, S, H;
   float scale;                   // 1/sqrt(head_dim)
+  float* split_ws = nullptr;     // mavlm_attention_split_ws_floats(R,S,H) floats, or null = never split the keys
 };
 hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream_t s);
+// split-KV plan for grids too small to fill the chip (attention3.hip): number of key splits (1 = none)
+int mavlm_attention_splits(int R, int S, int H, int* tiles_per_split);
+size_t mavlm_attention_split_ws_floats(int R, int S, int H);
 // software-pipelined LDS-DMA variant (attention3.hip); mavlm_launch_attention dispatches to it
 hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStream_t s);
 extern int g_mavlm_attn_impl;   // 0 = auto, 2 = register-staged kernel, 3 = pipelined kernel (tuning hook)

@@ -335,6 +335,21 @@ def kernel_tiling(head_dim: int) -> Tuple[int, int]:
     return (KV_TILE, WAVE_ROWS) if head_dim <= 128 else (32, 16)
 
 
+def split_plan(R: int, S: int, heads: int) -> Tuple[int, int]:
+    """(number of key splits, tiles per split) of the head_dim<=128 attention kernel - mirrors
+    mavlm_attention_splits (csrc/attention3.hip): grids of fewer than 320 workgroups split the keys."""
+    items = -(-R // 128) * heads
+    nt = -(-S // KV_TILE)
+    ns = 1
+    if items < 320 and nt >= 16:
+        ns = min(8, 512 // items, nt // 8)
+        if ns < 2:
+            ns = 1
+    tps = -(-nt // ns)
+    ns = -(-nt // tps)
+    return ns, (tps if ns > 1 else 0)
+
+
 def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mode: str = "fp32",
                     want_colsum: bool = False, want_probs: bool = False, kv_tile: Optional[int] = None,
                     wave_rows: Optional[int] = None):
@@ -367,22 +382,40 @@ def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mod
             l = p.sum(axis=1, keepdims=True, dtype=F32)
             acc = _mm(p, V[:, sl])
         else:
-            m = np.full((R, 1), -1e30, dtype=F32)
-            l = np.zeros((R, 1), dtype=F32)
-            acc = np.zeros((R, d), dtype=F32)
-            for k0 in range(0, Lk, kv_tile):
-                st = s[:, k0:k0 + kv_tile]
-                cand = np.maximum(m, st.max(axis=1, keepdims=True))
-                need = ((cand - m) * F32(1.4426950408889634) > F32(RESCALE_LOG2)).reshape(-1)
-                pad = (-R) % wave_rows
-                grp = np.concatenate([need, np.zeros(pad, bool)]).reshape(-1, wave_rows).any(axis=1)
-                move = np.repeat(grp, wave_rows)[:R].reshape(R, 1)
-                m_new = np.where(move, cand, m).astype(F32)
-                alpha = np.exp(m - m_new, dtype=F32)
-                pt = np.exp(st - m_new, dtype=F32)
-                l = l * alpha + pt.sum(axis=1, keepdims=True, dtype=F32)
-                acc = acc * alpha + _mm(r(pt), V[k0:k0 + kv_tile, sl])       # P rounded as the MFMA operand
-                m = m_new
+            def run(k_lo, k_hi):
+                m = np.full((R, 1), -1e30, dtype=F32)
+                l = np.zeros((R, 1), dtype=F32)
+                acc = np.zeros((R, d), dtype=F32)
+                for k0 in range(k_lo, k_hi, kv_tile):
+                    st = s[:, k0:min(k0 + kv_tile, k_hi)]
+                    cand = np.maximum(m, st.max(axis=1, keepdims=True))
+                    need = ((cand - m) * F32(1.4426950408889634) > F32(RESCALE_LOG2)).reshape(-1)
+                    pad = (-R) % wave_rows
+                    grp = np.concatenate([need, np.zeros(pad, bool)]).reshape(-1, wave_rows).any(axis=1)
+                    move = np.repeat(grp, wave_rows)[:R].reshape(R, 1)
+                    m_new = np.where(move, cand, m).astype(F32)
+                    alpha = np.exp(m - m_new, dtype=F32)
+                    pt = np.exp(st - m_new, dtype=F32)
+                    l = l * alpha + pt.sum(axis=1, keepdims=True, dtype=F32)
+                    acc = acc * alpha + _mm(r(pt), V[k0:min(k0 + kv_tile, k_hi), sl])   # P rounded as the MFMA operand
+                    m = m_new
+                return acc, m, l
+
+            ns, tps = split_plan(R, Lk, heads) if (d <= 128 and kv_tile == KV_TILE) else (1, 0)
+            if ns == 1:
+                acc, m, l = run(0, Lk)
+            else:
+                # split-KV (attention3.hip, small grids): each split yields a normalised fp32 partial + its
+                # log-sum-exp; the merge weights them by 2^(lse_s - lse)
+                parts = []
+                for sp in range(ns):
+                    a_, m_, l_ = run(sp * tps * kv_tile, min((sp + 1) * tps * kv_tile, Lk))
+                    parts.append(((a_ / l_).astype(F32), (m_ + np.log(l_)).astype(F32)))
+                mx = np.maximum.reduce([p_[1] for p_ in parts])
+                den = sum(np.exp(p_[1] - mx, dtype=F32) for p_ in parts)
+                lse_t = (mx + np.log(den)).astype(F32)
+                acc = sum(np.exp(p_[1] - lse_t, dtype=F32) * p_[0] for p_ in parts).astype(F32)
+                m, l = lse_t, np.ones((R, 1), dtype=F32)
         ctx[:, sl] = acc / l                                                 # :53
         lse = m + np.log(l)
         lse2[h] = (lse / F32(math.log(2.0))).reshape(-1)

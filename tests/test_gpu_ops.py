@@ -103,6 +103,39 @@ def test_attention_vs_oracle(mode, R, S, H, attn_impl):
     assert abs(float(part.sum()) - H * R) < 1e-3 * H * R
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("R,S,H", [(300, 2000, 2), (1568, 6272, 8), (100, 64 * 16, 1), (196, 64 * 40 + 17, 4)])
+def test_attention_split_kv_small_grids(mode, R, S, H):
+    """Grids of fewer than 320 workgroups split the keys over blockIdx.y (normalised fp32 partials + merge kernel):
+    same gates as the unsplit kernel against the oracle; the split result stays within 16-bit rounding of the
+    unsplit one; the log-sum-exp it hands to the column-sum pass and to the backward is the merged one."""
+    lib = capi.lib()
+    assert lib.mavlm_attention_ws_floats(R, S, H) > 0 and lib.mavlm_attention_ws_floats(12544, 6272, 8) == 0
+    r = O.rounder(mode)
+    q = r(O.hash_normal_like((R, H * 128), 21))
+    k = r(O.hash_normal_like((S, H * 128), 22))
+    v = r(O.hash_normal_like((S, H * 128), 23))
+    ctx, lse2, col = _attn_oracle(q, k, v, H, mode)
+    dq, dk, dv = to_dev(q, mode), to_dev(k, mode), to_dev(v, mode)
+    got, lse = ops.attention(dq, dk, dv, H, want_lse=True)
+    assert O.rel_l2(to_np(got), ctx) < TOL
+    np.testing.assert_allclose(to_np(lse), lse2, rtol=0, atol=2e-3)
+    part = ops.attention_colsum(dq, dk, lse, H)
+    assert O.rel_l2(to_np(part), col) < TOL and abs(float(part.sum()) - H * R) < 1e-3 * H * R
+    # the unsplit kernel through the plain entry point (never splits)
+    plain = torch.empty_like(got)
+    lse_p = torch.empty_like(lse)
+    capi.check(lib.mavlm_attention(dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(), dv.stride(0),
+                                   plain.data_ptr(), plain.stride(0), lse_p.data_ptr(), R, S, H, 1.0 / math.sqrt(128.0),
+                                   ops.dtype_code(dq.dtype), ops.stream_ptr()), "mavlm_attention")
+    assert O.rel_l2(to_np(got), to_np(plain)) < (3e-3 if mode == "bf16" else 5e-4)
+    np.testing.assert_allclose(to_np(lse), to_np(lse_p), rtol=0, atol=1e-4)
+    # a too-small workspace is an error, not a silent change of path
+    assert lib.mavlm_attention_ws(dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(), dv.stride(0),
+                                  plain.data_ptr(), plain.stride(0), 0, R, S, H, 1.0 / math.sqrt(128.0), 0, 0,
+                                  ops.dtype_code(dq.dtype), ops.stream_ptr()) == capi.E_ARG
+
+
 def test_attention_strided_kv_and_identity_v(attn_impl):
     """K/V as column slices of a wider [S, 4D] buffer (how the step lays them out) and V = one-hot columns:
     ctx then equals the probabilities themselves - catches any key/column permutation error in the P.V MFMA."""
