@@ -132,8 +132,31 @@ def pad_heads_in(t, heads, hd):
     return torch.nn.functional.pad(t.reshape(t.shape[0], heads, hd), (0, 128 - hd)).reshape(t.shape[0], heads * 128)
 
 
-def attention_block(attn, q_in, kv_in, want_stats=False):
-    """`Attention.forward` (MemoryController.py:47-56) on 2-D [rows, D] operands; returns (out, (q, k, lse) | None)."""
+def packed_kv_params(attns):
+    """[k_0; v_0; k_1; v_1; ...] projection weights / biases of several Attention modules, heads zero-padded to 128
+    rows each - the packed layout of the inference step (w_kv_seg / w_kv_evo, MemoryController._Engine.pack), built
+    with autograd-transparent ops so the gradients flow back to the individual nn.Linear parameters."""
+    ws, bs = [], []
+    for a in attns:
+        H, hd = a.num_attention_heads, a.attention_head_size
+        for lin in (a.k_proj, a.v_proj):
+            ws.append(pad_heads_out(lin.weight, H, hd))
+            bs.append(pad_heads_out(lin.bias, H, hd))
+    return torch.cat(ws, dim=0), torch.cat(bs, dim=0)
+
+
+def project_kv(attns, x):
+    """K/V of `x` for all `attns` in ONE GEMM (as mavlm_step does): returns [(k, v), ...] column views of the packed
+    [rows, 2*len(attns)*H*128] output."""
+    w, b = packed_kv_params(attns)
+    kv = LinearFn.apply(x, w, b, ACT_NONE)
+    Dp = attns[0].num_attention_heads * 128
+    return [(kv[:, (2 * i) * Dp:(2 * i + 1) * Dp], kv[:, (2 * i + 1) * Dp:(2 * i + 2) * Dp]) for i in range(len(attns))]
+
+
+def attention_block(attn, q_in, k, v, want_stats=False):
+    """`Attention.forward` (MemoryController.py:47-56) on a 2-D [rows, D] query input and already projected K/V
+    (padded-head layout; may be column views); returns (out, (q, k, lse) | None)."""
     H = attn.num_attention_heads
     hd = attn.attention_head_size
     if hd > 128:
@@ -141,8 +164,6 @@ def attention_block(attn, q_in, kv_in, want_stats=False):
                                   "backward attention kernel is head_dim-128; inference supports it")
     scale = ops.attn_scale(hd)
     q = LinearFn.apply(q_in, pad_heads_out(attn.q_proj.weight, H, hd), pad_heads_out(attn.q_proj.bias, H, hd), ACT_NONE)
-    k = LinearFn.apply(kv_in, pad_heads_out(attn.k_proj.weight, H, hd), pad_heads_out(attn.k_proj.bias, H, hd), ACT_NONE)
-    v = LinearFn.apply(kv_in, pad_heads_out(attn.v_proj.weight, H, hd), pad_heads_out(attn.v_proj.bias, H, hd), ACT_NONE)
     ctxv, lse = AttentionFn.apply(q, k, v, H, scale)
     d = attn.residual
     out = DenseResidualNormFn.apply(ctxv, pad_heads_in(d.dense.weight, H, hd), d.dense.bias, q_in, d.layernorm.weight,

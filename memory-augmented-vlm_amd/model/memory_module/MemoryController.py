@@ -281,6 +281,7 @@ class TransformerProjector(nn.Module):
         self.compute_frame_scores = True      # API parity default; False skips the column-sum pass
         self._memory_cache: List[torch.Tensor] = []
         self._cache_mode = "engine"           # "engine": ring views (inference); "autograd": graph tensors (training)
+        self._evo_kv = []                     # training path: (K, V) projections of the cached memories
         self._engine = None
         self._fuser_refs = None               # (memory_fuser, token_type_embedding) bound by the glue
 
@@ -296,6 +297,7 @@ class TransformerProjector(nn.Module):
             raise capi.MavlmError("memory_cache can only be reset to [] from outside (llava_arch.py:532); "
                                   "its entries are views into the module's ring buffer")
         self._memory_cache = value
+        self._evo_kv = []
         self._cache_mode = "engine"
         if self._engine is not None:
             capi.check(capi.lib().mavlm_reset(self._engine.ctx), "mavlm_reset")
@@ -338,6 +340,7 @@ class TransformerProjector(nn.Module):
         if getattr(self, "_engine", None) is not None:
             self._engine = None           # also ends a video in progress: its FIFO lived in the old engine
             self._memory_cache = []
+            self._evo_kv = []
         return out
 
     def spawn_replica(self) -> "TransformerProjector":
@@ -349,6 +352,7 @@ class TransformerProjector(nn.Module):
         r = copy.copy(self)                    # shallow: _parameters / _modules dicts are shared
         r._engine = None
         r._memory_cache = []
+        r._evo_kv = []
         r.frame_attn_scores = []
         return r
 
@@ -395,22 +399,34 @@ class TransformerProjector(nn.Module):
         R = self.num_memory_tokens * P
         dt = image_features.dtype
         frames = image_features.detach().reshape(F * P, D)         # frame features carry no gradient (llava_arch.py:302)
+        cap = int(getattr(self.config, "cache_cap", 10))
         if self._memory_cache:                                      # :125-127, 89-97
+            # K/V of a cached memory are row-independent: each memory is projected ONCE, when it is the newest (one
+            # packed GEMM, as mavlm_step does into its evo_kv ring), and the projections are concatenated
+            evo = self.memory_update_attention
             last = self._memory_cache[-1].reshape(R, D)
-            kv = torch.cat(self._memory_cache, dim=0).reshape(-1, D)
-            m, _ = ag.attention_block(self.memory_update_attention, last, kv)
+            while len(self._evo_kv) < len(self._memory_cache):
+                mem = self._memory_cache[len(self._evo_kv)].reshape(R, D)
+                self._evo_kv.append(ag.project_kv([evo], mem)[0])
+            k = torch.cat([kv_[0] for kv_ in self._evo_kv], dim=0)
+            v = torch.cat([kv_[1] for kv_ in self._evo_kv], dim=0)
+            m, _ = ag.attention_block(evo, last, k, v)
         else:
+            self._evo_kv = []
             m = (self.initial_memory + self.memory_pos_embed).to(dt).reshape(R, D)      # :123-124
         stats = None
+        atts = [layer.memory_segment_fusion_attention for layer in self.layers]
+        kvs = ag.project_kv(atts, frames)                           # chunk K/V of all layers: one GEMM
         for li, layer in enumerate(self.layers):                   # :132-133
             last_layer = li == len(self.layers) - 1
-            a, stats = ag.attention_block(layer.memory_segment_fusion_attention, m, frames,
+            a, stats = ag.attention_block(atts[li], m, kvs[li][0], kvs[li][1],
                                           want_stats=last_layer and self.compute_frame_scores)
             m = ag.mlp_block(layer, a)
         self._memory_cache.append(m.reshape(self.num_memory_tokens, P, D))             # :152
-        cap = int(getattr(self.config, "cache_cap", 10))
         if len(self._memory_cache) > cap:
-            self._memory_cache = self._memory_cache[-cap:]
+            drop = len(self._memory_cache) - cap
+            self._memory_cache = self._memory_cache[drop:]
+            self._evo_kv = self._evo_kv[drop:]
         if stats is not None:                                      # :135-139,156 (detached statistics)
             with torch.no_grad():
                 q, k, lse = stats

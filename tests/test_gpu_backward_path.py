@@ -42,9 +42,13 @@ def _hip_grads(rm, segs, cots, mode):
     return float(loss.detach()), out, [c.detach() for c in cache]
 
 
-@pytest.mark.parametrize("mode,H,hd,frames", [("bf16", 8, 128, [2, 1, 2]), ("fp16", 2, 64, [1, 2]), ("bf16", 8, 112, [2, 1])])
-def test_training_forward_bit_identical_to_inference(mode, H, hd, frames):
-    cfg = O.PathConfig(hidden=H * hd, heads=H, mem_tokens=4, depth=2)
+@pytest.mark.parametrize("mode,H,hd,frames,M", [("bf16", 8, 128, [2, 1, 2], 4), ("fp16", 2, 64, [1, 2], 4),
+                                                  ("bf16", 8, 112, [2, 1], 4), ("bf16", 8, 128, [32, 32, 7], 16)])
+def test_training_forward_bit_identical_to_inference(mode, H, hd, frames, M):
+    """The last case is large enough for every kernel choice of the bench shape to occur (256^2 / persistent GEMMs on
+    the packed K/V projection, split-KV attention off and on): the training path takes the same kernels because it
+    issues the same launches - packed K/V GEMM per chunk, one packed projection per cached memory."""
+    cfg = O.PathConfig(hidden=H * hd, heads=H, mem_tokens=M, depth=2)
     w = O.make_weights(cfg, seed=5)
     rm = make_projector(cfg, w, mode)
     segs = _segs(cfg, frames, 900)
