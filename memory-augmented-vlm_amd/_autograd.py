@@ -149,7 +149,7 @@ def project_kv(attns, x):
     """K/V of `x` for all `attns` in ONE GEMM (as mavlm_step does): returns [(k, v), ...] column views of the packed
     [rows, 2*len(attns)*H*128] output."""
     w, b = packed_kv_params(attns)
-    kv = LinearFn.apply(x, w, b, ACT_NONE)
+    kv = LinearFn.apply(x, w.to(x.dtype), b, ACT_NONE)
     Dp = attns[0].num_attention_heads * 128
     return [(kv[:, (2 * i) * Dp:(2 * i + 1) * Dp], kv[:, (2 * i + 1) * Dp:(2 * i + 2) * Dp]) for i in range(len(attns))]
 
@@ -163,20 +163,22 @@ def attention_block(attn, q_in, k, v, want_stats=False):
         raise NotImplementedError("training the memory path with head_dim > 128 (OV-7B shape) is not implemented: the "
                                   "backward attention kernel is head_dim-128; inference supports it")
     scale = ops.attn_scale(hd)
-    q = LinearFn.apply(q_in, pad_heads_out(attn.q_proj.weight, H, hd), pad_heads_out(attn.q_proj.bias, H, hd), ACT_NONE)
+    dt = q_in.dtype      # parameters kept in fp32 (master weights) are cast per use; the cast is autograd-transparent
+    q = LinearFn.apply(q_in, pad_heads_out(attn.q_proj.weight, H, hd).to(dt), pad_heads_out(attn.q_proj.bias, H, hd),
+                       ACT_NONE)
     ctxv, lse = AttentionFn.apply(q, k, v, H, scale)
     d = attn.residual
-    out = DenseResidualNormFn.apply(ctxv, pad_heads_in(d.dense.weight, H, hd), d.dense.bias, q_in, d.layernorm.weight,
-                                    d.layernorm.bias, d.layernorm.eps)
+    out = DenseResidualNormFn.apply(ctxv, pad_heads_in(d.dense.weight, H, hd).to(dt), d.dense.bias, q_in,
+                                    d.layernorm.weight, d.layernorm.bias, d.layernorm.eps)
     return out, ((q, k, lse) if want_stats else None)
 
 
 def mlp_block(layer, a):
     """TransformerLayer's MLP + Residual (MemoryController.py:63-67,71)."""
     up = layer.mlp[0]
-    h = LinearFn.apply(a, up.weight, up.bias, ACT_RELU)
+    h = LinearFn.apply(a, up.weight.to(a.dtype), up.bias, ACT_RELU)
     d = layer.residual
-    return DenseResidualNormFn.apply(h, d.dense.weight, d.dense.bias, a, d.layernorm.weight, d.layernorm.bias,
+    return DenseResidualNormFn.apply(h, d.dense.weight.to(a.dtype), d.dense.bias, a, d.layernorm.weight, d.layernorm.bias,
                                      d.layernorm.eps)
 
 
@@ -184,8 +186,8 @@ def fuser_mlp(fuser, x, type_row=None):
     """memory_fuser = Linear GELU Linear (llava_arch.py:132-136,546); `type_row` (token_type_embedding row 0) rides in
     the second bias so the add costs no extra rounding (as the inference epilogue, :548-553)."""
     shp = x.shape
-    u = LinearFn.apply(x.reshape(-1, shp[-1]), fuser[0].weight, fuser[0].bias, ACT_GELU)
+    u = LinearFn.apply(x.reshape(-1, shp[-1]), fuser[0].weight.to(x.dtype), fuser[0].bias, ACT_GELU)
     b2 = fuser[2].bias.float()
     if type_row is not None:
         b2 = b2 + type_row.float()
-    return LinearFn.apply(u, fuser[2].weight, b2, ACT_NONE).reshape(shp)
+    return LinearFn.apply(u, fuser[2].weight.to(x.dtype), b2, ACT_NONE).reshape(shp)

@@ -197,3 +197,24 @@ def test_full_token_block_gradients():
         checked += 1
     assert checked >= len(ref) - 4
     assert "token_type_embedding.weight" in named and "image_newline" in named
+
+
+def test_fp32_master_parameters_with_16bit_activations():
+    """Parameters kept in fp32 (master weights), activations in bf16: the training path casts per use (autograd-
+    transparent), runs the same kernels, and returns fp32 gradients equal to the bf16-parameter run up to the one
+    rounding of the gradient itself."""
+    cfg = O.PathConfig(hidden=256, heads=2, mem_tokens=3, depth=2)
+    w = O.make_weights(cfg, seed=29)            # values on the bf16 grid: both runs see identical weights
+    segs = _segs(cfg, [2, 1], 990)
+    cots = _cotangents(cfg, 2, 995, 0.05)
+    rm16 = make_projector(cfg, w, "bf16").train()
+    _, g16, cache16 = _hip_grads(rm16, segs, cots, "bf16")
+    rm32 = make_projector(cfg, w, "bf16").float().train()
+    _, g32, cache32 = _hip_grads(rm32, segs, cots, "bf16")
+    for a, b in zip(cache16, cache32):
+        assert torch.equal(a, b)
+    for name in g16:
+        p = dict(rm32.named_parameters())[name]
+        assert p.grad.dtype == torch.float32
+        if g16[name] is not None and not name.endswith("k_proj.bias"):
+            assert O.rel_l2(g16[name], g32[name]) < 4e-3, name
