@@ -131,18 +131,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
   }
 }
 
-// out[c] = sum_p part[p][c]; a workgroup owns 64 columns, its 4 waves take every 4th partial row (fixed order)
-__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, int nparts, int cols,
-                                                              float* __restrict__ out) {
-  __shared__ float red[4][64];
+// out[c] = sum_p part[p][c]; a workgroup owns 64 columns, its 16 waves take every 16th partial row (fixed order:
+// deterministic), then add up through LDS
+__global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __restrict__ part, int nparts, int cols,
+                                                               float* __restrict__ out) {
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
-  float s = 0.f;
-  if (c < cols)
-    for (int p = w; p < nparts; p += 4) s += part[(size_t)p * cols + c];
-  red[w][lane] = s;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < cols) {
+    int p = w;
+    for (; p + 16 < nparts; p += 32) {       // two independent chains per thread
+      s0 += part[(size_t)p * cols + c];
+      s1 += part[(size_t)(p + 16) * cols + c];
+    }
+    if (p < nparts) s0 += part[(size_t)p * cols + c];
+  }
+  red[w][lane] = s0 + s1;
   __syncthreads();
-  if (w == 0 && c < cols) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (w == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][lane];
+    out[c] = t;
+  }
 }
 
 // 64x64 tile through LDS; 8-byte global accesses on both sides.
@@ -274,7 +286,7 @@ hipError_t mavlm_launch_layernorm_bwd(const void* dy, const float* x, const void
   if (e != hipSuccess) return e;
   // partial rows are [workgroup][2][D]: view as [LNB_BLOCKS][2D] and sum down the columns; dgamma = cols [0,D), dbeta = [D,2D)
   // of a 2D-wide result; write through a small two-step so that dgamma / dbeta may be separate allocations
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, part, LNB_BLOCKS, 2 * D,
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, s, part, LNB_BLOCKS, 2 * D,
                      part + (size_t)LNB_BLOCKS * 2 * D);
   e = hipMemcpyAsync(dgamma, part + (size_t)LNB_BLOCKS * 2 * D, sizeof(float) * D, hipMemcpyDeviceToDevice, s);
   if (e != hipSuccess) return e;
