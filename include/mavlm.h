@@ -203,6 +203,9 @@ int mavlm_adjacent_cosine(const float* v, float* out, int32_t n, int32_t D, floa
 int mavlm_gru_sequence(const float* xg, const void* whh, const float* bhh, void* out, int32_t F, int32_t H, int32_t ndir,
                        int32_t dtype, void* stream);
 
+/* tuning hook: 1 = attention backward computes dK and dV in ONE kernel (7 instead of 8 recompute products, 512-register
+ * waves at one workgroup per CU); 0 = separate dK / dV kernels.  Same rounding points. */
+int mavlm_set_attention_bwd_fused(int32_t on);
 /* tuning hook: force the GEMM kernel (128 = 128^2 tile, 256 = 256^2 non-persistent, 257 = 256^2 persistent;
  * 0 = automatic choice by grid size and epilogue).  Results are identical
  * up to fp32 summation order. */

@@ -78,6 +78,7 @@ SIGNATURES = {
     "mavlm_frame_mean": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "mavlm_adjacent_cosine": (C.c_int, [vp, vp, i32, i32, C.c_float, vp]),
     "mavlm_gru_sequence": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mavlm_set_attention_bwd_fused": (C.c_int, [i32]),
     "mavlm_set_gemm_tile": (C.c_int, [i32]),
     "mavlm_set_attention_impl": (C.c_int, [i32]),
     "mavlm_prof_enable": (C.c_int, [i32]),

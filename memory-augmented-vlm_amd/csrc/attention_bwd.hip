@@ -14,10 +14,15 @@
 //     MODE 0 (dQ):  X = Q, X2 = dO | Y = K, Y2 = V  | Z = K   | lse2/delta indexed by the lane (x)
 //     MODE 1 (dK):  X = K, X2 = V  | Y = Q, Y2 = dO | Z = Q   | lse2/delta indexed by the streamed row (y), from LDS
 //     MODE 2 (dV):  X = K          | Y = Q          | Z = dO  | E = P
+//     MODE 3 (dK and dV fused): MODE 1 plus a second accumulator dV^T += dO^T . P (Z2 = dO, already staged for dP):
+//                   one S recompute less (7 products instead of 8); 128 accumulator + 64 stationary registers force one
+//                   workgroup per CU (512-register waves)
 // No atomics: each output row is owned by one lane, results are deterministic.
 // LDS image and its XOR swizzle: as attention.hip (conflict-free for the row reads and the transposed reads).
 #include "mavlm_common.h"
 #include "mavlm_kernels.h"
+
+extern int g_mavlm_attn_bwd_fused;
 
 namespace {
 
@@ -29,13 +34,14 @@ constexpr int BWD_LDS = 4 * BTILE + 2 * 512;
 __device__ __forceinline__ int bimg_x(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 template <typename T, int MODE>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __restrict__ X, int ldx,
+__global__ __launch_bounds__(256, (MODE == 3 ? 1 : 2)) void attn_bwd_kernel(const uint16_t* __restrict__ X, int ldx,
                                                           const uint16_t* __restrict__ X2, int ldx2,
                                                           const uint16_t* __restrict__ Y, int ldy,
                                                           const uint16_t* __restrict__ Y2, int ldy2,
                                                           const float* __restrict__ lse2, const float* __restrict__ delta,
                                                           uint16_t* __restrict__ Out, int ldo, int NX, int NY, int R,
-                                                          int H, float c, float out_scale) {
+                                                          int H, float c, float out_scale,
+                                                          uint16_t* __restrict__ Out2 = nullptr, int ldo2 = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
       yreg[i] = *(const u32x4*)(yg + (size_t)row * ldy);
       y2reg[i] = *(const u32x4*)(y2g + (size_t)row * ldy2);
     }
-    if (MODE != 0 && tid < 128) {                 // per-row statistics of the streamed queries
+    if (MODE != 0 && tid < 128) {                 // per-row statistics of the streamed queries (MODE 1-3)
       const int q = t * BKT + (tid & 63);
       if (tid < 64) sreg = q < NY ? lse2[(size_t)h * R + q] : INFINITY;    // masked query: exp2(-inf) = 0
       else sreg = q < NY ? delta[(size_t)h * R + q] : 0.f;
@@ -109,11 +115,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) zaddr[db][jj] = z_rd + 256 * 8 * jj + 16 * (((db ^ tq) << 2) | ((tg1 ^ jj) << 1));
 
-  f32x16 acc[4];
+  f32x16 acc[4], acc2[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[d][i] = 0.f;
+    for (int i = 0; i < 16; ++i) { acc[d][i] = 0.f; acc2[d][i] = 0.f; }
 
   load_tile(0);
   store_tile(0);
@@ -130,6 +136,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
     const char* yb = smem + cur * 2 * BTILE;                   // Y image; Y2 image at + BTILE
     const char* zb = (MODE == 2) ? yb + BTILE : yb;            // image read transposed
     const unsigned zbase = (unsigned)(uintptr_t)(MAVLM_LDS const char*)zb;
+    const unsigned z2base = (unsigned)(uintptr_t)(MAVLM_LDS const char*)(yb + BTILE);   // MODE 3: dO image, transposed
     const float* stat = (const float*)(smem + BSTAT + cur * 512);
     const bool ragged = (t == nt - 1) && (NY & (BKT - 1));
 
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
         f32x4 l4, d4;
         if (MODE != 0) {
           l4 = *(const f32x4*)(stat + 32 * b + 8 * g + 4 * hh);
-          if (MODE == 1) d4 = *(const f32x4*)(stat + 64 + 32 * b + 8 * g + 4 * hh);
+          if (MODE == 1 || MODE == 3) d4 = *(const f32x4*)(stat + 64 + 32 * b + 8 * g + 4 * hh);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -164,15 +171,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
           if (MODE == 0 && ragged && t * BKT + 32 * b + j + 8 * g + 4 * hh >= NY) p = 0.f;   // key past the end
           if (MODE == 2) tt[i] = p;
           else tt[i] = p * (dp[i] - ((MODE == 0) ? del_l : d4[j]));
+          if (MODE == 3) dp[i] = p;                                   // dP is consumed: its registers carry P
         }
       }
-      typename T::vec8 ef[2];
+      typename T::vec8 ef[2], pf[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         u32x4 w;
 #pragma unroll
         for (int j = 0; j < 4; ++j) w[j] = pack2<T>(tt[8 * s + 2 * j], tt[8 * s + 2 * j + 1]);
         ef[s] = __builtin_bit_cast(typename T::vec8, w);
+        if (MODE == 3) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = pack2<T>(dp[8 * s + 2 * j], dp[8 * s + 2 * j + 1]);
+          pf[s] = __builtin_bit_cast(typename T::vec8, w);
+        }
       }
       // ---- A^T += Z^T . E^T
 #pragma unroll
@@ -183,6 +196,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
           const typename T::vec4 hi = T::ds_read_tr(zbase + zaddr[db][1] + 256 * (32 * b + 16 * s));
           const typename T::vec8 zf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           acc[db] = T::mfma32(zf, ef[s], acc[db]);
+          if (MODE == 3) {
+            const typename T::vec4 lo2 = T::ds_read_tr(z2base + zaddr[db][0] + 256 * (32 * b + 16 * s));
+            const typename T::vec4 hi2 = T::ds_read_tr(z2base + zaddr[db][1] + 256 * (32 * b + 16 * s));
+            const typename T::vec8 z2f = __builtin_shufflevector(lo2, hi2, 0, 1, 2, 3, 4, 5, 6, 7);
+            acc2[db] = T::mfma32(z2f, pf[s], acc2[db]);
+          }
         }
     }
 
@@ -200,6 +219,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
       for (int g = 0; g < 4; ++g)
         *(u32x2*)(op + 32 * db + 8 * g) = pack4<T>(acc[db][4 * g] * out_scale, acc[db][4 * g + 1] * out_scale,
                                                    acc[db][4 * g + 2] * out_scale, acc[db][4 * g + 3] * out_scale);
+    if (MODE == 3) {
+      uint16_t* op2 = Out2 + (size_t)x * ldo2 + h * BHD + 4 * hh;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(u32x2*)(op2 + 32 * db + 8 * g) = pack4<T>(acc2[db][4 * g], acc2[db][4 * g + 1], acc2[db][4 * g + 2],
+                                                      acc2[db][4 * g + 3]);
+    }
   }
 }
 
@@ -233,10 +261,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restr
 template <typename T, int MODE>
 void launch_mode(dim3 grid, hipStream_t s, const void* X, int ldx, const void* X2, int ldx2, const void* Y, int ldy,
                  const void* Y2, int ldy2, const float* lse2, const float* delta, void* out, int ldo, int NX, int NY,
-                 int R, int H, float c, float out_scale) {
+                 int R, int H, float c, float out_scale, void* out2 = nullptr, int ldo2 = 0) {
   hipLaunchKernelGGL((attn_bwd_kernel<T, MODE>), grid, dim3(256), BWD_LDS, s, (const uint16_t*)X, ldx, (const uint16_t*)X2,
                      ldx2, (const uint16_t*)Y, ldy, (const uint16_t*)Y2, ldy2, lse2, delta, (uint16_t*)out, ldo, NX, NY,
-                     R, H, c, out_scale);
+                     R, H, c, out_scale, (uint16_t*)out2, ldo2);
 }
 
 template <typename T>
@@ -247,6 +275,7 @@ hipError_t launch_all(const mavlm_attn_bwd_args& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
     attr_done = true;
   }
   hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((a.R + 3) / 4), dim3(256), 0, s, (const uint16_t*)a.O, a.ldo,
@@ -255,6 +284,11 @@ hipError_t launch_all(const mavlm_attn_bwd_args& a, hipStream_t s) {
   if (a.dQ != nullptr)
     launch_mode<T, 0>(gq, s, a.Q, a.ldq, a.dO, a.lddo, a.K, a.ldk, a.V, a.ldv, a.lse2, a.delta, a.dQ, a.lddq, a.R, a.S,
                       a.R, a.H, c, a.scale);
+  if (a.dK != nullptr && a.dV != nullptr && g_mavlm_attn_bwd_fused) {
+    launch_mode<T, 3>(gk, s, a.K, a.ldk, a.V, a.ldv, a.Q, a.ldq, a.dO, a.lddo, a.lse2, a.delta, a.dK, a.lddk, a.S, a.R,
+                      a.R, a.H, c, a.scale, a.dV, a.lddv);
+    return hipGetLastError();
+  }
   if (a.dK != nullptr)
     launch_mode<T, 1>(gk, s, a.K, a.ldk, a.V, a.ldv, a.Q, a.ldq, a.dO, a.lddo, a.lse2, a.delta, a.dK, a.lddk, a.S, a.R,
                       a.R, a.H, c, a.scale);
@@ -265,6 +299,8 @@ hipError_t launch_all(const mavlm_attn_bwd_args& a, hipStream_t s) {
 }
 
 }  // namespace
+
+int g_mavlm_attn_bwd_fused = 0;   // experiment switch: 1 = fused dK+dV kernel (512-register waves, one workgroup per CU)
 
 hipError_t mavlm_launch_attention_bwd(const mavlm_attn_bwd_args& a, int dtype, hipStream_t s) {
   return dtype == MAVLM_F16 ? launch_all<F16>(a, s) : launch_all<BF16>(a, s);

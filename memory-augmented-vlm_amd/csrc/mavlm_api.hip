@@ -116,6 +116,12 @@ int mavlm_set_attention_impl(int32_t impl) {
   return 0;
 }
 
+extern int g_mavlm_attn_bwd_fused;
+int mavlm_set_attention_bwd_fused(int32_t on) {
+  g_mavlm_attn_bwd_fused = on ? 1 : 0;
+  return 0;
+}
+
 int mavlm_set_gemm_tile(int32_t tile) {
   if (tile != 0 && tile != 128 && tile != 256 && tile != 257) return MAVLM_E_ARG;
   g_mavlm_gemm_tile = tile;

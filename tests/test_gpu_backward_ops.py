@@ -81,6 +81,14 @@ def test_activation_kernels(mode):
     assert np.array_equal(to_np(ops.act(ops.ACT_RELU_BWD, to_dev(y, mode), to_dev(dy, mode))), OB.relu_bwd(y, dy))
 
 
+@pytest.fixture(params=[0, 1])
+def bwd_fused(request):
+    """Attention-backward tests run with separate dK / dV kernels and with the fused dK+dV kernel."""
+    capi.check(capi.lib().mavlm_set_attention_bwd_fused(request.param), "set fused")
+    yield request.param
+    capi.lib().mavlm_set_attention_bwd_fused(0)
+
+
 def _attn_case(R, S, H, mode, seed, qs=1.0):
     r = O.rounder(mode)
     W = H * 128
@@ -93,7 +101,7 @@ def _attn_case(R, S, H, mode, seed, qs=1.0):
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("R,S,H", [(128, 64, 1), (32, 200, 2), (196, 392, 8), (300, 130, 2), (1, 2, 1), (129, 65, 1)])
-def test_attention_bwd_vs_oracle(mode, R, S, H):
+def test_attention_bwd_vs_oracle(mode, R, S, H, bwd_fused):
     r = O.rounder(mode)
     Q, K, V, dO = _attn_case(R, S, H, mode, 31)
     q, k, v, do = (to_dev(a, mode) for a in (Q, K, V, dO))
@@ -108,7 +116,7 @@ def test_attention_bwd_vs_oracle(mode, R, S, H):
     assert dq2 is None and dv2 is None and torch.equal(dk2, dk)
 
 
-def test_attention_bwd_matches_autograd_fp32():
+def test_attention_bwd_matches_autograd_fp32(bwd_fused):
     """End check against torch autograd of the reference expression (MemoryController.py:51-54) in fp32 on the
     same 16-bit inputs; the distance is the kernels' operand rounding (P, dS to bf16): a few 1e-3."""
     R, S, H = 260, 330, 2
@@ -126,7 +134,7 @@ def test_attention_bwd_matches_autograd_fp32():
         assert O.rel_l2(to_np(got), to_np(ref)) < 8e-3
 
 
-def test_attention_bwd_strided_operands_and_bad_args():
+def test_attention_bwd_strided_operands_and_bad_args(bwd_fused):
     """K and V as column slices of a packed [S, 2W] projection output (as the path stores them); argument checks."""
     R, S, H = 100, 150, 2
     W = H * 128
