@@ -129,6 +129,14 @@ int mavlm_linear(const void* A, int32_t lda, const void* W, int32_t ldw, const f
 /* ctx[R,H*128] = softmax(Q K^T / sqrt(128)) V per head; lse2 [H,R] fp32 optional.  MemoryController.py:51-54 */
 int mavlm_attention(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                     int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream);
+/* As mavlm_linear, with the split-K path for GEMMs with few output tiles and a long contraction (<= 128 tiles of 128^2,
+ * K >= 2048, contiguous C: e.g. the 4D -> D projections at 8 memory tokens): the contraction is split over up to 4
+ * workgroup planes (fp32 partials in `ws`, mavlm_linear_ws_floats(...) floats; 0 = this shape does not split) and
+ * bias + epilogue are applied once in the reduce.  Pure function of the shape; mavlm_step uses the same plan. */
+int64_t mavlm_linear_ws_floats(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t ldc);
+int mavlm_linear_ws(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const void* res, int32_t ldr,
+                    void* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue, float* ws, int64_t ws_floats,
+                    int32_t dtype, void* stream);
 /* As mavlm_attention, with the split-KV path for grids too small to fill the chip (ceil(R/128)*H < 320 workgroups,
  * e.g. the reference's default 8 memory tokens): the keys are split over up to 8 workgroup planes that write normalised
  * fp32 partials into `ws` (mavlm_attention_ws_floats(R,S,H) floats; 0 = this shape does not split), a second kernel

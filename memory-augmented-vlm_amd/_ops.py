@@ -57,9 +57,12 @@ def linear(x, weight, bias_f32, epilogue=capi.EPI_BIAS, residual=None, out=None)
             raise capi.MavlmError("linear: residual required")
         _, _, ldr = _rows(residual)
         rp = residual.data_ptr()
-    capi.check(capi.lib().mavlm_linear(x.data_ptr(), lda, weight.data_ptr(), ldw, bias_f32.data_ptr(), rp, ldr,
-                                       out.data_ptr(), ldc, M, N, K, epilogue, dtype_code(x.dtype), stream_ptr()),
-               "mavlm_linear")
+    lib = capi.lib()
+    nws = lib.mavlm_linear_ws_floats(M, N, K, epilogue, ldc)   # > 0: few tiles + long contraction -> split-K (as mavlm_step)
+    ws = torch.empty((nws,), device=x.device, dtype=torch.float32) if nws else None
+    capi.check(lib.mavlm_linear_ws(x.data_ptr(), lda, weight.data_ptr(), ldw, bias_f32.data_ptr(), rp, ldr,
+                                   out.data_ptr(), ldc, M, N, K, epilogue, ws.data_ptr() if nws else 0, nws,
+                                   dtype_code(x.dtype), stream_ptr()), "mavlm_linear_ws")
     return out
 
 

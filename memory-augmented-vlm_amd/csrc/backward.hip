@@ -230,16 +230,27 @@ __global__ __launch_bounds__(256) void act_kernel(const uint16_t* __restrict__ x
   }
 }
 
-template <typename T>
+// out = epilogue(sum of the split-K planes + bias); EPI as the GEMM epilogues (bias may be null = 0); N % 4 == 0
+template <typename T, int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, size_t n4,
-                                                            uint16_t* __restrict__ out) {
+                                                            const float* __restrict__ bias, int N4, void* __restrict__ out) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     f32x4 s = ((const f32x4*)part)[i];
     for (int k = 1; k < splits; ++k) {
       const f32x4 v = ((const f32x4*)part)[(size_t)k * n4 + i];
       s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
-    ((u32x2*)out)[i] = pack4<T>(s[0], s[1], s[2], s[3]);
+    if (bias != nullptr) {
+      const f32x4 b = ((const f32x4*)bias)[i % (size_t)N4];
+      s[0] += b[0]; s[1] += b[1]; s[2] += b[2]; s[3] += b[3];
+    }
+    if (EPI == MAVLM_EPI_RELU) {
+      s[0] = fmaxf(s[0], 0.f); s[1] = fmaxf(s[1], 0.f); s[2] = fmaxf(s[2], 0.f); s[3] = fmaxf(s[3], 0.f);
+    } else if (EPI == MAVLM_EPI_GELU) {
+      s[0] = gelu_erf_fast(s[0]); s[1] = gelu_erf_fast(s[1]); s[2] = gelu_erf_fast(s[2]); s[3] = gelu_erf_fast(s[3]);
+    }
+    if (EPI == MAVLM_EPI_F32) ((f32x4*)out)[i] = s;
+    else ((u32x2*)out)[i] = pack4<T>(s[0], s[1], s[2], s[3]);
   }
 }
 
@@ -329,13 +340,22 @@ hipError_t mavlm_launch_act(int kind, const void* x, const void* dy, void* out, 
   return hipGetLastError();
 }
 
-hipError_t mavlm_launch_splitk_reduce(const float* part, int splits, size_t n, void* out, int dtype, hipStream_t s) {
-  if (n & 3) return hipErrorInvalidValue;
+hipError_t mavlm_launch_splitk_reduce(const float* part, int splits, size_t n, void* out, int dtype, hipStream_t s,
+                                      const float* bias, int N, int epilogue) {
+  if ((n & 3) || (bias != nullptr && (N <= 0 || (N & 3)))) return hipErrorInvalidValue;
   const size_t n4 = n >> 2;
   const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-  if (dtype == MAVLM_F16)
-    hipLaunchKernelGGL(splitk_reduce_kernel<F16>, dim3(blocks), dim3(256), 0, s, part, splits, n4, (uint16_t*)out);
-  else
-    hipLaunchKernelGGL(splitk_reduce_kernel<BF16>, dim3(blocks), dim3(256), 0, s, part, splits, n4, (uint16_t*)out);
+#define SKR(TT, EE) hipLaunchKernelGGL((splitk_reduce_kernel<TT, EE>), dim3(blocks), dim3(256), 0, s, part, splits, n4, bias, N / 4, out)
+#define SKR_T(TT)                                                    \
+  switch (epilogue) {                                                \
+    case MAVLM_EPI_BIAS: SKR(TT, MAVLM_EPI_BIAS); break;             \
+    case MAVLM_EPI_RELU: SKR(TT, MAVLM_EPI_RELU); break;             \
+    case MAVLM_EPI_GELU: SKR(TT, MAVLM_EPI_GELU); break;             \
+    case MAVLM_EPI_F32: SKR(TT, MAVLM_EPI_F32); break;               \
+    default: return hipErrorInvalidValue;                            \
+  }
+  if (dtype == MAVLM_F16) { SKR_T(F16) } else { SKR_T(BF16) }
+#undef SKR_T
+#undef SKR
   return hipGetLastError();
 }

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const uint16_t* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + fq * 4;
-      const f32x4 bv = *(const f32x4*)(bias + n);
+      const f32x4 bv = ksplit > 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(bias + n);   // split-K planes: bias in the reduce
       float v0 = acc[i][j][0] + bv[0], v1 = acc[i][j][1] + bv[1], v2 = acc[i][j][2] + bv[2],
             v3 = acc[i][j][3] + bv[3];
       if (EPI == MAVLM_EPI_RELU) {
@@ -233,8 +233,42 @@ static bool use_256(const mavlm_gemm_args& g) {
   return tiles >= 192;
 }
 
+int mavlm_gemm_splits(int M, int N, int K, int epilogue, int ldc) {
+  if (M <= 0 || N % BN || K % BK || ldc != N || epilogue == MAVLM_EPI_RES_F32) return 1;
+  const long tiles = (long)((M + BM - 1) / BM) * (N / BN);
+  if (tiles > 128 || K < 2048) return 1;
+  int splits = K / 1024;
+  if (splits > 4) splits = 4;
+  return splits < 2 ? 1 : splits;
+}
+
+size_t mavlm_gemm_split_ws_floats(int M, int N, int K, int epilogue, int ldc) {
+  const int sp = mavlm_gemm_splits(M, N, K, epilogue, ldc);
+  return sp > 1 ? (size_t)sp * M * N : 0;
+}
+
 hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s) {
   if (g.M <= 0) return hipSuccess;
+  if (g.splitk_ws != nullptr && g_mavlm_gemm_tile == 0) {
+    // few output tiles, long contraction (e.g. the 4D -> D projections at 8 memory tokens): one workgroup per CU would
+    // walk all K-tiles alone; split the contraction over blockIdx.y instead and apply bias + epilogue in the reduce
+    const int sp = mavlm_gemm_splits(g.M, g.N, g.K, g.epilogue, g.ldc);
+    if (sp > 1) {
+      if ((g.lda & 7) || (g.ldw & 7)) return hipErrorInvalidValue;
+      const int nk = g.K / BK;
+      const int ksplit = ((nk + sp - 1) / sp) * BK;
+      const int splits = (g.K + ksplit - 1) / ksplit;
+      mavlm_prof_scope prof(MAVLM_K_GEMM, 2.0 * g.M * (double)g.N * g.K,
+                            2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (8.0 * splits + 2.0) * g.M * (double)g.N, s);
+      mavlm_gemm_args p = g;
+      p.C = g.splitk_ws;
+      p.epilogue = MAVLM_EPI_F32;
+      hipError_t e = dtype == MAVLM_F16 ? launch_splitk<F16>(p, splits, ksplit, s) : launch_splitk<BF16>(p, splits, ksplit, s);
+      if (e != hipSuccess) return e;
+      // the planes are pure partial products (the kernel skips its bias when ksplit > 0); bias + epilogue once, here
+      return mavlm_launch_splitk_reduce(g.splitk_ws, splits, (size_t)g.M * g.N, g.C, dtype, s, g.bias, g.N, g.epilogue);
+    }
+  }
   if (g.N % BN != 0 || g.K % BK != 0 || g.K <= 0 || (g.lda & 7) || (g.ldw & 7) || (g.ldc & 3)) return hipErrorInvalidValue;
   if (g.epilogue == MAVLM_EPI_RES_F32 && (g.res == nullptr || (g.ldr & 3))) return hipErrorInvalidValue;
   const double osz = g.epilogue == MAVLM_EPI_RES_F32 ? 6.0 : (g.epilogue == MAVLM_EPI_F32 ? 4.0 : 2.0);

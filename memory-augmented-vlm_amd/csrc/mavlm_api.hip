@@ -15,7 +15,7 @@ struct mavlm_ctx {
   bool has_w = false, has_b = false;
   int steps = 0;
   // workspace carve (byte offsets)
-  size_t o_kv, o_q, o_ctx, o_a, o_h, o_pre, o_mA, o_mB, o_lse, o_part, o_split, total;
+  size_t o_kv, o_q, o_ctx, o_a, o_h, o_pre, o_mA, o_mB, o_lse, o_part, o_split, o_gsplit, gsplit_floats, total;
 };
 
 namespace {
@@ -64,6 +64,11 @@ void carve(mavlm_ctx* x) {
     const size_t cap = items < 320 ? (512 / items > 8 ? 8 : 512 / items) : 0;
     if (cap >= 2) o += al(cap * (R * H * 128 + H * R) * 4);
   }
+  // split-K planes of the GEMMs with few output tiles and a long contraction (mavlm_gemm_splits): the I -> D
+  // projections (MLP down, fuser second layer) at small R
+  x->o_gsplit = o;
+  x->gsplit_floats = mavlm_gemm_split_ws_floats((int)R, (int)D, (int)I, MAVLM_EPI_F32, (int)D);
+  o += al(x->gsplit_floats * 4);
   x->total = o;
 }
 
@@ -76,10 +81,13 @@ inline char* ws(mavlm_ctx* x, size_t off) { return (char*)x->b.workspace + off; 
   } while (0)
 
 hipError_t gemm(int dtype, hipStream_t s, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
-                int M, int N, int K, int epi, const void* res = nullptr, int ldr = 0) {
+                int M, int N, int K, int epi, const void* res = nullptr, int ldr = 0, float* split_ws = nullptr,
+                size_t split_floats = 0) {
   mavlm_gemm_args g;
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.res = res; g.ldr = ldr; g.C = C; g.ldc = ldc;
   g.M = M; g.N = N; g.K = K; g.epilogue = epi;
+  // split-K only when the caller's workspace covers this shape's plan (the plan is part of the result)
+  if (split_ws != nullptr && mavlm_gemm_split_ws_floats(M, N, K, epi, ldc) <= split_floats) g.splitk_ws = split_ws;
   return mavlm_launch_gemm(g, dtype, s);
 }
 
@@ -254,7 +262,7 @@ int mavlm_step(mavlm_ctx* x, const void* seg, int32_t F, void* frame_scores, int
     // MLP: Linear(D,I)+ReLU -> Residual(I->D)  (MemoryController.py:63-67,71)
     MAVLM_TRY(gemm(dt, s, ws(x, x->o_a), D, x->w.w_up[l], D, x->w.b_up[l], ws(x, x->o_h), I, R, I, D, MAVLM_EPI_RELU));
     MAVLM_TRY(gemm(dt, s, ws(x, x->o_h), I, x->w.w_down[l], I, x->w.b_down[l], ws(x, x->o_pre), D, R, D, I,
-                   MAVLM_EPI_F32));
+                   MAVLM_EPI_F32, nullptr, 0, (float*)ws(x, x->o_gsplit), x->gsplit_floats));
     void* dst = last ? (void*)((char*)x->b.mem_ring + (size_t)(x->steps % cap) * mem_bytes)
                      : (void*)ws(x, (l & 1) ? x->o_mA : x->o_mB);
     MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), ws(x, x->o_a), D, x->w.ln2_g[l], x->w.ln2_b[l], dst, R, D,
@@ -293,7 +301,7 @@ int mavlm_fuse_emit(mavlm_ctx* x, const void* x_pe, const int64_t* fine_idx, int
     const char* mem = (const char*)x->b.mem_ring + (size_t)slot * R * rowb;
     MAVLM_TRY(gemm(dt, s, mem, D, x->w.w_f1, D, x->w.b_f1, ws(x, x->o_h), I, R, I, D, MAVLM_EPI_GELU));
     MAVLM_TRY(gemm(dt, s, ws(x, x->o_h), I, x->w.w_f2, I, x->w.b_f2_type0, o + (size_t)row * rowb, D, R, D, I,
-                   MAVLM_EPI_BIAS));
+                   MAVLM_EPI_BIAS, nullptr, 0, (float*)ws(x, x->o_gsplit), x->gsplit_floats));
     row += R;
   }
   MAVLM_TRY(hipMemcpyAsync(o + (size_t)row * rowb, newline, rowb, hipMemcpyDeviceToDevice, s));
@@ -316,6 +324,22 @@ int mavlm_linear(const void* A, int32_t lda, const void* W, int32_t ldw, const f
   if (!A || !W || !bias || !C || M < 0) return MAVLM_E_ARG;
   if (N % 128 || K % 64 || N <= 0 || K <= 0) return MAVLM_E_SHAPE;
   hipError_t e = gemm(dtype, (hipStream_t)stream, A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, res, ldr);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int64_t mavlm_linear_ws_floats(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t ldc) {
+  return (int64_t)mavlm_gemm_split_ws_floats(M, N, K, epilogue, ldc);
+}
+
+int mavlm_linear_ws(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const void* res, int32_t ldr,
+                    void* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue, float* ws_, int64_t ws_floats,
+                    int32_t dtype, void* stream) {
+  if (!A || !W || !bias || !C || M < 0) return MAVLM_E_ARG;
+  if (N % 128 || K % 64 || N <= 0 || K <= 0) return MAVLM_E_SHAPE;
+  const int64_t need = (int64_t)mavlm_gemm_split_ws_floats(M, N, K, epilogue, ldc);
+  if (need > 0 && (!ws_ || ws_floats < need)) return MAVLM_E_ARG;      // the plan is part of the result
+  hipError_t e = gemm(dtype, (hipStream_t)stream, A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, res, ldr,
+                      need > 0 ? ws_ : nullptr, need > 0 ? (size_t)ws_floats : 0);
   return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
 }
 

@@ -14,8 +14,13 @@ struct mavlm_gemm_args {
   void* C; int ldc;              // [M,N] 16-bit, or fp32 for EPI_RES_F32
   int M, N, K;
   int epilogue;
+  float* splitk_ws = nullptr;    // mavlm_gemm_split_ws_floats(M,N,K) floats, or null = never split the contraction
 };
 hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s);
+// split-K plan for GEMMs with few output tiles and a long contraction (small M, K >= 2048): 1 = none.  Pure function of
+// the shape: the fused step and the stand-alone operator take the same path.
+int mavlm_gemm_splits(int M, int N, int K, int epilogue, int ldc);
+size_t mavlm_gemm_split_ws_floats(int M, int N, int K, int epilogue, int ldc);
 // 256x256x64 8-wave kernel (gemm256.hip); mavlm_launch_gemm picks it when the grid fills the chip
 bool mavlm_gemm256_supported(const mavlm_gemm_args& g);
 hipError_t mavlm_launch_gemm256(const mavlm_gemm_args& g, int dtype, hipStream_t s);
@@ -70,7 +75,8 @@ hipError_t mavlm_launch_layernorm_bwd(const void* dy, const float* x, const void
 hipError_t mavlm_launch_transpose(const void* in, int ldi, int rows, int cols, void* out, int ldo, hipStream_t s);
 hipError_t mavlm_launch_rowsum(const void* in, int ld, int rows, int cols, float* out, int dtype, hipStream_t s);
 hipError_t mavlm_launch_act(int kind, const void* x, const void* dy, void* out, size_t n, int dtype, hipStream_t s);
-hipError_t mavlm_launch_splitk_reduce(const float* part, int splits, size_t n, void* out, int dtype, hipStream_t s);
+hipError_t mavlm_launch_splitk_reduce(const float* part, int splits, size_t n, void* out, int dtype, hipStream_t s,
+                                      const float* bias = nullptr, int N = 0, int epilogue = MAVLM_EPI_BIAS);
 
 // variants.hip (inactive variants of the reference)
 hipError_t mavlm_launch_frame_mean(const void* x, void* out16, float* out32, int F, int P, int D, int dtype, hipStream_t s);

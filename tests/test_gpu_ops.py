@@ -70,6 +70,36 @@ def test_linear_random_vs_oracle(M, N, K, epi, gemm_tile):
     assert O.rel_l2(got, r(y)) < TOL
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 2048), (1568, 1024, 4096), (129, 128, 4160), (1, 1024, 2048)])
+def test_linear_split_k_small_grids(mode, M, N, K):
+    """<= 128 output tiles and K >= 2048 (the 4D -> D projections at 8 memory tokens) split the contraction over
+    blockIdx.y; bias and epilogue are applied once, in the reduce.  Integer data: exact for every epilogue."""
+    lib = capi.lib()
+    assert lib.mavlm_linear_ws_floats(M, N, K, capi.EPI_BIAS, N) > 0
+    assert lib.mavlm_linear_ws_floats(12544, 1024, 4096, capi.EPI_F32, 1024) == 0      # full grids never split
+    assert lib.mavlm_linear_ws_floats(M, N, K, capi.EPI_RES_F32, N) == 0
+    A = _int_mat((M, K), 1, -2, 2)
+    W = _int_mat((N, K), 2, -2, 2)
+    b = _int_mat((N,), 3, -8, 8)
+    ref = A @ W.T + b
+    r = O.rounder(mode)
+    a, w, bb = to_dev(A, mode), to_dev(W, mode), f32_dev(b)
+    assert np.array_equal(to_np(ops.linear(a, w, bb, capi.EPI_BIAS)), r(ref))
+    assert np.array_equal(to_np(ops.linear(a, w, bb, capi.EPI_RELU)), r(np.maximum(ref, 0)))
+    assert np.array_equal(to_np(ops.linear(a, w, bb, capi.EPI_F32)), ref)
+    assert O.rel_l2(to_np(ops.linear(a, w, bb, capi.EPI_GELU)), r(O.gelu_erf(ref))) < 1e-4
+    # a too-small workspace is an error, not a silent change of path
+    out = torch.empty((M, N), device="cuda", dtype=a.dtype)
+    assert lib.mavlm_linear_ws(a.data_ptr(), K, w.data_ptr(), K, bb.data_ptr(), 0, 0, out.data_ptr(), N, M, N, K,
+                               capi.EPI_BIAS, 0, 0, ops.dtype_code(a.dtype), ops.stream_ptr()) == capi.E_ARG
+    # random data against the oracle
+    Ar = r(O.hash_normal_like((M, K), 11))
+    Wr = r(O.hash_uniform((N, K), 12, -1 / math.sqrt(K), 1 / math.sqrt(K)))
+    got = to_np(ops.linear(to_dev(Ar, mode), to_dev(Wr, mode), bb, capi.EPI_BIAS))
+    assert O.rel_l2(got, r(O.linear(Ar, Wr, b))) < TOL
+
+
 @pytest.fixture(params=[2, 3])
 def attn_impl(request):
     """Run the attention tests once per forward kernel (2 = register-staged, 3 = software-pipelined LDS-DMA)."""
