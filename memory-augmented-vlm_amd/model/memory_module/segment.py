@@ -136,3 +136,51 @@ def sample_scenes_priority(features, sample_num=32, alpha=0.3, k=None):
     _, means = ops.frame_mean(features.contiguous(), want_f32=True)
     bounds, depth = segment(means, alpha=alpha, k=k)
     return scenes_priority_from_boundaries(bounds, depth, T, sample_num)
+
+
+def adjusted_from_similarity(sim_scores, num_frames, alpha=0.5, k=None, min_distance=32, max_distance=64):
+    """Host half of `adjusted_segment` (segment.py:56-128): depth-score boundaries (at most 15 by threshold, else the
+    top 15), then gaps shorter than `min_distance` are merged and gaps longer than `max_distance` get evenly spaced
+    extra boundaries; the sequence end is appended or merged into the last boundary."""
+    T = num_frames
+    depth = cal_depth_score(sim_scores)
+    if k is not None:
+        b = torch.topk(depth, k).indices.sort()[0]
+    else:
+        std, mean = torch.std_mean(depth)
+        b = (depth > mean + alpha * std).nonzero().squeeze(-1)
+        if len(b) > 15:
+            b = torch.topk(depth, 15).indices.sort()[0]
+    b = b.tolist()
+    if not b or b[-1] != T:
+        b.append(T)
+    if b[0] != 0:
+        b.insert(0, 0)
+    b = sorted(set(b))
+    out = [b[0]]
+    for cand in b[1:-1]:
+        gap = cand - out[-1]
+        if gap < min_distance:
+            continue
+        if gap > max_distance:
+            extra, start = int(gap / max_distance), out[-1]
+            for i in range(1, extra + 1):
+                nb = start + round(gap * i / (extra + 1))
+                if out[-1] < nb < cand:
+                    out.append(nb)
+        out.append(cand)
+    gap = T - out[-1]
+    if gap >= min_distance or out[-1] == 0:
+        out.append(T)
+    else:
+        out[-1] = T
+    return out
+
+
+def adjusted_segment(features, alpha=0.5, k=None, min_distance=32, max_distance=64):
+    """features [T,D] on the GPU -> boundary list (segment.py:56-128; torch's default cosine eps 1e-8, no first-score
+    patch - as the reference)."""
+    if features.shape[0] == 1:
+        return [0]
+    return adjusted_from_similarity(adjacent_similarity(features, eps=1e-8), features.shape[0], alpha, k, min_distance,
+                                    max_distance)

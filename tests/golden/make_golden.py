@@ -417,12 +417,23 @@ def g9():
         out[tag + "_depth"] = depth.numpy()
         out[tag + "_bounds"] = np.array(b, dtype=np.int64)
         out[tag + "_idx"] = np.array(idx, dtype=np.int64)
+    import contextlib, io
+    adj = {"a300": (300, 23, None, 0.5, 32, 64), "a90": (90, 9, None, 0.3, 16, 24), "a500k": (500, 40, 6, 0.5, 32, 64),
+           "a40": (40, 50, None, 0.5, 32, 64)}
+    for tag, (Tn, slen, k, alpha, mind, maxd) in adj.items():
+        feats = T(V.scene_features(Tn, 4, 64, slen, 980)).mean(dim=1)
+        with contextlib.redirect_stdout(io.StringIO()):                # the reference prints its boundaries
+            b = SEG.adjusted_segment(feats, alpha=alpha, k=k, min_distance=mind, max_distance=maxd)
+        out[tag + "_sims"] = torch.cosine_similarity(feats[:-1], feats[1:]).numpy()
+        out[tag + "_adj"] = np.array(b, dtype=np.int64)
     out["uniform_segment"] = np.array([len(SEG.uniform_segment(torch.zeros(t, 1), d=32)) for t in range(1, 140)], dtype=np.int64)
     out["uniform_segment_70"] = np.array(SEG.uniform_segment(torch.zeros(70, 1), d=32), dtype=np.int64)
     save("g9_variants.npz", meta=meta(cases={k: list(v) for k, v in cases.items()}, wseed=91, xseed=910, rowstride=3,
                                       heads=4, layers=2, gru_cases={k: list(v) for k, v in gru_cases.items()},
                                       gru_wseed=95, gru_xseed=950, seg_cases={k: list(v) for k, v in seg_cases.items()},
-                                      seg_seed=970, seg_rng=4242, seg_P=4, seg_D=64), **out)
+                                      seg_seed=970, seg_rng=4242, seg_P=4, seg_D=64,
+                                      adj_cases={k_: [x if x is not None else -1 for x in v] for k_, v in adj.items()},
+                                      adj_seed=980), **out)
 
 
 if __name__ == "__main__":

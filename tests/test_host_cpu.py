@@ -181,3 +181,17 @@ def test_scene_segmentation_host_logic_matches_reference():
         assert len(idx) == min(num, Tn) and len(set(idx)) == len(idx)
     assert [len(S.uniform_segment(t, 32)) for t in range(1, 140)] == z["uniform_segment"].tolist()
     assert S.uniform_segment(70, 32) == z["uniform_segment_70"].tolist()
+
+
+def test_adjusted_segment_host_logic_matches_reference():
+    """segment.py:56-128 (imported by llava_arch.py:34): min/max-distance adjusted boundaries, exact."""
+    import torch
+    from memory_augmented_vlm_amd.model.memory_module import segment as S
+    z, meta = load_golden("g9_variants.npz")
+    for tag, (Tn, slen, k, alpha, mind, maxd) in meta["adj_cases"].items():
+        sims = torch.from_numpy(z[tag + "_sims"].copy())
+        got = S.adjusted_from_similarity(sims, Tn, alpha=alpha, k=None if k < 0 else k, min_distance=mind, max_distance=maxd)
+        assert got == z[tag + "_adj"].tolist(), tag
+    import inspect
+    for name in ("segment", "adjusted_segment", "uniform_segment", "uniform_segment_variant", "sample_scenes_priority"):
+        assert callable(getattr(S, name))                 # the five names llava_arch.py:34 imports
