@@ -11,11 +11,12 @@ from memory_augmented_vlm_amd.model.memory_module.MemoryController import Config
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 capi.lib().mavlm_set_attention_bwd_fused(int(os.environ.get("BWD_FUSED", "0")))
 M = int(os.environ.get("MEM_TOKENS", "64"))
-c = Config(); c.mm_hidden_size = 1024; c.mm_intermediate_size = 4096; c.mm_num_attention_heads = 8
+HID = int(os.environ.get("HIDDEN", "1024"))
+c = Config(); c.mm_hidden_size = HID; c.mm_intermediate_size = 4 * HID; c.mm_num_attention_heads = 8
 c.num_memory_tokens = M; c.patch_size = 196; c.depth = 2; c.mm_dtype = torch.float32
 torch.manual_seed(0)
 rm = TransformerProjector(c).cuda().to(torch.bfloat16).train()
-x = (torch.randn(64, 196, 1024, device="cuda") * 0.5).bfloat16()
+x = (torch.randn(64, 196, HID, device="cuda") * 0.5).bfloat16()
 
 def step():
     rm.zero_grad(set_to_none=True)
