@@ -67,7 +67,17 @@ void carve(mavlm_ctx* x) {
   // split-K planes of the GEMMs with few output tiles and a long contraction (mavlm_gemm_splits): the I -> D
   // projections (MLP down, fuser second layer) at small R
   x->o_gsplit = o;
-  x->gsplit_floats = mavlm_gemm_split_ws_floats((int)R, (int)D, (int)I, MAVLM_EPI_F32, (int)D);
+  {
+    const int r = (int)R, sk = (int)S, d = (int)D, dp = (int)Dp, in = (int)I, l2 = (int)(2 * L * Dp);
+    const size_t need[] = {mavlm_gemm_split_ws_floats(r, dp, d, MAVLM_EPI_BIAS, dp),      // q projection
+                           mavlm_gemm_split_ws_floats(r, d, dp, MAVLM_EPI_F32, d),        // attention out dense
+                           mavlm_gemm_split_ws_floats(r, in, d, MAVLM_EPI_RELU, in),      // MLP up / fuser first
+                           mavlm_gemm_split_ws_floats(r, d, in, MAVLM_EPI_F32, d),        // MLP down / fuser second
+                           mavlm_gemm_split_ws_floats(sk, l2, d, MAVLM_EPI_BIAS, l2),     // chunk K/V
+                           mavlm_gemm_split_ws_floats(r, 2 * dp, d, MAVLM_EPI_BIAS, 2 * dp)};   // evolution K/V
+    x->gsplit_floats = 0;
+    for (size_t n : need) x->gsplit_floats = n > x->gsplit_floats ? n : x->gsplit_floats;
+  }
   o += al(x->gsplit_floats * 4);
   x->total = o;
 }
@@ -91,12 +101,20 @@ hipError_t gemm(int dtype, hipStream_t s, const void* A, int lda, const void* W,
   return mavlm_launch_gemm(g, dtype, s);
 }
 
+// GEMM of the fused step: the split-K workspace of the context rides along, so that every launch takes the same plan
+// as the stand-alone operator (mavlm_linear_ws) would for its shape
+inline hipError_t gemm_x(mavlm_ctx* x, hipStream_t s, const void* A, int lda, const void* W, int ldw, const float* bias, void* C,
+                         int ldc, int M, int N, int K, int epi) {
+  return gemm(x->cfg.dtype, s, A, lda, W, ldw, bias, C, ldc, M, N, K, epi, nullptr, 0,
+              x->gsplit_floats ? (float*)ws(x, x->o_gsplit) : nullptr, x->gsplit_floats);
+}
+
 // One `Attention` block given projected K/V:  out = LN(dense(attn(q_proj(xq), K, V)) + xq)
 int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const void* xq, const void* K, int ldk,
                const void* V, int ldv, int S, void* out, float* lse2) {
   const mavlm_config& c = x->cfg;
   const int R = c.mem_tokens * c.patches, D = c.hidden, H = c.heads, dt = c.dtype, Dp = padded_width(c);
-  MAVLM_TRY(gemm(dt, s, xq, D, aw.wq, D, aw.bq, ws(x, x->o_q), Dp, R, Dp, D, MAVLM_EPI_BIAS));
+  MAVLM_TRY(gemm_x(x, s, xq, D, aw.wq, D, aw.bq, ws(x, x->o_q), Dp, R, Dp, D, MAVLM_EPI_BIAS));
   mavlm_attn_args a;
   a.Q = ws(x, x->o_q); a.ldq = Dp; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = ws(x, x->o_ctx); a.ldo = Dp;
   a.lse2 = lse2; a.R = R; a.S = S; a.H = H; a.scale = attn_scale(c);
@@ -107,7 +125,7 @@ int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const 
     MAVLM_TRY(mavlm_launch_attention(a, dt, s));
   }
   // Residual: dense + bias in fp32 (GEMM epilogue), + residual and LayerNorm in the row kernel (MemoryController.py:26-29)
-  MAVLM_TRY(gemm(dt, s, ws(x, x->o_ctx), Dp, aw.wo, Dp, aw.bo, ws(x, x->o_pre), D, R, D, Dp, MAVLM_EPI_F32));
+  MAVLM_TRY(gemm_x(x, s, ws(x, x->o_ctx), Dp, aw.wo, Dp, aw.bo, ws(x, x->o_pre), D, R, D, Dp, MAVLM_EPI_F32));
   MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), xq, D, aw.ln_g, aw.ln_b, out, R, D, c.eps, dt, s));
   return 0;
 }
@@ -229,7 +247,7 @@ int mavlm_step(mavlm_ctx* x, const void* seg, int32_t F, void* frame_scores, int
     const char* mem_new = (const char*)x->b.mem_ring + (size_t)newest * mem_bytes;
     char* kv_new = (char*)x->b.evo_kv_ring + (size_t)newest * kv_bytes;
     // K/V of a cached memory are row-independent -> project each memory once, when it becomes the newest
-    MAVLM_TRY(gemm(dt, s, mem_new, D, x->w.w_kv_evo, D, x->w.b_kv_evo, kv_new, 2 * Dp, R, 2 * Dp, D, MAVLM_EPI_BIAS));
+    MAVLM_TRY(gemm_x(x, s, mem_new, D, x->w.w_kv_evo, D, x->w.b_kv_evo, kv_new, 2 * Dp, R, 2 * Dp, D, MAVLM_EPI_BIAS));
     const char* kv = (const char*)x->b.evo_kv_ring;
     int rc = attn_block(x, s, x->w.evo, mem_new, kv, 2 * Dp, kv + (size_t)Dp * 2, 2 * Dp, n * R, ws(x, x->o_mA), nullptr);
     if (rc) return rc;
@@ -239,7 +257,7 @@ int mavlm_step(mavlm_ctx* x, const void* seg, int32_t F, void* frame_scores, int
   // ---- memory formation (MemoryController.py:132-133): K/V of the chunk for all L layers in one GEMM
   char* kvs = ws(x, x->o_kv);
   const int ldkv = 2 * L * Dp;
-  MAVLM_TRY(gemm(dt, s, seg, D, x->w.w_kv_seg, D, x->w.b_kv_seg, kvs, ldkv, S, ldkv, D, MAVLM_EPI_BIAS));
+  MAVLM_TRY(gemm_x(x, s, seg, D, x->w.w_kv_seg, D, x->w.b_kv_seg, kvs, ldkv, S, ldkv, D, MAVLM_EPI_BIAS));
   for (int l = 0; l < L; ++l) {
     const bool last = l == L - 1;
     const bool want_scores = last && frame_scores != nullptr;
@@ -260,9 +278,9 @@ int mavlm_step(mavlm_ctx* x, const void* seg, int32_t F, void* frame_scores, int
       MAVLM_TRY(mavlm_launch_frame_scores(ca.part, H, S, F, c.patches, frame_scores, scores_f32, dt, s));
     }
     // MLP: Linear(D,I)+ReLU -> Residual(I->D)  (MemoryController.py:63-67,71)
-    MAVLM_TRY(gemm(dt, s, ws(x, x->o_a), D, x->w.w_up[l], D, x->w.b_up[l], ws(x, x->o_h), I, R, I, D, MAVLM_EPI_RELU));
-    MAVLM_TRY(gemm(dt, s, ws(x, x->o_h), I, x->w.w_down[l], I, x->w.b_down[l], ws(x, x->o_pre), D, R, D, I,
-                   MAVLM_EPI_F32, nullptr, 0, (float*)ws(x, x->o_gsplit), x->gsplit_floats));
+    MAVLM_TRY(gemm_x(x, s, ws(x, x->o_a), D, x->w.w_up[l], D, x->w.b_up[l], ws(x, x->o_h), I, R, I, D, MAVLM_EPI_RELU));
+    MAVLM_TRY(gemm_x(x, s, ws(x, x->o_h), I, x->w.w_down[l], I, x->w.b_down[l], ws(x, x->o_pre), D, R, D, I,
+                     MAVLM_EPI_F32));
     void* dst = last ? (void*)((char*)x->b.mem_ring + (size_t)(x->steps % cap) * mem_bytes)
                      : (void*)ws(x, (l & 1) ? x->o_mA : x->o_mB);
     MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), ws(x, x->o_a), D, x->w.ln2_g[l], x->w.ln2_b[l], dst, R, D,
@@ -299,9 +317,9 @@ int mavlm_fuse_emit(mavlm_ctx* x, const void* x_pe, const int64_t* fine_idx, int
   for (int i = 0; i < n; ++i) {   // torch.cat(memory_cache) order = oldest first (llava_arch.py:545)
     const int slot = (oldest + i) % cap;
     const char* mem = (const char*)x->b.mem_ring + (size_t)slot * R * rowb;
-    MAVLM_TRY(gemm(dt, s, mem, D, x->w.w_f1, D, x->w.b_f1, ws(x, x->o_h), I, R, I, D, MAVLM_EPI_GELU));
-    MAVLM_TRY(gemm(dt, s, ws(x, x->o_h), I, x->w.w_f2, I, x->w.b_f2_type0, o + (size_t)row * rowb, D, R, D, I,
-                   MAVLM_EPI_BIAS, nullptr, 0, (float*)ws(x, x->o_gsplit), x->gsplit_floats));
+    MAVLM_TRY(gemm_x(x, s, mem, D, x->w.w_f1, D, x->w.b_f1, ws(x, x->o_h), I, R, I, D, MAVLM_EPI_GELU));
+    MAVLM_TRY(gemm_x(x, s, ws(x, x->o_h), I, x->w.w_f2, I, x->w.b_f2_type0, o + (size_t)row * rowb, D, R, D, I,
+                     MAVLM_EPI_BIAS));
     row += R;
   }
   MAVLM_TRY(hipMemcpyAsync(o + (size_t)row * rowb, newline, rowb, hipMemcpyDeviceToDevice, s));
