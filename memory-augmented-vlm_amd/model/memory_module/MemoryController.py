@@ -282,6 +282,7 @@ class TransformerProjector(nn.Module):
         self._memory_cache: List[torch.Tensor] = []
         self._cache_mode = "engine"           # "engine": ring views (inference); "autograd": graph tensors (training)
         self._evo_kv = []                     # training path: (K, V) projections of the cached memories
+        self._train_steps = 0                 # training path: memories produced since the last reset
         self._engine = None
         self._fuser_refs = None               # (memory_fuser, token_type_embedding) bound by the glue
 
@@ -408,11 +409,16 @@ class TransformerProjector(nn.Module):
             while len(self._evo_kv) < len(self._memory_cache):
                 mem = self._memory_cache[len(self._evo_kv)].reshape(R, D)
                 self._evo_kv.append(ag.project_kv([evo], mem)[0])
-            k = torch.cat([kv_[0] for kv_ in self._evo_kv], dim=0)
-            v = torch.cat([kv_[1] for kv_ in self._evo_kv], dim=0)
+            # key order = slot order of the inference ring (memory g lives in slot g % cap), so that the attention sums
+            # in the same order after the FIFO has wrapped as well
+            first = self._train_steps - len(self._evo_kv)          # global index of the oldest cached memory
+            order = sorted(range(len(self._evo_kv)), key=lambda i: (first + i) % cap)
+            k = torch.cat([self._evo_kv[i][0] for i in order], dim=0)
+            v = torch.cat([self._evo_kv[i][1] for i in order], dim=0)
             m, _ = ag.attention_block(evo, last, k, v)
         else:
             self._evo_kv = []
+            self._train_steps = 0
             m = (self.initial_memory + self.memory_pos_embed).to(dt).reshape(R, D)      # :123-124
         stats = None
         atts = [layer.memory_segment_fusion_attention for layer in self.layers]
@@ -423,6 +429,7 @@ class TransformerProjector(nn.Module):
                                           want_stats=last_layer and self.compute_frame_scores)
             m = ag.mlp_block(layer, a)
         self._memory_cache.append(m.reshape(self.num_memory_tokens, P, D))             # :152
+        self._train_steps += 1
         if len(self._memory_cache) > cap:
             drop = len(self._memory_cache) - cap
             self._memory_cache = self._memory_cache[drop:]

@@ -521,3 +521,36 @@ def test_config3_shape_long_video_ov7b_hipgraph():
     out = g(x, mp, fp, model.image_newline)
     torch.cuda.synchronize()
     assert torch.equal(out, eager)
+
+
+@pytest.mark.parametrize("depth,cap,H,hd,M,frames", [(1, 10, 8, 128, 8, [2, 1, 2]), (3, 1, 4, 128, 2, [1, 2, 1]),
+                                                     (2, 2, 16, 64, 3, [1, 1, 1, 1]), (4, 10, 1, 128, 1, [1, 2])])
+def test_config_corners_vs_oracle(depth, cap, H, hd, M, frames):
+    """Corners of the configuration space: depth 1 (the reference Config default) up to the ABI maximum, a FIFO of one
+    entry (every step evicts), 16 narrow heads, a single memory token; inference and training forward, bit-identical
+    to each other and inside the chain tolerance of the oracle."""
+    cfg = O.PathConfig(hidden=H * hd, heads=H, mem_tokens=M, depth=depth, cache_cap=cap)
+    w = O.make_weights(cfg, seed=40 + depth)
+    proj = make_projector(cfg, w, "bf16", cache_cap=cap)
+    segs = [O.bf16_round(O.hash_normal_like((f, 196, cfg.hidden), 4000 + t)) for t, f in enumerate(frames)]
+    ref = run_oracle_steps(cfg, w, "bf16", segs, np.float32)
+    alt = run_oracle_steps(cfg, w, "bf16", segs, np.float64)
+    proj.memory_cache = []
+    for t, s_ in enumerate(segs):
+        cache, scores = proj(to_dev(s_))
+        assert len(cache) == min(t + 1, cap)
+        floor = O.rel_l2(alt[t][0][-1], ref[t][0][-1])
+        assert O.rel_l2(to_np(cache[-1]), ref[t][0][-1]) < chain_tol(floor)
+        assert O.rel_l2(to_np(scores[-1]), ref[t][1]) < max(5e-3, 4 * O.rel_l2(alt[t][1], ref[t][1]))
+    infer = [c.clone() for c in cache]
+    proj.memory_cache = []
+    with torch.enable_grad():
+        for s_ in segs:
+            cache, _ = proj(to_dev(s_))
+        assert all(c.requires_grad for c in cache)
+        for a, b in zip(cache, infer):
+            assert torch.equal(a.detach(), b)
+        sum((c.float() ** 2).mean() for c in cache).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad.float()).all() for n, p in proj.named_parameters()
+               if not n.startswith("memory_update_attention"))
+    proj.memory_cache = []
