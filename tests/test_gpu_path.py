@@ -554,3 +554,32 @@ def test_config_corners_vs_oracle(depth, cap, H, hd, M, frames):
     assert all(p.grad is not None and torch.isfinite(p.grad.float()).all() for n, p in proj.named_parameters()
                if not n.startswith("memory_update_attention"))
     proj.memory_cache = []
+
+
+def test_options_no_frame_scores_and_oversized_chunk():
+    """compute_frame_scores=False skips the column-sum pass (no scores appended) without changing the memory; a chunk
+    longer than the default 32 frames re-creates the engine with a larger workspace (first step only) and matches the
+    oracle; changing the chunk size upward in the middle of a video is refused."""
+    cfg = O.PathConfig(hidden=256, heads=2, mem_tokens=4, depth=2)
+    w = O.make_weights(cfg, seed=51)
+    proj = make_projector(cfg, w, "bf16")
+    seg40 = O.bf16_round(O.hash_normal_like((40, 196, 256), 5100))
+    seg3 = O.bf16_round(O.hash_normal_like((3, 196, 256), 5101))
+    proj.memory_cache = []
+    n0 = len(proj.frame_attn_scores)
+    cache, scores = proj(to_dev(seg40))
+    with_scores = cache[-1].clone()
+    assert len(scores) == n0 + 1 and scores[-1].shape == (40,)
+    ref = run_oracle_steps(cfg, w, "bf16", [seg40], np.float32)
+    alt = run_oracle_steps(cfg, w, "bf16", [seg40], np.float64)
+    assert O.rel_l2(to_np(with_scores), ref[0][0][-1]) < chain_tol(O.rel_l2(alt[0][0][-1], ref[0][0][-1]))
+    proj.compute_frame_scores = False
+    proj.memory_cache = []
+    cache, scores = proj(to_dev(seg40))
+    assert len(scores) == n0 + 1 and torch.equal(cache[-1], with_scores)
+    proj(to_dev(seg3))                                   # smaller chunks are fine
+    small = make_projector(cfg, w, "bf16")
+    small.memory_cache = []
+    small(to_dev(seg3))
+    with pytest.raises(capi.MavlmError, match="middle of a video"):
+        small(to_dev(seg40))
