@@ -198,6 +198,20 @@ int mavlm_rowsum(const void* in, int32_t ld, int32_t rows, int32_t cols, float* 
  * 2 out = x > 0 ? dy : 0 (x = ReLU output).  llava_arch.py:134; MemoryController.py:64 */
 int mavlm_act(int32_t kind, const void* x, const void* dy, void* out, int64_t n, int32_t dtype, void* stream);
 
+/* Wide heads (head_dim 448: LLaVA-OneVision-7B, the shape scripts/train/finetune_long.sh trains): the flash-style
+ * backward does not fit the register file, so that case materialises ONE head's scores at a time and runs every
+ * product through mavlm_linear / mavlm_linear_splitk; these are the element-wise steps in between.
+ *   P[r,s]  = exp2(S[r,s]*scale*log2e - lse2[r]) for s < valid, else 0     (S fp32 [R, lds], P 16-bit [R, ldp])
+ *   dS[r,s] = exp2(S[r,s]*scale*log2e - lse2[r]) * (dP[r,s] - delta[r]) * scale for s < valid, else 0
+ *   out[h,r] = sum_d a[r, h*head_dim+d] * b[r, h*head_dim+d]                (delta = rowdot(dO, O)) */
+int mavlm_attention_probs(const float* S, int32_t lds, const float* lse2, void* P, int32_t ldp, int32_t R, int32_t cols,
+                          int32_t valid, float scale, int32_t dtype, void* stream);
+int mavlm_attention_dscores(const float* S, int32_t lds, const float* dP, int32_t lddp, const float* lse2, const float* delta,
+                            void* dS, int32_t ldds, int32_t R, int32_t cols, int32_t valid, float scale, int32_t dtype,
+                            void* stream);
+int mavlm_rowdot_heads(const void* a, int32_t lda, const void* b, int32_t ldb, float* out, int32_t R, int32_t H,
+                       int32_t head_dim, int32_t dtype, void* stream);
+
 /* ---- inactive variants of the reference (dead code there, forward only here) ----------------
  * v[f,:] = mean over the P patch rows of x[f,:,:] (16-bit and/or fp32 output).  bigru.py:50; segment.py:268 */
 int mavlm_frame_mean(const void* x, void* out16, float* out32, int32_t F, int32_t P, int32_t D, int32_t dtype,

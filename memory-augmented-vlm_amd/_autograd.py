@@ -101,11 +101,11 @@ class AttentionFn(torch.autograd.Function):
     zero-padded by the caller).  Saves O and the log-sum-exp; the backward recomputes the probabilities per tile."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, scale):
+    def forward(ctx, q, k, v, heads, scale, head_dim=128):
         q, k, v = q.detach(), k.detach(), v.detach()
-        o, lse = ops.attention(q, k, v, heads, want_lse=True, scale=scale)
+        o, lse = ops.attention(q, k, v, heads, want_lse=True, scale=scale, head_dim=head_dim)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.heads, ctx.scale = heads, scale
+        ctx.heads, ctx.scale, ctx.head_dim = heads, scale, head_dim
         ctx.mark_non_differentiable(lse)
         return o, lse
 
@@ -113,13 +113,22 @@ class AttentionFn(torch.autograd.Function):
     def backward(ctx, do, _dlse):
         q, k, v, o, lse = ctx.saved_tensors
         n = ctx.needs_input_grad
-        dq, dk, dv = ops.attention_bwd(q, k, v, o, _c(do), lse, ctx.heads, n[0], n[1], n[2], scale=ctx.scale)
-        return dq, dk, dv, None, None
+        if ctx.head_dim == 128:
+            dq, dk, dv = ops.attention_bwd(q, k, v, o, _c(do), lse, ctx.heads, n[0], n[1], n[2], scale=ctx.scale)
+        else:       # wide heads (448): one head's scores at a time, every product a GEMM (ops.attention_bwd_wide)
+            dq, dk, dv = ops.attention_bwd_wide(q, k, v, o, _c(do), lse, ctx.heads, ctx.head_dim, ctx.scale, n[0], n[1], n[2])
+        return dq, dk, dv, None, None, None
+
+
+def head_width(hd):
+    """Columns one head occupies in the projected Q/K/V layout: narrow heads are zero-padded to 128, wide ones (448,
+    the wide-head kernels) are not padded."""
+    return 128 if hd <= 128 else hd
 
 
 def pad_heads_out(t, heads, hd):
     """[H*hd, ...] -> [H*128, ...]: zero rows after each head (projection OUTPUT side); autograd-transparent."""
-    if hd == 128:
+    if hd >= 128:
         return t
     tail = t.shape[1:]
     return torch.nn.functional.pad(t.reshape(heads, hd, -1), (0, 0, 0, 128 - hd)).reshape(heads * 128, *tail)
@@ -127,7 +136,7 @@ def pad_heads_out(t, heads, hd):
 
 def pad_heads_in(t, heads, hd):
     """[D, H*hd] -> [D, H*128]: zero columns after each head (projection INPUT side)."""
-    if hd == 128:
+    if hd >= 128:
         return t
     return torch.nn.functional.pad(t.reshape(t.shape[0], heads, hd), (0, 128 - hd)).reshape(t.shape[0], heads * 128)
 
@@ -150,7 +159,7 @@ def project_kv(attns, x):
     [rows, 2*len(attns)*H*128] output."""
     w, b = packed_kv_params(attns)
     kv = LinearFn.apply(x, w.to(x.dtype), b, ACT_NONE)
-    Dp = attns[0].num_attention_heads * 128
+    Dp = attns[0].num_attention_heads * head_width(attns[0].attention_head_size)
     return [(kv[:, (2 * i) * Dp:(2 * i + 1) * Dp], kv[:, (2 * i + 1) * Dp:(2 * i + 2) * Dp]) for i in range(len(attns))]
 
 
@@ -159,14 +168,13 @@ def attention_block(attn, q_in, k, v, want_stats=False):
     (padded-head layout; may be column views); returns (out, (q, k, lse) | None)."""
     H = attn.num_attention_heads
     hd = attn.attention_head_size
-    if hd > 128:
-        raise NotImplementedError("training the memory path with head_dim > 128 (OV-7B shape) is not implemented: the "
-                                  "backward attention kernel is head_dim-128; inference supports it")
+    if hd > 128 and hd != 448:
+        raise capi.MavlmError(f"head_dim {hd}: no attention kernel (<= 128, or 448)")
     scale = ops.attn_scale(hd)
     dt = q_in.dtype      # parameters kept in fp32 (master weights) are cast per use; the cast is autograd-transparent
     q = LinearFn.apply(q_in, pad_heads_out(attn.q_proj.weight, H, hd).to(dt), pad_heads_out(attn.q_proj.bias, H, hd),
                        ACT_NONE)
-    ctxv, lse = AttentionFn.apply(q, k, v, H, scale)
+    ctxv, lse = AttentionFn.apply(q, k, v, H, scale, head_width(hd))
     d = attn.residual
     out = DenseResidualNormFn.apply(ctxv, pad_heads_in(d.dense.weight, H, hd).to(dt), d.dense.bias, q_in,
                                     d.layernorm.weight, d.layernorm.bias, d.layernorm.eps)

@@ -77,6 +77,9 @@ SIGNATURES = {
     "mavlm_transpose": (C.c_int, [vp, i32, i32, i32, vp, i32, vp]),
     "mavlm_rowsum": (C.c_int, [vp, i32, i32, i32, vp, i32, vp]),
     "mavlm_act": (C.c_int, [i32, vp, vp, vp, C.c_int64, i32, vp]),
+    "mavlm_attention_probs": (C.c_int, [vp, i32, vp, vp, i32, i32, i32, i32, C.c_float, i32, vp]),
+    "mavlm_attention_dscores": (C.c_int, [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, C.c_float, i32, vp]),
+    "mavlm_rowdot_heads": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "mavlm_frame_mean": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "mavlm_adjacent_cosine": (C.c_int, [vp, vp, i32, i32, C.c_float, vp]),
     "mavlm_gru_sequence": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),

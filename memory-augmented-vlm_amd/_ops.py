@@ -111,7 +111,8 @@ def attention_colsum(q, k, lse2, heads, head_dim=128, wide_kernel=False, scale=N
                    "mavlm_attention_colsum")
     else:
         capi.check(capi.lib().mavlm_attention_colsum_hd(q.data_ptr(), ldq, k.data_ptr(), ldk, lse2.data_ptr(),
-                                                        part.data_ptr(), R, S, heads, head_dim, 1.0 / math.sqrt(head_dim),
+                                                        part.data_ptr(), R, S, heads, head_dim,
+                                                        1.0 / math.sqrt(head_dim) if scale is None else float(scale),
                                                         dtype_code(q.dtype), stream_ptr()), "mavlm_attention_colsum_hd")
     return part
 
@@ -196,13 +197,17 @@ def attention_bwd(q, k, v, o, do, lse2, heads, need_dq=True, need_dk=True, need_
     return dq, dk, dv
 
 
-def transpose(x, pad_to=64):
+def transpose(x, pad_to=64, out_rows=None):
     """[rows, cols] 16-bit -> [cols, roundup(rows, 64)] with a zero-filled pad (the K-contiguous operand form of
-    the contract-over-rows products)."""
+    the contract-over-rows products).  `out_rows` > cols: the result gets that many rows, the extra ones zero (an
+    operand whose row count must be a multiple of 128 for the GEMM, e.g. a 448-wide head -> 512)."""
     _need_gpu(x)
     rows, cols, ld = _rows(x)
     rp = -(-rows // pad_to) * pad_to
-    out = torch.empty((cols, rp), device=x.device, dtype=x.dtype)
+    if out_rows is None or out_rows == cols:
+        out = torch.empty((cols, rp), device=x.device, dtype=x.dtype)
+    else:
+        out = torch.zeros((out_rows, rp), device=x.device, dtype=x.dtype)
     capi.check(capi.lib().mavlm_transpose(x.data_ptr(), ld, rows, cols, out.data_ptr(), rp, stream_ptr()),
                "mavlm_transpose")
     return out
@@ -322,3 +327,61 @@ def gru_sequence(xg_f32, whh, bhh_f32, hidden, ndir):
     capi.check(capi.lib().mavlm_gru_sequence(xg_f32.data_ptr(), whh.data_ptr(), bhh_f32.data_ptr(), out.data_ptr(), F,
                                              hidden, ndir, dtype_code(whh.dtype), stream_ptr()), "mavlm_gru_sequence")
     return out
+
+
+def attention_bwd_wide(q, k, v, o, do, lse2, heads, head_dim, scale, need_dq=True, need_dk=True, need_dv=True):
+    """Gradients of `attention` for wide heads (head_dim 448: LLaVA-OneVision-7B).  The flash-style backward kernels
+    hold a 128-wide head in registers; a 448-wide one does not fit, so ONE head's [R,S] scores are materialised at a
+    time (fp32, from the MFMA GEMM) and every product of the backward runs as a GEMM of this library:
+        S = q_h k_h^T  ->  P = exp2(S c - lse2)  ->  dP = dO_h v_h^T  ->  dS = P o (dP - delta) scale
+        dV_h = P^T dO_h,   dQ_h = dS k_h,   dK_h = dS^T q_h
+    (same rounding points as the flash-style path: P and dS in 16 bits, everything else fp32 accumulation)."""
+    _need_gpu(q, k, v, o, do, lse2)
+    R, S = q.shape[0], k.shape[0]
+    hd, H = head_dim, heads
+    W = H * hd
+    if o.shape != (R, W) or do.shape != (R, W) or lse2.shape != (H, R) or hd % 64 or v.shape[0] != S:
+        raise capi.MavlmError("attention_bwd_wide: operand mismatch")
+    lib, dt, dev = capi.lib(), q.dtype, q.device
+    code = dtype_code(dt)
+    hp = -(-hd // 128) * 128                       # output width the GEMM can produce (448 -> 512)
+    Sp = -(-S // 128) * 128
+    delta = torch.empty((H, R), device=dev, dtype=torch.float32)
+    do = do if do.is_contiguous() else do.contiguous()
+    capi.check(lib.mavlm_rowdot_heads(do.data_ptr(), do.stride(0), o.data_ptr(), o.stride(0), delta.data_ptr(), R, H, hd,
+                                      code, stream_ptr()), "mavlm_rowdot_heads")
+    dq = torch.empty((R, W), device=dev, dtype=dt) if need_dq else None
+    dk = torch.empty((S, W), device=dev, dtype=dt) if need_dk else None
+    dv = torch.empty((S, W), device=dev, dtype=dt) if need_dv else None
+
+    def rows_padded(t):                            # [S, hd] view -> [Sp, hd] with zero rows (GEMM N % 128)
+        if Sp == S:
+            return t
+        out = torch.zeros((Sp, hd), device=dev, dtype=dt)
+        out[:S] = t
+        return out
+
+    for h in range(H):
+        sl = slice(h * hd, (h + 1) * hd)
+        qh, doh = q[:, sl], do[:, sl]
+        kc, vc = rows_padded(k[:, sl]), rows_padded(v[:, sl])
+        s32 = linear(qh, kc, zero_bias(Sp, dev), capi.EPI_F32)                       # [R, Sp] raw scores
+        p16 = torch.empty((R, Sp), device=dev, dtype=dt)
+        capi.check(lib.mavlm_attention_probs(s32.data_ptr(), Sp, lse2[h].data_ptr(), p16.data_ptr(), Sp, R, Sp, S,
+                                             float(scale), code, stream_ptr()), "mavlm_attention_probs")
+        if need_dv:
+            dvh = linear(transpose(p16), transpose(doh, out_rows=hp), zero_bias(hp, dev))        # [Sp, hp]
+            dv[:, sl] = dvh[:S, :hd]
+        if need_dq or need_dk:
+            dp32 = linear(doh, vc, zero_bias(Sp, dev), capi.EPI_F32)
+            ds16 = torch.empty((R, Sp), device=dev, dtype=dt)      # from the UNROUNDED probability, as the flash kernels
+            capi.check(lib.mavlm_attention_dscores(s32.data_ptr(), Sp, dp32.data_ptr(), Sp, lse2[h].data_ptr(),
+                                                   delta[h].data_ptr(), ds16.data_ptr(), Sp, R, Sp, S, float(scale), code,
+                                                   stream_ptr()), "mavlm_attention_dscores")
+            if need_dq:
+                dqh = linear(ds16, transpose(kc, out_rows=hp), zero_bias(hp, dev))               # [R, hp]
+                dq[:, sl] = dqh[:, :hd]
+            if need_dk:
+                dkh = linear(transpose(ds16), transpose(qh, out_rows=hp), zero_bias(hp, dev))    # [Sp, hp]
+                dk[:, sl] = dkh[:S, :hd]
+    return dq, dk, dv

@@ -254,6 +254,69 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// ---- wide-head attention backward (head_dim 448: LLaVA-OneVision-7B, the shape scripts/train/finetune_long.sh trains):
+// the register budget of the flash-style backward (attention_bwd.hip) does not stretch to 448-wide heads, so that
+// case materialises the scores of ONE head at a time ([R,S] fp32 from the MFMA GEMM) and runs every product as a GEMM;
+// these are the element-wise pieces in between.
+//   prob_kernel     P[r,s]  = exp2(S[r,s]*c - lse2[r])  (0 for s >= S_valid)          -> 16-bit
+//   dscore_kernel   dS[r,s] = exp2(S[r,s]*c - lse2[r]) * (dP[r,s] - delta[r]) * scale  (the UNROUNDED probability, as the
+//                   flash-style kernels use; 0 for s >= S_valid)                       -> 16-bit
+//   rowdot_kernel   delta[h][r] = sum_d a[r, h*hd+d] * b[r, h*hd+d]                   (any head_dim)
+template <typename T>
+__global__ __launch_bounds__(256) void prob_kernel(const float* __restrict__ S, int lds_, const float* __restrict__ lse2,
+                                                   uint16_t* __restrict__ P, int ldp, int R, int cols, int valid, float c) {
+  const int r = blockIdx.y;
+  const float l = lse2[r];
+  const float* sr = S + (size_t)r * lds_;
+  uint16_t* pr = P + (size_t)r * ldp;
+  for (int j = (blockIdx.x * 256 + threadIdx.x) * 4; j < cols; j += gridDim.x * 1024) {
+    const f32x4 v = *(const f32x4*)(sr + j);
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (j + e < valid) ? __builtin_amdgcn_exp2f(v[e] * c - l) : 0.f;
+    *(u32x2*)(pr + j) = pack4<T>(o[0], o[1], o[2], o[3]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dscore_kernel(const float* __restrict__ S, int lds_, const float* __restrict__ dP,
+                                                     int lddp, const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                     uint16_t* __restrict__ dS, int ldds, int R, int cols, int valid, float c,
+                                                     float scale) {
+  const int r = blockIdx.y;
+  const float d = delta[r], l = lse2[r];
+  for (int j = (blockIdx.x * 256 + threadIdx.x) * 4; j < cols; j += gridDim.x * 1024) {
+    const f32x4 sv = *(const f32x4*)(S + (size_t)r * lds_ + j);
+    const f32x4 g = *(const f32x4*)(dP + (size_t)r * lddp + j);
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = (j + e < valid) ? __builtin_amdgcn_exp2f(sv[e] * c - l) * (g[e] - d) * scale : 0.f;
+    *(u32x2*)(dS + (size_t)r * ldds + j) = pack4<T>(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// one wave per (row, head)
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_kernel(const uint16_t* __restrict__ a, int lda, const uint16_t* __restrict__ b,
+                                                     int ldb, float* __restrict__ out, int R, int H, int hd) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= R * H) return;
+  const int r = item / H, h = item % H;
+  const uint16_t* pa = a + (size_t)r * lda + h * hd;
+  const uint16_t* pb = b + (size_t)r * ldb + h * hd;
+  float s = 0.f;
+  for (int j = lane * 8; j < hd; j += 512) {
+    const u16x8 x = *(const u16x8*)(pa + j);
+    const u16x8 y = *(const u16x8*)(pb + j);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += T::to_f32(x[e]) * T::to_f32(y[e]);
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[(size_t)h * R + r] = s;
+}
+
 template <typename T>
 hipError_t launch_ln_bwd(const uint16_t* dy, const float* x, const uint16_t* res, int ldr, const float* gamma,
                          uint16_t* dz, float* part, int rows, int D, float eps, hipStream_t s) {
@@ -357,5 +420,44 @@ hipError_t mavlm_launch_splitk_reduce(const float* part, int splits, size_t n, v
   if (dtype == MAVLM_F16) { SKR_T(F16) } else { SKR_T(BF16) }
 #undef SKR_T
 #undef SKR
+  return hipGetLastError();
+}
+
+hipError_t mavlm_launch_attn_probs(const float* S, int lds_, const float* lse2, void* P, int ldp, int R, int cols, int valid,
+                                   float c, int dtype, hipStream_t s) {
+  if (R <= 0 || cols <= 0 || (cols & 3) || (lds_ & 3) || (ldp & 3) || valid > cols) return hipErrorInvalidValue;
+  mavlm_prof_scope prof(MAVLM_K_MISC, 0.0, 6.0 * R * (double)cols, s);
+  const dim3 grid((cols / 4 + 255) / 256 < 8 ? (cols / 4 + 255) / 256 : 8, R);
+  if (dtype == MAVLM_F16)
+    hipLaunchKernelGGL(prob_kernel<F16>, grid, dim3(256), 0, s, S, lds_, lse2, (uint16_t*)P, ldp, R, cols, valid, c);
+  else
+    hipLaunchKernelGGL(prob_kernel<BF16>, grid, dim3(256), 0, s, S, lds_, lse2, (uint16_t*)P, ldp, R, cols, valid, c);
+  return hipGetLastError();
+}
+
+hipError_t mavlm_launch_attn_dscores(const float* S, int lds_, const float* dP, int lddp, const float* lse2, const float* delta,
+                                     void* dS, int ldds, int R, int cols, int valid, float c, float scale, int dtype,
+                                     hipStream_t s) {
+  if (R <= 0 || cols <= 0 || (cols & 3) || (lds_ & 3) || (lddp & 3) || (ldds & 3) || valid > cols) return hipErrorInvalidValue;
+  mavlm_prof_scope prof(MAVLM_K_MISC, 0.0, 10.0 * R * (double)cols, s);
+  const dim3 grid((cols / 4 + 255) / 256 < 8 ? (cols / 4 + 255) / 256 : 8, R);
+  if (dtype == MAVLM_F16)
+    hipLaunchKernelGGL(dscore_kernel<F16>, grid, dim3(256), 0, s, S, lds_, dP, lddp, lse2, delta, (uint16_t*)dS, ldds, R, cols,
+                       valid, c, scale);
+  else
+    hipLaunchKernelGGL(dscore_kernel<BF16>, grid, dim3(256), 0, s, S, lds_, dP, lddp, lse2, delta, (uint16_t*)dS, ldds, R, cols,
+                       valid, c, scale);
+  return hipGetLastError();
+}
+
+hipError_t mavlm_launch_rowdot(const void* a, int lda, const void* b, int ldb, float* out, int R, int H, int hd, int dtype,
+                               hipStream_t s) {
+  if (R <= 0 || H <= 0 || hd <= 0 || (hd & 7) || (lda & 7) || (ldb & 7)) return hipErrorInvalidValue;
+  if (dtype == MAVLM_F16)
+    hipLaunchKernelGGL(rowdot_kernel<F16>, dim3((R * H + 3) / 4), dim3(256), 0, s, (const uint16_t*)a, lda, (const uint16_t*)b,
+                       ldb, out, R, H, hd);
+  else
+    hipLaunchKernelGGL(rowdot_kernel<BF16>, dim3((R * H + 3) / 4), dim3(256), 0, s, (const uint16_t*)a, lda, (const uint16_t*)b,
+                       ldb, out, R, H, hd);
   return hipGetLastError();
 }

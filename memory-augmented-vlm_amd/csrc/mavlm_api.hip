@@ -500,6 +500,31 @@ int mavlm_act(int32_t kind, const void* xin, const void* dy, void* out, int64_t 
   return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
 }
 
+// wide-head attention backward: element-wise pieces between the per-head GEMMs (backward.hip)
+int mavlm_attention_probs(const float* S, int32_t lds_, const float* lse2, void* P, int32_t ldp, int32_t R, int32_t cols,
+                          int32_t valid, float scale, int32_t dtype, void* stream) {
+  if (!S || !lse2 || !P) return MAVLM_E_ARG;
+  hipError_t e = mavlm_launch_attn_probs(S, lds_, lse2, P, ldp, R, cols, valid, scale * 1.44269504088896340736f, dtype,
+                                         (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int mavlm_attention_dscores(const float* S, int32_t lds_, const float* dP, int32_t lddp, const float* lse2, const float* delta,
+                            void* dS, int32_t ldds, int32_t R, int32_t cols, int32_t valid, float scale, int32_t dtype,
+                            void* stream) {
+  if (!S || !dP || !lse2 || !delta || !dS) return MAVLM_E_ARG;
+  hipError_t e = mavlm_launch_attn_dscores(S, lds_, dP, lddp, lse2, delta, dS, ldds, R, cols, valid,
+                                           scale * 1.44269504088896340736f, scale, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int mavlm_rowdot_heads(const void* a, int32_t lda, const void* b, int32_t ldb, float* out, int32_t R, int32_t H, int32_t head_dim,
+                       int32_t dtype, void* stream) {
+  if (!a || !b || !out) return MAVLM_E_ARG;
+  hipError_t e = mavlm_launch_rowdot(a, lda, b, ldb, out, R, H, head_dim, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
 // ---- inactive variants of the reference -------------------------------------------------------
 int mavlm_frame_mean(const void* xin, void* out16, float* out32, int32_t F, int32_t P, int32_t D, int32_t dtype,
                      void* stream) {

@@ -84,6 +84,15 @@ hipError_t mavlm_launch_adjacent_cosine(const float* v, float* out, int n, int D
 hipError_t mavlm_launch_gru_seq(const float* xg, const void* whh, const float* bhh, void* out, int F, int H, int ndir,
                                 int dtype, hipStream_t s);
 
+// element-wise pieces of the wide-head attention backward (backward.hip)
+hipError_t mavlm_launch_attn_probs(const float* S, int lds_, const float* lse2, void* P, int ldp, int R, int cols, int valid,
+                                   float c, int dtype, hipStream_t s);
+hipError_t mavlm_launch_attn_dscores(const float* S, int lds_, const float* dP, int lddp, const float* lse2, const float* delta,
+                                     void* dS, int ldds, int R, int cols, int valid, float c, float scale, int dtype,
+                                     hipStream_t s);
+hipError_t mavlm_launch_rowdot(const void* a, int lda, const void* b, int ldb, float* out, int R, int H, int hd, int dtype,
+                               hipStream_t s);
+
 // column sums of the normalised probabilities: part[h][k] = sum_q exp2(s*c - lse2[h][q])
 struct mavlm_colsum_args {
   const void* Q; int ldq;

@@ -438,7 +438,8 @@ class TransformerProjector(nn.Module):
             with torch.no_grad():
                 q, k, lse = stats
                 att = self.layers[-1].memory_segment_fusion_attention
-                part = ops.attention_colsum(q, k, lse, att.num_attention_heads,
+                hdw = 128 if att.attention_head_size <= 128 else att.attention_head_size
+                part = ops.attention_colsum(q, k, lse, att.num_attention_heads, head_dim=hdw,
                                             scale=ops.attn_scale(att.attention_head_size))
                 self.frame_attn_scores.append(part.sum(dim=0).view(F, P).mean(dim=1).to(dt))
         return self._memory_cache, self.frame_attn_scores

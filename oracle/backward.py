@@ -17,13 +17,15 @@ from . import memory_path as O
 F32 = np.float32
 
 
-def attention_bwd(Q, K, V, Oc, dO, lse2, heads, mode="fp32"):
+def attention_bwd(Q, K, V, Oc, dO, lse2, heads, mode="fp32", scale_in_ds=False):
     """Gradients of ctx = softmax(Q K^T / sqrt(d)) V per head (MemoryController.py:51-54).
 
     Oc = forward output (as stored), lse2 = [H,R] log2-domain log-sum-exp of the forward.  Rounding points of the
     kernel (emulation modes): P rounded to 16 bits as the operand of dV = P^T dO; dS = P o (dP - delta) rounded as
     the operand of dQ = dS K and dK = dS^T Q; delta = sum_d dO*O in fp32; the 1/sqrt(d) factor applied to the fp32
-    accumulators.  Returns (dQ, dK, dV) unrounded float32."""
+    accumulators.  `scale_in_ds`: the wide-head path (ops.attention_bwd_wide) folds 1/sqrt(d) into dS BEFORE its
+    16-bit rounding (its products are plain GEMMs without an output scale) - same accuracy, different rounding point.
+    Returns (dQ, dK, dV) unrounded float32."""
     r = O.rounder(mode)
     R, S = Q.shape[0], K.shape[0]
     d = Q.shape[1] // heads
@@ -38,10 +40,11 @@ def attention_bwd(Q, K, V, Oc, dO, lse2, heads, mode="fp32"):
         p = np.exp2(s * c - lse2[h].reshape(R, 1).astype(F32), dtype=F32)
         delta = (dO[:, sl].astype(F32) * Oc[:, sl].astype(F32)).sum(axis=1, keepdims=True, dtype=F32)
         dp = O._mm(dO[:, sl], V[:, sl].T)
-        ds = r(p * (dp - delta))
+        ds = r(p * (dp - delta) * scale) if scale_in_ds else r(p * (dp - delta))
+        post = F32(1.0) if scale_in_ds else scale
         dV[:, sl] = O._mm(r(p).T, dO[:, sl])
-        dQ[:, sl] = O._mm(ds, K[:, sl]) * scale
-        dK[:, sl] = O._mm(ds.T, Q[:, sl]) * scale
+        dQ[:, sl] = O._mm(ds, K[:, sl]) * post
+        dK[:, sl] = O._mm(ds.T, Q[:, sl]) * post
     return dQ, dK, dV
 
 

@@ -150,3 +150,27 @@ def test_attention_bwd_strided_operands_and_bad_args(bwd_fused):
         ops.attention_bwd(q, kv[:, :W], kv[:, W:], o, do[:50], lse, H)
     with pytest.raises(capi.MavlmError):
         ops.attention_bwd(q.cpu(), kv[:, :W], kv[:, W:], o, do, lse, H)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("R,S,H", [(196, 392, 2), (130, 200, 1), (64, 128, 8)])
+def test_attention_bwd_wide_heads_vs_oracle(mode, R, S, H):
+    """head_dim 448 (LLaVA-OneVision-7B): per-head materialised scores, every product a GEMM; same gates as the
+    flash-style backward (P and dS are the only 16-bit operands, as there)."""
+    hd = 448
+    r = O.rounder(mode)
+    W = H * hd
+    Q = r(O.hash_normal_like((R, W), 61, 0.5))
+    K = r(O.hash_normal_like((S, W), 62, 0.5))
+    V = r(O.hash_normal_like((S, W), 63, 1.0))
+    dO = r(O.hash_normal_like((R, W), 64, 0.5))
+    q, k, v, do = (to_dev(a, mode) for a in (Q, K, V, dO))
+    o, lse = ops.attention(q, k, v, H, want_lse=True, head_dim=hd)
+    scale = ops.attn_scale(hd)
+    dq, dk, dv = ops.attention_bwd_wide(q, k, v, o, do, lse, H, hd, scale)
+    rq, rk, rv = OB.attention_bwd(Q, K, V, to_np(o), dO, to_np(lse), H, mode, scale_in_ds=True)
+    assert O.rel_l2(to_np(dv), r(rv)) < TOL
+    assert O.rel_l2(to_np(dq), r(rq)) < TOL
+    assert O.rel_l2(to_np(dk), r(rk)) < TOL
+    a = ops.attention_bwd_wide(q, k, v, o, do, lse, H, hd, scale, need_dq=False, need_dk=True, need_dv=False)
+    assert a[0] is None and a[2] is None and torch.equal(a[1], dk)

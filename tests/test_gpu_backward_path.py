@@ -43,7 +43,8 @@ def _hip_grads(rm, segs, cots, mode):
 
 
 @pytest.mark.parametrize("mode,H,hd,frames,M", [("bf16", 8, 128, [2, 1, 2], 4), ("fp16", 2, 64, [1, 2], 4),
-                                                  ("bf16", 8, 112, [2, 1], 4), ("bf16", 8, 128, [32, 32, 7], 16)])
+                                                  ("bf16", 8, 112, [2, 1], 4), ("bf16", 8, 128, [32, 32, 7], 16),
+                                                  ("bf16", 2, 448, [2, 1, 2], 3)])
 def test_training_forward_bit_identical_to_inference(mode, H, hd, frames, M):
     """The last case is large enough for every kernel choice of the bench shape to occur (256^2 / persistent GEMMs on
     the packed K/V projection, split-KV attention off and on): the training path takes the same kernels because it
@@ -110,10 +111,11 @@ def test_gradients_inside_reference_bf16_envelope(tag):
 
 
 @pytest.mark.parametrize("mode,H,hd,M,frames,cap", [("bf16", 2, 128, 3, [1, 2, 1, 1], 2), ("fp16", 4, 64, 2, [2, 1], 10),
-                                                    ("bf16", 1, 128, 5, [3], 10)])
+                                                    ("bf16", 1, 128, 5, [3], 10), ("bf16", 2, 448, 2, [1, 2], 10)])
 def test_gradients_vs_torch_oracle(mode, H, hd, M, frames, cap):
     """Other shapes against oracle/torch_path.py (float64 autograd on the same 16-bit weights and inputs): FIFO
-    eviction under BPTT (cap 2), zero-padded heads (hd 64), fp16, a single step (no evolution).
+    eviction under BPTT (cap 2), zero-padded heads (hd 64), fp16, a single step (no evolution), wide heads (hd 448: the
+    LLaVA-OneVision-7B shape that scripts/train/finetune_long.sh trains).
     Gate per parameter gradient: 6e-2 in bf16 (the reference's own bf16 autograd sits at 1.6-6e-2 on the golden
     case, 3 steps; measured here 2-3e-2 over 4 steps), 2e-2 in fp16 (finer grid; ReLU gates flipping on near-zero pre-activations keep mlp.0 at 1.4e-2)."""
     tol = 6e-2 if mode == "bf16" else 2e-2
