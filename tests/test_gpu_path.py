@@ -583,3 +583,39 @@ def test_options_no_frame_scores_and_oversized_chunk():
     small(to_dev(seg3))
     with pytest.raises(capi.MavlmError, match="middle of a video"):
         small(to_dev(seg40))
+
+
+def test_long_video_1024_frames():
+    """BASELINE configs[3] frame count on one GPU: 1024 frames = 32 chunks, the FIFO wraps three times.  Small width
+    against the oracle (every step of the chain inside the calibrated tolerance), full width (D = 1024, M = 8) as
+    properties: eager == hipGraph bit for bit, 10 memories kept, finite tokens."""
+    cfg = O.PathConfig(hidden=256, heads=2, mem_tokens=2, depth=2)
+    w = O.make_weights(cfg, seed=61)
+    proj = make_projector(cfg, w, "bf16")
+    segs = [O.bf16_round(O.hash_normal_like((32, 196, 256), 6100 + t)) for t in range(32)]
+    ref = run_oracle_steps(cfg, w, "bf16", segs, np.float32)
+    alt = run_oracle_steps(cfg, w, "bf16", segs, np.float64)
+    proj.memory_cache = []
+    worst = 0.0
+    for t, s_ in enumerate(segs):
+        cache, _ = proj(to_dev(s_))
+        assert len(cache) == min(t + 1, 10)
+        err, floor = O.rel_l2(to_np(cache[-1]), ref[t][0][-1]), O.rel_l2(alt[t][0][-1], ref[t][0][-1])
+        worst = max(worst, err / chain_tol(floor))
+        assert err < chain_tol(floor), (t, err, floor)
+    for i in range(10):                                   # the whole FIFO after three wraps, oldest first
+        assert O.rel_l2(to_np(cache[i]), ref[-1][0][i]) < chain_tol(O.rel_l2(alt[-1][0][i], ref[-1][0][i]))
+    print(f"1024-frame chain: worst error / tolerance = {worst:.2f}")
+
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=8, depth=2)
+    model, _ = _tiny_host(cfg, O.make_weights(cfg, seed=62))
+    T = 1024
+    idx = torch.arange(T) % 600
+    x = to_dev(O.bf16_round(O.hash_normal_like((T, 196, 1024), 6200)))
+    mp = (torch.randn((10, 1024), device="cuda") * 0.02).bfloat16()
+    fp = (torch.randn((9, 1024), device="cuda") * 0.02).bfloat16()
+    eager, info = arch.video_memory_tokens(model, x, idx, mp, fp, model.image_newline)
+    assert info["num_memories"] == 10 and eager.shape[0] == arch.video_token_rows(T, 8)
+    assert torch.isfinite(eager.float()).all()
+    g = arch.GraphedVideoMemory(model, T, idx)
+    assert torch.equal(g(x, mp, fp, model.image_newline), eager)
