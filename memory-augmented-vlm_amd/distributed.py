@@ -51,3 +51,83 @@ def all_gather_memory_state(state: torch.Tensor, out: Optional[torch.Tensor] = N
         return out, None
     work = dist.all_gather_into_tensor(out.view(-1), state.contiguous().view(-1), group=group, async_op=async_op)
     return out, work
+
+
+class RowShardedMemory:
+    """ONE video's recurrence with the memory ROWS sharded over the ranks of a process group - SURVEY.md §8e option 2,
+    BASELINE.json configs[3] ("a 1024-frame video ... chunks sharded across GPUs, RCCL all-gather of memory state").
+
+    The chunks of a video cannot be sharded (step t reads the FIFO of steps < t), but inside a step every operation on
+    the memory side is row-independent: q projection, attention rows, out dense, LayerNorm, MLP.  Rank g owns the rows
+    of memory tokens [g*M/W, (g+1)*M/W); per step it
+      * projects the chunk's K/V itself (redundant on every rank: 6 % of a step's flops at M = 64, no communication),
+      * runs evolution + formation for its own rows only (the small-grid paths of the kernels - split-KV attention,
+        split-K GEMMs - keep the chip busy at 1/W of the rows),
+      * all-gathers the new memory rows (M*P*D*2 bytes in total: 25.7 MB at M = 64) so that every rank holds the full
+        FIFO entry, and all-reduces the per-frame attention scores (F floats).
+    Exact: same values as the single-GPU path up to fp32 summation order (the kernel plan depends on the row count).
+    Inference only.  `projector` is a TransformerProjector whose parameters are replicated on every rank."""
+
+    def __init__(self, projector, group=None):
+        self.p = projector
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        M = projector.num_memory_tokens
+        if M % self.world:
+            raise ValueError(f"num_memory_tokens ({M}) must be a multiple of the group size ({self.world})")
+        self.rows = (M // self.world) * projector.patch_size
+        self.r0 = self.rank * self.rows
+        self.reset()
+
+    def reset(self):
+        self.cache, self._kv, self._steps = [], [], 0
+
+    @torch.no_grad()
+    def step(self, image_features: torch.Tensor):
+        """One chunk [F,P,D] (already PE-added).  Returns (memory_cache: list of full [M,P,D] memories, scores [F])."""
+        from . import _autograd as ag
+        from . import _ops as ops
+        p = self.p
+        F, P, D = image_features.shape
+        M = p.num_memory_tokens
+        R, dt = M * P, image_features.dtype
+        cap = int(getattr(p.config, "cache_cap", 10))
+        frames = image_features.reshape(F * P, D)
+        sl = slice(self.r0, self.r0 + self.rows)
+        if self.cache:
+            evo = p.memory_update_attention
+            while len(self._kv) < len(self.cache):                       # K/V of a cached memory: once, on every rank
+                self._kv.append(ag.project_kv([evo], self.cache[len(self._kv)].reshape(R, D))[0])
+            first = self._steps - len(self._kv)
+            order = sorted(range(len(self._kv)), key=lambda i: (first + i) % cap)   # ring order, as the fused step
+            k = torch.cat([self._kv[i][0] for i in order], dim=0)
+            v = torch.cat([self._kv[i][1] for i in order], dim=0)
+            m, _ = ag.attention_block(evo, self.cache[-1].reshape(R, D)[sl].contiguous(), k, v)
+        else:
+            m = (p.initial_memory + p.memory_pos_embed).to(dt).reshape(R, D)[sl].contiguous()
+        atts = [layer.memory_segment_fusion_attention for layer in p.layers]
+        kvs = ag.project_kv(atts, frames)
+        stats = None
+        for li, layer in enumerate(p.layers):
+            a, stats = ag.attention_block(atts[li], m, kvs[li][0], kvs[li][1], want_stats=li == len(p.layers) - 1)
+            m = ag.mlp_block(layer, a)
+        full = torch.empty((R, D), device=m.device, dtype=dt)
+        if self.world > 1:
+            dist.all_gather_into_tensor(full.view(-1), m.contiguous().view(-1), group=self.group)
+        else:
+            full.copy_(m)
+        q, kk, lse = stats
+        att = atts[-1]
+        hdw = 128 if att.attention_head_size <= 128 else att.attention_head_size
+        part = ops.attention_colsum(q, kk, lse, att.num_attention_heads, head_dim=hdw,
+                                    scale=ops.attn_scale(att.attention_head_size)).sum(dim=0)     # [S], local queries
+        if self.world > 1:
+            dist.all_reduce(part, group=self.group)
+        scores = part.view(F, P).mean(dim=1).to(dt)
+        self.cache.append(full.view(M, P, D))
+        self._steps += 1
+        if len(self.cache) > cap:
+            drop = len(self.cache) - cap
+            self.cache, self._kv = self.cache[drop:], self._kv[drop:]
+        return self.cache, scores

@@ -66,3 +66,13 @@ def test_single_process_gather_is_identity():
     s = torch.arange(24.).reshape(2, 3, 4)
     out, work = D.all_gather_memory_state(s)
     assert work is None and torch.equal(out[0], s)
+
+
+def test_row_sharded_memory_argument_checks():
+    """RowShardedMemory (SURVEY.md §8e option 2): host-side contract without a GPU - the memory tokens must divide over
+    the ranks; a single process owns all rows."""
+    import types
+    from memory_augmented_vlm_amd import distributed as D
+    proj = types.SimpleNamespace(num_memory_tokens=8, patch_size=196)
+    s = D.RowShardedMemory(proj)
+    assert (s.world, s.rank, s.rows, s.r0) == (1, 0, 8 * 196, 0) and s.cache == []
