@@ -151,6 +151,13 @@ int mavlm_attention_ws(const void* Q, int32_t ldq, const void* K, int32_t ldk, c
 int mavlm_attention_hd(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                        int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, int32_t head_dim, float scale,
                        int32_t dtype, void* stream);
+/* mavlm_attention_hd with the split-KV path for small grids (ceil(R/128)*H < 200 workgroups, >= 32 key tiles of 32: e.g.
+ * 8 memory tokens at the OneVision-7B width); ws = mavlm_attention_hd_ws_floats(...) floats (0 = no split).  Same
+ * scheme and merge kernel as mavlm_attention_ws; mavlm_step uses the same plan. */
+int64_t mavlm_attention_hd_ws_floats(int32_t R, int32_t S, int32_t H, int32_t head_dim);
+int mavlm_attention_hd_ws(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
+                          int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, int32_t head_dim, float scale, float* ws,
+                          int64_t ws_floats, int32_t dtype, void* stream);
 int mavlm_attention_colsum_hd(const void* Q, int32_t ldq, const void* K, int32_t ldk, const float* lse2, float* part,
                               int32_t R, int32_t S, int32_t H, int32_t head_dim, float scale, int32_t dtype, void* stream);
 /* part[H,S] fp32 = column sums over queries of the normalised probabilities.  MemoryController.py:135 */

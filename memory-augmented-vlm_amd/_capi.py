@@ -64,6 +64,9 @@ SIGNATURES = {
     "mavlm_linear_ws": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, C.c_int64, i32, vp]),
     "mavlm_attention_ws_floats": (C.c_int64, [i32, i32, i32]),
     "mavlm_attention_ws": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.c_float, vp, C.c_int64, i32, vp]),
+    "mavlm_attention_hd_ws_floats": (C.c_int64, [i32, i32, i32, i32]),
+    "mavlm_attention_hd_ws": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, C.c_float, vp, C.c_int64,
+                                        i32, vp]),
     "mavlm_attention_colsum_hd": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, C.c_float, i32, vp]),
     "mavlm_attention_colsum": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, i32, i32, C.c_float, i32, vp]),
     "mavlm_layernorm": (C.c_int, [vp, vp, i32, vp, vp, vp, i32, i32, C.c_float, i32, vp]),

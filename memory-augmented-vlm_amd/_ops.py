@@ -91,10 +91,14 @@ def attention(q, k, v, heads, want_lse=False, out=None, head_dim=128, wide_kerne
                                           ws.data_ptr() if nws else 0, nws, dtype_code(q.dtype), stream_ptr()),
                    "mavlm_attention_ws")
     else:
-        capi.check(capi.lib().mavlm_attention_hd(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(),
-                                                 out.stride(0), lp, R, S, heads, head_dim,
-                                                 1.0 / math.sqrt(head_dim) if scale is None else float(scale),
-                                                 dtype_code(q.dtype), stream_ptr()), "mavlm_attention_hd")
+        lib = capi.lib()
+        nws = lib.mavlm_attention_hd_ws_floats(R, S, heads, head_dim)    # > 0: small grid, keys split (as mavlm_step)
+        ws = torch.empty((nws,), device=q.device, dtype=torch.float32) if nws else None
+        capi.check(lib.mavlm_attention_hd_ws(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(),
+                                             out.stride(0), lp, R, S, heads, head_dim,
+                                             1.0 / math.sqrt(head_dim) if scale is None else float(scale),
+                                             ws.data_ptr() if nws else 0, nws, dtype_code(q.dtype), stream_ptr()),
+                   "mavlm_attention_hd_ws")
     return out, lse
 
 

@@ -345,15 +345,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
 template <typename T>
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ Opart, const float* __restrict__ lse_part,
                                                            uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
-                                                           int R, int H, int ns) {
+                                                           int R, int H, int hd, int ns) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= R) return;
-  const int W = H * HD3;
+  const int W = H * hd;                                      // hd % 16 == 0: a lane's 16 columns lie in one head
   for (int c0 = 0; c0 < W; c0 += 1024) {
     const int col = c0 + lane * 16;
     if (col >= W) continue;
-    const int h = col / HD3;
+    const int h = col / hd;
     float mx = -INFINITY;
     for (int sp = 0; sp < ns; ++sp) mx = fmaxf(mx, lse_part[((size_t)sp * H + h) * R + q]);
     float den = 0.f;
@@ -374,11 +374,22 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
     uint16_t* op = O + (size_t)q * ldo + col;
 #pragma unroll
     for (int v = 0; v < 4; ++v) *(u32x2*)(op + 4 * v) = pack4<T>(acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]);
-    if (lse2 != nullptr && (lane & 7) == 0) lse2[(size_t)h * R + q] = lse;
+    if (lse2 != nullptr && col % hd == 0) lse2[(size_t)h * R + q] = lse;
   }
 }
 
 }  // namespace
+
+hipError_t mavlm_launch_attention_combine(const float* opart, const float* lpart, void* O, int ldo, float* lse2, int R, int H,
+                                          int hd, int ns, int dtype, hipStream_t s) {
+  if (dtype == MAVLM_F16)
+    hipLaunchKernelGGL(attn_combine_kernel<F16>, dim3((R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)O, ldo, lse2, R, H,
+                       hd, ns);
+  else
+    hipLaunchKernelGGL(attn_combine_kernel<BF16>, dim3((R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)O, ldo, lse2, R, H,
+                       hd, ns);
+  return hipGetLastError();
+}
 
 // Split-KV plan: grids that fill less than ~60 % of the 512 workgroup slots (2 per CU) split the keys over
 // blockIdx.y.  Deterministic function of the shape: the fused step and the stand-alone operator take the same path.
@@ -422,7 +433,7 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
                        a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps);
     if (ns > 1)
       hipLaunchKernelGGL(attn_combine_kernel<F16>, dim3((a.R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
-                         a.lse2, a.R, a.H, ns);
+                         a.lse2, a.R, a.H, HD3, ns);
   } else {
     if (!done[0]) {
       hipError_t e = hipFuncSetAttribute((const void*)attn_fwd3_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN3_LDS);
@@ -433,7 +444,7 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
                        a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps);
     if (ns > 1)
       hipLaunchKernelGGL(attn_combine_kernel<BF16>, dim3((a.R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
-                         a.lse2, a.R, a.H, ns);
+                         a.lse2, a.R, a.H, HD3, ns);
   }
   return hipGetLastError();
 }

@@ -15,6 +15,7 @@
 //     attention.hip (2-way conflicts for the 16x16x32 operand reads, as the guide documents for this image).
 #include "mavlm_common.h"
 #include "mavlm_kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -45,7 +46,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd_kernel(const uint16_t* __r
                                                              const uint16_t* __restrict__ K, int ldk,
                                                              const uint16_t* __restrict__ V, int ldv,
                                                              uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
-                                                             int R, int S, int H, float c) {
+                                                             int R, int S, int H, float c, float* __restrict__ Opart,
+                                                             float* __restrict__ lse_part, int tps) {
+  // split-KV for small grids (as attn_fwd3_kernel): blockIdx.y owns the keys [y*tps*32, (y+1)*tps*32), writes a
+  // normalised fp32 partial + its log-sum-exp; attn_combine_kernel (attention3.hip) merges them
+  const int split = blockIdx.y;
+  if (tps > 0) {
+    const int k0 = split * tps * KTH;
+    K += (size_t)k0 * ldk;
+    V += (size_t)k0 * ldv;
+    S = (S - k0 < tps * KTH) ? S - k0 : tps * KTH;
+  }
   constexpr int NSUB = (HD + 127) / 128;                  // 128-column sub-images per tile row
   constexpr int SUB = KTH * 256;                          // 8 KiB per sub-image
   constexpr int TILE = NSUB * SUB;                        // one K or V tile
@@ -195,11 +206,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd_kernel(const uint16_t* __r
   const float inv = 1.0f / l_tot;
   const int q = q0 + qi;
   if (q < R) {
-    uint16_t* op = O + (size_t)q * ldo + h * HD + 4 * g;
+    if (tps > 0) {
+      float* pp = Opart + ((size_t)split * R + q) * (H * HD) + h * HD + 4 * g;
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
-      *(u32x2*)(op + 16 * db) = pack4<T>(ot[db][0] * inv, ot[db][1] * inv, ot[db][2] * inv, ot[db][3] * inv);
-    if (lse2 != nullptr && g == 0) lse2[(size_t)h * R + q] = m_run * c + log2f(l_tot);
+      for (int db = 0; db < DB; ++db)
+        *(f32x4*)(pp + 16 * db) = f32x4{ot[db][0] * inv, ot[db][1] * inv, ot[db][2] * inv, ot[db][3] * inv};
+      if (g == 0) lse_part[((size_t)split * H + h) * R + q] = m_run * c + log2f(l_tot);
+    } else {
+      uint16_t* op = O + (size_t)q * ldo + h * HD + 4 * g;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+        *(u32x2*)(op + 16 * db) = pack4<T>(ot[db][0] * inv, ot[db][1] * inv, ot[db][2] * inv, ot[db][3] * inv);
+      if (lse2 != nullptr && g == 0) lse2[(size_t)h * R + q] = m_run * c + log2f(l_tot);
+    }
   }
 }
 
@@ -309,8 +328,15 @@ hipError_t launch_fwd_hd(const mavlm_attn_args& a, hipStream_t s) {
     done = true;
   }
   const float c = a.scale * 1.44269504088896340736f;
-  hipLaunchKernelGGL(kern, dim3(((a.R + 127) / 128) * a.H), dim3(512), LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
-                     a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c);
+  int tps = 0;
+  int ns = a.split_ws != nullptr ? mavlm_attention_hd_splits(a.R, a.S, a.H, &tps) : 1;
+  if (ns <= 1) { ns = 1; tps = 0; }
+  float* opart = a.split_ws;
+  float* lpart = ns > 1 ? a.split_ws + (size_t)ns * a.R * a.H * HD : nullptr;
+  hipLaunchKernelGGL(kern, dim3(((a.R + 127) / 128) * a.H, ns), dim3(512), LDS, s, (const uint16_t*)a.Q, a.ldq,
+                     (const uint16_t*)a.K, a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c,
+                     opart, lpart, tps);
+  if (ns > 1) return mavlm_launch_attention_combine(opart, lpart, a.O, a.ldo, a.lse2, a.R, a.H, HD, ns, std::is_same<T, F16>::value ? MAVLM_F16 : MAVLM_BF16, s);
   return hipGetLastError();
 }
 
@@ -331,6 +357,28 @@ hipError_t launch_colsum_hd(const mavlm_colsum_args& a, hipStream_t s) {
 }
 
 }  // namespace
+
+// Split-KV plan of the wide-head kernel (128-query workgroups of 8 waves, at most 2 per CU; 32-key tiles)
+int mavlm_attention_hd_splits(int R, int S, int H, int* tiles_per_split) {
+  const int items = ((R + 127) / 128) * H;
+  const int nt = (S + KTH - 1) / KTH;
+  int ns = 1;
+  if (items < 200 && nt >= 32) {
+    ns = 400 / items;
+    if (ns > 8) ns = 8;
+    if (ns > nt / 16) ns = nt / 16;
+    if (ns < 2) ns = 1;
+  }
+  int tps = (nt + ns - 1) / ns;
+  ns = (nt + tps - 1) / tps;
+  if (tiles_per_split) *tiles_per_split = ns > 1 ? tps : 0;
+  return ns;
+}
+
+size_t mavlm_attention_hd_split_ws_floats(int R, int S, int H, int head_dim) {
+  const int ns = mavlm_attention_hd_splits(R, S, H, nullptr);
+  return ns > 1 ? (size_t)ns * R * H * head_dim + (size_t)ns * H * R : 0;
+}
 
 hipError_t mavlm_launch_attention_hd(const mavlm_attn_args& a, int head_dim, int dtype, hipStream_t s) {
   const bool f16 = dtype == MAVLM_F16;

@@ -236,6 +236,9 @@ static bool use_256(const mavlm_gemm_args& g) {
 int mavlm_gemm_splits(int M, int N, int K, int epilogue, int ldc) {
   if (M <= 0 || N % BN || K % BK || ldc != N || epilogue == MAVLM_EPI_RES_F32) return 1;
   const long tiles = (long)((M + BM - 1) / BM) * (N / BN);
+  // at most one 128^2 tile per two CUs and a long contraction.  (Measured: extending this to grids of up to 448 tiles,
+  // e.g. the 364-tile GEMMs of R = 1568 at the OneVision-7B width, LOSES 4 % end to end - the partial planes cost more
+  // than the idle CUs.)
   if (tiles > 128 || K < 2048) return 1;
   int splits = K / 1024;
   if (splits > 4) splits = 4;

@@ -59,10 +59,12 @@ void carve(mavlm_ctx* x) {
   x->o_part = o; o += al(H * S * 4);
   // split-KV partials of the attention (small grids only: mavlm_attention_splits): worst case over the key count
   x->o_split = o;
-  if (!wide_heads(c)) {
+  {
     const size_t items = ((R + 127) / 128) * H;
-    const size_t cap = items < 320 ? (512 / items > 8 ? 8 : 512 / items) : 0;
-    if (cap >= 2) o += al(cap * (R * H * 128 + H * R) * 4);
+    size_t cap;
+    if (!wide_heads(c)) cap = items < 320 ? (512 / items > 8 ? 8 : 512 / items) : 0;      // mavlm_attention_splits
+    else cap = items < 200 ? (400 / items > 8 ? 8 : 400 / items) : 0;                      // mavlm_attention_hd_splits
+    if (cap >= 2) o += al(cap * (R * Dp + H * R) * 4);
   }
   // split-K planes of the GEMMs with few output tiles and a long contraction (mavlm_gemm_splits): the I -> D
   // projections (MLP down, fuser second layer) at small R
@@ -118,7 +120,7 @@ int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const 
   mavlm_attn_args a;
   a.Q = ws(x, x->o_q); a.ldq = Dp; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = ws(x, x->o_ctx); a.ldo = Dp;
   a.lse2 = lse2; a.R = R; a.S = S; a.H = H; a.scale = attn_scale(c);
-  a.split_ws = (!wide_heads(c) && x->total > x->o_split) ? (float*)ws(x, x->o_split) : nullptr;
+  a.split_ws = x->o_gsplit > x->o_split ? (float*)ws(x, x->o_split) : nullptr;
   if (wide_heads(c)) {
     MAVLM_TRY(mavlm_launch_attention_hd(a, c.hidden / c.heads, dt, s));
   } else {
@@ -399,6 +401,26 @@ int mavlm_attention_hd(const void* Q, int32_t ldq, const void* K, int32_t ldk, c
   mavlm_attn_args a;
   a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.lse2 = lse2;
   a.R = R; a.S = S; a.H = H; a.scale = scale;
+  return (int)mavlm_launch_attention_hd(a, head_dim, dtype, (hipStream_t)stream);
+}
+
+int64_t mavlm_attention_hd_ws_floats(int32_t R, int32_t S, int32_t H, int32_t head_dim) {
+  return (R > 0 && S > 0 && H > 0 && head_dim > 0) ? (int64_t)mavlm_attention_hd_split_ws_floats(R, S, H, head_dim) : 0;
+}
+
+int mavlm_attention_hd_ws(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
+                          int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, int32_t head_dim, float scale, float* ws_,
+                          int64_t ws_floats, int32_t dtype, void* stream) {
+  if (!Q || !K || !V || !O || R <= 0 || S <= 0 || H <= 0 || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) ||
+      ldq < H * head_dim || ldk < head_dim || ldv < head_dim)
+    return MAVLM_E_ARG;
+  if (head_dim != 448 && head_dim != 128 && head_dim != 256 && head_dim != 224) return MAVLM_E_SHAPE;
+  const int64_t need = (int64_t)mavlm_attention_hd_split_ws_floats(R, S, H, head_dim);
+  if (need > 0 && (!ws_ || ws_floats < need)) return MAVLM_E_ARG;        // the plan is part of the result
+  mavlm_attn_args a;
+  a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.lse2 = lse2;
+  a.R = R; a.S = S; a.H = H; a.scale = scale;
+  a.split_ws = need > 0 ? ws_ : nullptr;
   return (int)mavlm_launch_attention_hd(a, head_dim, dtype, (hipStream_t)stream);
 }
 

@@ -350,6 +350,21 @@ def split_plan(R: int, S: int, heads: int) -> Tuple[int, int]:
     return ns, (tps if ns > 1 else 0)
 
 
+def split_plan_wide(R: int, S: int, heads: int) -> Tuple[int, int]:
+    """(number of key splits, tiles per split) of the wide-head kernel (32-key tiles) - mirrors
+    mavlm_attention_hd_splits (csrc/attention_hd.hip)."""
+    items = -(-R // 128) * heads
+    nt = -(-S // 32)
+    ns = 1
+    if items < 200 and nt >= 32:
+        ns = min(8, 400 // items, nt // 16)
+        if ns < 2:
+            ns = 1
+    tps = -(-nt // ns)
+    ns = -(-nt // tps)
+    return ns, (tps if ns > 1 else 0)
+
+
 def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mode: str = "fp32",
                     want_colsum: bool = False, want_probs: bool = False, kv_tile: Optional[int] = None,
                     wave_rows: Optional[int] = None):
@@ -401,7 +416,12 @@ def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mod
                     m = m_new
                 return acc, m, l
 
-            ns, tps = split_plan(R, Lk, heads) if (d <= 128 and kv_tile == KV_TILE) else (1, 0)
+            if kv_tile == KV_TILE:            # attention3.hip (head_dim <= 128)
+                ns, tps = split_plan(R, Lk, heads)
+            elif kv_tile == 32:               # attention_hd.hip
+                ns, tps = split_plan_wide(R, Lk, heads)
+            else:
+                ns, tps = 1, 0
             if ns == 1:
                 acc, m, l = run(0, Lk)
             else:

@@ -4,13 +4,15 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+if os.environ.get("HIDDEN"):
+    bench.HIDDEN = int(os.environ["HIDDEN"])
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 bench.MEM_TOKENS = M
 dev = torch.device("cuda", 0)
 model, arch = bench.build_model(dev)
-x = torch.randn(T, 196, 1024, device=dev).bfloat16()
+x = torch.randn(T, 196, bench.HIDDEN, device=dev).bfloat16()
 idx = torch.arange(T) % 600
-mp = torch.randn(10, 1024, device=dev).bfloat16(); fp = torch.randn(9, 1024, device=dev).bfloat16()
+mp = torch.randn(10, bench.HIDDEN, device=dev).bfloat16(); fp = torch.randn(9, bench.HIDDEN, device=dev).bfloat16()
 
 def timed(fn, n=30):
     for _ in range(5): fn()

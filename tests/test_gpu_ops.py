@@ -272,10 +272,13 @@ def test_pool_bilinear_vs_oracle_and_reference_golden(mode):
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("hd,R,S,H", [(128, 200, 300, 2), (448, 16, 32, 1), (448, 200, 300, 2), (448, 129, 97, 1),
-                                      (448, 392, 588, 8), (128, 1, 1, 1), (448, 1, 1, 1)])
+                                      (448, 392, 588, 8), (128, 1, 1, 1), (448, 1, 1, 1), (448, 196, 2048, 2),
+                                      (128, 100, 1100, 1), (448, 1568, 6272, 8)])
 def test_attention_wide_heads_vs_oracle(mode, hd, R, S, H):
     """attention_hd.hip: 16-query waves on 16x16x32 MFMA, head_dim 448 (LLaVA-OneVision-7B) and 128 (cross-check of
-    the same machinery); oracle emulation with that kernel's tiling (32-key tiles, 16-query waves)."""
+    the same machinery); oracle emulation with that kernel's tiling (32-key tiles, 16-query waves).  The last three
+    shapes are small grids with many key tiles: the kernel splits the keys (partials + merge), the oracle mirrors the
+    plan."""
     r = O.rounder(mode)
     W = H * hd
     q = r(O.hash_normal_like((R, W), 81))
