@@ -10,6 +10,9 @@ T = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 bench.MEM_TOKENS = M
 dev = torch.device("cuda", 0)
 model, arch = bench.build_model(dev)
+if os.environ.get("MAVLM_GEMM_TILE"):
+    from memory_augmented_vlm_amd import _capi as _c
+    _c.check(_c.lib().mavlm_set_gemm_tile(int(os.environ["MAVLM_GEMM_TILE"])), "tile")
 x = torch.randn(T, 196, bench.HIDDEN, device=dev).bfloat16()
 idx = torch.arange(T) % 600
 mp = torch.randn(10, bench.HIDDEN, device=dev).bfloat16(); fp = torch.randn(9, bench.HIDDEN, device=dev).bfloat16()
