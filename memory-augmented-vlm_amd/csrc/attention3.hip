@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
                                                            const uint16_t* __restrict__ V, int ldv,
                                                            uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
                                                            int R, int S, int H, float c, float* __restrict__ Opart,
-                                                           float* __restrict__ lse_part, int tps, int lse_ld) {
+                                                           float* __restrict__ lse_part, int tps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // split-KV (small grids, tps > 0): blockIdx.y owns the keys [y*tps*64, (y+1)*tps*64) and writes a NORMALISED fp32
   // partial + its log-sum-exp; attn_combine_kernel merges the splits.  The body below is unchanged: only the K/V
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
         for (int g = 0; g < 4; ++g)
           *(u32x2*)(op + 32 * db + 8 * g) = pack4<T>(ot[db][4 * g] * inv, ot[db][4 * g + 1] * inv,
                                                      ot[db][4 * g + 2] * inv, ot[db][4 * g + 3] * inv);
-      if (lse2 != nullptr && hh == 0) lse2[(size_t)h * lse_ld + q] = m_run * c + log2f(l_tot);
+      if (lse2 != nullptr && hh == 0) lse2[(size_t)h * R + q] = m_run * c + log2f(l_tot);
     }
   }
 }
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
 template <typename T>
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ Opart, const float* __restrict__ lse_part,
                                                            uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
-                                                           int R, int H, int hd, int ns, int lse_ld) {
+                                                           int R, int H, int hd, int ns) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= R) return;
@@ -374,112 +374,79 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
     uint16_t* op = O + (size_t)q * ldo + col;
 #pragma unroll
     for (int v = 0; v < 4; ++v) *(u32x2*)(op + 4 * v) = pack4<T>(acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]);
-    if (lse2 != nullptr && col % hd == 0) lse2[(size_t)h * lse_ld + q] = lse;
+    if (lse2 != nullptr && col % hd == 0) lse2[(size_t)h * R + q] = lse;
   }
 }
 
 }  // namespace
 
 hipError_t mavlm_launch_attention_combine(const float* opart, const float* lpart, void* O, int ldo, float* lse2, int R, int H,
-                                          int hd, int ns, int dtype, hipStream_t s, int lse_ld) {
-  if (lse_ld <= 0) lse_ld = R;
+                                          int hd, int ns, int dtype, hipStream_t s) {
   if (dtype == MAVLM_F16)
     hipLaunchKernelGGL(attn_combine_kernel<F16>, dim3((R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)O, ldo, lse2, R, H,
-                       hd, ns, lse_ld);
+                       hd, ns);
   else
     hipLaunchKernelGGL(attn_combine_kernel<BF16>, dim3((R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)O, ldo, lse2, R, H,
-                       hd, ns, lse_ld);
+                       hd, ns);
   return hipGetLastError();
 }
 
-// Split-KV plan.  A workgroup = 128 queries of one head; 512 fit the chip at once (2 per CU).
-//   * fewer than 320 workgroups (small grids): ALL rows split their keys over blockIdx.y;
-//   * more than 512 with a last "round" that would run 25-75 % empty (e.g. 784 = 512 + 272 at the bench shape: two
-//     rounds for 1.53 rounds of work): the rows of the full rounds run unsplit, the REMAINING rows split their keys
-//     ns-way, ns chosen so that their ns*rem workgroups waste the least (784: ns = 3 -> 1 + 2/3 rounds instead of 2).
-//     Measured, same box: 394 -> 382 us at S = 6272, 712 -> 674 us at S = 12544 (the gain is smaller than the round
-//     count suggests because a last round with one workgroup per CU runs each of them ~1.6x faster than a shared CU).
-// rows_full = rows handled unsplit (0 = all rows split, R = none split); the rest splits into ns key ranges of tps
-// tiles.  Deterministic function of the shape: the fused step, the stand-alone operator and the oracle share it.
-int mavlm_attention_plan(int R, int S, int H, int* rows_full, int* tiles_per_split) {
-  const int qb = (R + 127) / 128;
-  const int items = qb * H;
+// Split-KV plan: grids that fill less than ~60 % of the 512 workgroup slots (2 per CU) split the keys over
+// blockIdx.y.  Deterministic function of the shape: the fused step and the stand-alone operator take the same path.
+int mavlm_attention_splits(int R, int S, int H, int* tiles_per_split) {
+  const int items = ((R + 127) / 128) * H;
   const int nt = (S + KT3 - 1) / KT3;
-  int ns = 1, full = R;
+  int ns = 1;
   if (items < 320 && nt >= 16) {
     ns = 512 / items;
     if (ns > 8) ns = 8;
     if (ns > nt / 8) ns = nt / 8;
     if (ns < 2) ns = 1;
-    full = ns > 1 ? 0 : R;
-  } else if (items > 512 && 512 % H == 0 && nt >= 24) {
-    const int rounds = items / 512, rem = items - rounds * 512;
-    if (rem > 0) {
-      int best = 1;
-      double best_t = 1.0;                                     // the remainder's cost today: one whole round
-      for (int n = 2; n <= 4; ++n) {
-        if (nt / n < 8) break;
-        const double t = (double)((rem * n + 511) / 512) / n + 0.04;   // + the merge pass
-        if (t < best_t - 0.15) { best_t = t; best = n; }
-      }
-      if (best > 1) { ns = best; full = rounds * (512 / H) * 128; }
-    }
   }
   int tps = (nt + ns - 1) / ns;
   ns = (nt + tps - 1) / tps;
-  if (ns <= 1) { ns = 1; full = R; }
-  if (rows_full) *rows_full = full;
   if (tiles_per_split) *tiles_per_split = ns > 1 ? tps : 0;
   return ns;
 }
 
-int mavlm_attention_splits(int R, int S, int H, int* tiles_per_split) {     // whole-launch split only (small grids)
-  int full = 0;
-  const int ns = mavlm_attention_plan(R, S, H, &full, tiles_per_split);
-  return full == 0 ? ns : 1;
-}
-
 size_t mavlm_attention_split_ws_floats(int R, int S, int H) {
-  int full = 0;
-  const int ns = mavlm_attention_plan(R, S, H, &full, nullptr);
-  const size_t rs = (size_t)(R - full);
-  return ns > 1 ? (size_t)ns * rs * H * HD3 + (size_t)ns * H * rs : 0;
-}
-
-template <typename T>
-static hipError_t launch3(const mavlm_attn_args& a, hipStream_t s) {
-  const float c = a.scale * 1.44269504088896340736f;
-  static bool done = false;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN3_LDS);
-    if (e != hipSuccess) return e;
-    done = true;
-  }
-  int tps = 0, full = a.R;
-  int ns = a.split_ws != nullptr ? mavlm_attention_plan(a.R, a.S, a.H, &full, &tps) : 1;
-  if (ns <= 1) { ns = 1; tps = 0; full = a.R; }
-  const uint16_t* Q = (const uint16_t*)a.Q;
-  uint16_t* O = (uint16_t*)a.O;
-  if (full > 0)          // rows [0, full): whole key range per workgroup
-    hipLaunchKernelGGL(attn_fwd3_kernel<T>, dim3(((full + 127) / 128) * a.H), dim3(256), ATTN3_LDS, s, Q, a.ldq,
-                       (const uint16_t*)a.K, a.ldk, (const uint16_t*)a.V, a.ldv, O, a.ldo, a.lse2, full, a.S, a.H, c,
-                       (float*)nullptr, (float*)nullptr, 0, a.R);
-  if (full < a.R) {      // rows [full, R): keys split ns-way, merged afterwards
-    const int rs = a.R - full;
-    float* opart = a.split_ws;
-    float* lpart = a.split_ws + (size_t)ns * rs * a.H * HD3;
-    float* lse_t = a.lse2 ? a.lse2 + full : nullptr;
-    hipLaunchKernelGGL(attn_fwd3_kernel<T>, dim3(((rs + 127) / 128) * a.H, ns), dim3(256), ATTN3_LDS, s,
-                       Q + (size_t)full * a.ldq, a.ldq, (const uint16_t*)a.K, a.ldk, (const uint16_t*)a.V, a.ldv,
-                       O + (size_t)full * a.ldo, a.ldo, lse_t, rs, a.S, a.H, c, opart, lpart, tps, a.R);
-    hipLaunchKernelGGL(attn_combine_kernel<T>, dim3((rs + 3) / 4), dim3(256), 0, s, opart, lpart, O + (size_t)full * a.ldo,
-                       a.ldo, lse_t, rs, a.H, HD3, ns, a.R);
-  }
-  return hipGetLastError();
+  const int ns = mavlm_attention_splits(R, S, H, nullptr);
+  return ns > 1 ? (size_t)ns * R * H * HD3 + (size_t)ns * H * R : 0;
 }
 
 hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStream_t s) {
-  return dtype == MAVLM_F16 ? launch3<F16>(a, s) : launch3<BF16>(a, s);
+  const float c = a.scale * 1.44269504088896340736f;
+  int tps = 0;
+  int ns = a.split_ws != nullptr ? mavlm_attention_splits(a.R, a.S, a.H, &tps) : 1;
+  if (ns <= 1) { ns = 1; tps = 0; }
+  float* opart = a.split_ws;
+  float* lpart = ns > 1 ? a.split_ws + (size_t)ns * a.R * a.H * HD3 : nullptr;
+  dim3 grid(((a.R + 127) / 128) * a.H, ns);
+  static bool done[2] = {false, false};
+  if (dtype == MAVLM_F16) {
+    if (!done[1]) {
+      hipError_t e = hipFuncSetAttribute((const void*)attn_fwd3_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN3_LDS);
+      if (e != hipSuccess) return e;
+      done[1] = true;
+    }
+    hipLaunchKernelGGL(attn_fwd3_kernel<F16>, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
+                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps);
+    if (ns > 1)
+      hipLaunchKernelGGL(attn_combine_kernel<F16>, dim3((a.R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
+                         a.lse2, a.R, a.H, HD3, ns);
+  } else {
+    if (!done[0]) {
+      hipError_t e = hipFuncSetAttribute((const void*)attn_fwd3_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN3_LDS);
+      if (e != hipSuccess) return e;
+      done[0] = true;
+    }
+    hipLaunchKernelGGL(attn_fwd3_kernel<BF16>, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
+                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps);
+    if (ns > 1)
+      hipLaunchKernelGGL(attn_combine_kernel<BF16>, dim3((a.R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
+                         a.lse2, a.R, a.H, HD3, ns);
+  }
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -62,17 +62,9 @@ void carve(mavlm_ctx* x) {
   {
     const size_t items = ((R + 127) / 128) * H;
     size_t cap;
-    size_t rows = R;
-    if (!wide_heads(c)) {                                                                  // mavlm_attention_plan
-      cap = items < 320 ? (512 / items > 8 ? 8 : 512 / items) : 0;
-      if (items > 512 && 512 % H == 0 && items % 512) {       // tail split of a big grid: at most 4 ways, tail rows only
-        cap = 4;
-        rows = R - (items / 512) * (512 / H) * 128;
-      }
-    } else {
-      cap = items < 200 ? (400 / items > 8 ? 8 : 400 / items) : 0;                        // mavlm_attention_hd_splits
-    }
-    if (cap >= 2) o += al(cap * (rows * Dp + H * rows) * 4);
+    if (!wide_heads(c)) cap = items < 320 ? (512 / items > 8 ? 8 : 512 / items) : 0;      // mavlm_attention_splits
+    else cap = items < 200 ? (400 / items > 8 ? 8 : 400 / items) : 0;                      // mavlm_attention_hd_splits
+    if (cap >= 2) o += al(cap * (R * Dp + H * R) * 4);
   }
   // split-K planes of the GEMMs with few output tiles and a long contraction (mavlm_gemm_splits): the I -> D
   // projections (MLP down, fuser second layer) at small R

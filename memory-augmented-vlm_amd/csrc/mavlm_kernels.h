@@ -45,14 +45,12 @@ struct mavlm_attn_args {
 hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream_t s);
 // split-KV plan for grids too small to fill the chip (attention3.hip): number of key splits (1 = none)
 int mavlm_attention_splits(int R, int S, int H, int* tiles_per_split);
-// general plan: rows [0, rows_full) unsplit, the rest split ns-way (small grids: rows_full = 0; tail of a big grid)
-int mavlm_attention_plan(int R, int S, int H, int* rows_full, int* tiles_per_split);
 size_t mavlm_attention_split_ws_floats(int R, int S, int H);
 // the same for the wide-head kernel (attention_hd.hip) and the merge kernel both use (attention3.hip)
 int mavlm_attention_hd_splits(int R, int S, int H, int* tiles_per_split);
 size_t mavlm_attention_hd_split_ws_floats(int R, int S, int H, int head_dim);
 hipError_t mavlm_launch_attention_combine(const float* opart, const float* lpart, void* O, int ldo, float* lse2, int R, int H,
-                                          int hd, int ns, int dtype, hipStream_t s, int lse_ld = 0);
+                                          int hd, int ns, int dtype, hipStream_t s);
 // software-pipelined LDS-DMA variant (attention3.hip); mavlm_launch_attention dispatches to it
 hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStream_t s);
 extern int g_mavlm_attn_impl;   // 0 = auto, 2 = register-staged kernel, 3 = pipelined kernel (tuning hook)

@@ -335,36 +335,19 @@ def kernel_tiling(head_dim: int) -> Tuple[int, int]:
     return (KV_TILE, WAVE_ROWS) if head_dim <= 128 else (32, 16)
 
 
-def split_plan(R: int, S: int, heads: int) -> Tuple[int, int, int]:
-    """(rows handled unsplit, number of key splits for the remaining rows, tiles per split) of the head_dim<=128
-    attention kernel - mirrors mavlm_attention_plan (csrc/attention3.hip): small grids split the keys for all rows;
-    a big grid whose last round of workgroups would run mostly empty splits the keys for the rows of that round."""
-    qb = -(-R // 128)
-    items = qb * heads
+def split_plan(R: int, S: int, heads: int) -> Tuple[int, int]:
+    """(number of key splits, tiles per split) of the head_dim<=128 attention kernel - mirrors
+    mavlm_attention_splits (csrc/attention3.hip): grids of fewer than 320 workgroups split the keys."""
+    items = -(-R // 128) * heads
     nt = -(-S // KV_TILE)
-    ns, full = 1, R
+    ns = 1
     if items < 320 and nt >= 16:
         ns = min(8, 512 // items, nt // 8)
         if ns < 2:
             ns = 1
-        full = 0 if ns > 1 else R
-    elif items > 512 and 512 % heads == 0 and nt >= 24:
-        rounds, rem = divmod(items, 512)
-        if rem > 0:
-            best, best_t = 1, 1.0
-            for n in (2, 3, 4):
-                if nt // n < 8:
-                    break
-                t = float((rem * n + 511) // 512) / n + 0.04
-                if t < best_t - 0.15:
-                    best_t, best = t, n
-            if best > 1:
-                ns, full = best, rounds * (512 // heads) * 128
     tps = -(-nt // ns)
     ns = -(-nt // tps)
-    if ns <= 1:
-        ns, full = 1, R
-    return full, ns, (tps if ns > 1 else 0)
+    return ns, (tps if ns > 1 else 0)
 
 
 def split_plan_wide(R: int, S: int, heads: int) -> Tuple[int, int]:
@@ -414,18 +397,17 @@ def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mod
             l = p.sum(axis=1, keepdims=True, dtype=F32)
             acc = _mm(p, V[:, sl])
         else:
-            def run(rows, k_lo, k_hi):
-                n = rows.stop - rows.start
-                m = np.full((n, 1), -1e30, dtype=F32)
-                l = np.zeros((n, 1), dtype=F32)
-                acc = np.zeros((n, d), dtype=F32)
+            def run(k_lo, k_hi):
+                m = np.full((R, 1), -1e30, dtype=F32)
+                l = np.zeros((R, 1), dtype=F32)
+                acc = np.zeros((R, d), dtype=F32)
                 for k0 in range(k_lo, k_hi, kv_tile):
-                    st = s[rows, k0:min(k0 + kv_tile, k_hi)]
+                    st = s[:, k0:min(k0 + kv_tile, k_hi)]
                     cand = np.maximum(m, st.max(axis=1, keepdims=True))
                     need = ((cand - m) * F32(1.4426950408889634) > F32(RESCALE_LOG2)).reshape(-1)
-                    pad = (-n) % wave_rows
+                    pad = (-R) % wave_rows
                     grp = np.concatenate([need, np.zeros(pad, bool)]).reshape(-1, wave_rows).any(axis=1)
-                    move = np.repeat(grp, wave_rows)[:n].reshape(n, 1)
+                    move = np.repeat(grp, wave_rows)[:R].reshape(R, 1)
                     m_new = np.where(move, cand, m).astype(F32)
                     alpha = np.exp(m - m_new, dtype=F32)
                     pt = np.exp(st - m_new, dtype=F32)
@@ -434,34 +416,26 @@ def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mod
                     m = m_new
                 return acc, m, l
 
-            def split_rows(rows, ns, tps):
-                # split-KV (attention3.hip / attention_hd.hip): each split yields a normalised fp32 partial + its
+            if kv_tile == KV_TILE:            # attention3.hip (head_dim <= 128)
+                ns, tps = split_plan(R, Lk, heads)
+            elif kv_tile == 32:               # attention_hd.hip
+                ns, tps = split_plan_wide(R, Lk, heads)
+            else:
+                ns, tps = 1, 0
+            if ns == 1:
+                acc, m, l = run(0, Lk)
+            else:
+                # split-KV (attention3.hip, small grids): each split yields a normalised fp32 partial + its
                 # log-sum-exp; the merge weights them by 2^(lse_s - lse)
                 parts = []
                 for sp in range(ns):
-                    a_, m_, l_ = run(rows, sp * tps * kv_tile, min((sp + 1) * tps * kv_tile, Lk))
+                    a_, m_, l_ = run(sp * tps * kv_tile, min((sp + 1) * tps * kv_tile, Lk))
                     parts.append(((a_ / l_).astype(F32), (m_ + np.log(l_)).astype(F32)))
                 mx = np.maximum.reduce([p_[1] for p_ in parts])
                 den = sum(np.exp(p_[1] - mx, dtype=F32) for p_ in parts)
                 lse_t = (mx + np.log(den)).astype(F32)
-                acc_ = sum(np.exp(p_[1] - lse_t, dtype=F32) * p_[0] for p_ in parts).astype(F32)
-                return acc_, lse_t, np.ones((rows.stop - rows.start, 1), dtype=F32)
-
-            if kv_tile == KV_TILE:            # attention3.hip (head_dim <= 128)
-                full, ns, tps = split_plan(R, Lk, heads)
-            elif kv_tile == 32:               # attention_hd.hip
-                ns, tps = split_plan_wide(R, Lk, heads)
-                full = 0 if ns > 1 else R
-            else:
-                full, ns, tps = R, 1, 0
-            pieces = []
-            if full > 0:
-                pieces.append(run(slice(0, full), 0, Lk))
-            if full < R:
-                pieces.append(split_rows(slice(full, R), ns, tps))
-            acc = np.concatenate([p_[0] for p_ in pieces], axis=0)
-            m = np.concatenate([p_[1] for p_ in pieces], axis=0)
-            l = np.concatenate([p_[2] for p_ in pieces], axis=0)
+                acc = sum(np.exp(p_[1] - lse_t, dtype=F32) * p_[0] for p_ in parts).astype(F32)
+                m, l = lse_t, np.ones((R, 1), dtype=F32)
         ctx[:, sl] = acc / l                                                 # :53
         lse = m + np.log(l)
         lse2[h] = (lse / F32(math.log(2.0))).reshape(-1)
