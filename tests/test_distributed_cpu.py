@@ -76,3 +76,34 @@ def test_row_sharded_memory_argument_checks():
     proj = types.SimpleNamespace(num_memory_tokens=8, patch_size=196)
     s = D.RowShardedMemory(proj)
     assert (s.world, s.rank, s.rows, s.r0) == (1, 0, 8 * 196, 0) and s.cache == []
+
+
+def _dropout_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import types
+    from memory_augmented_vlm_amd.model import llava_arch as arch
+    D.init_from_env("gloo")
+    torch.manual_seed(1000 + 17 * rank)                    # different RNG streams per rank, as in a real job
+    me = types.SimpleNamespace(device=torch.device("cpu"))
+    draws = [arch.LlavaMetaForCausalLM.get_synced_dropout_decision(me, 0.5) for _ in range(24)]
+    q.put((rank, draws))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_synced_dropout_decision_world2():
+    """llava_arch.py:378-386: rank 0 draws Bernoulli(p), a 1-element broadcast makes every rank take the same branch
+    (frames dropped or kept) although their RNG streams differ."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dropout_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0] == res[1] and all(isinstance(d, bool) for d in res[0])
+    assert 2 <= sum(res[0]) <= 22                          # a fair coin, not a constant
