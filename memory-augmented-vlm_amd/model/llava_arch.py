@@ -46,6 +46,9 @@ class MemoryFuserMLP(nn.Sequential):
         super().__init__(nn.Linear(hidden, hidden * 4), nn.GELU(), nn.Linear(hidden * 4, hidden))
 
     def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .. import _autograd as ag            # training: same kernels as autograd Functions
+            return ag.fuser_mlp(self, x)
         x2 = x.reshape(-1, x.shape[-1])
         u = ops.linear(x2, self[0].weight, self[0].bias.float(), capi.EPI_GELU)
         y = ops.linear(u, self[2].weight, self[2].bias.float(), capi.EPI_BIAS)

@@ -49,6 +49,13 @@ class Config:
     max_chunk_frames = 32
 
 
+def _wants_grad(module, *tensors) -> bool:
+    """Autograd is recording and something on this call can receive a gradient: take the training path (the same
+    kernels wrapped as autograd Functions, _autograd.py) instead of the plain launches, which record no graph."""
+    return torch.is_grad_enabled() and (any(t is not None and t.requires_grad for t in tensors)
+                                        or any(p.requires_grad for p in module.parameters()))
+
+
 class FusedAttentionStats:
     """What the fused kernel keeps of the attention probabilities: per-(head,query) log2-sum-exp and, on demand,
     the per-key column sums  sum_h sum_q p[h,q,k]  (all the reference ever reads, MemoryController.py:135)."""
@@ -75,6 +82,10 @@ class Residual(nn.Module):
         shp = input_tensor.shape
         h2 = hidden_states.reshape(-1, hidden_states.shape[-1])
         x2 = input_tensor.reshape(-1, shp[-1])
+        if _wants_grad(self, hidden_states, input_tensor):
+            from ... import _autograd as ag
+            return ag.DenseResidualNormFn.apply(h2, self.dense.weight.to(h2.dtype), self.dense.bias, x2,
+                                                self.layernorm.weight, self.layernorm.bias, self.layernorm.eps).reshape(shp)
         pre = ops.linear(h2, self.dense.weight, self.dense.bias.float(), capi.EPI_RES_F32, residual=x2)
         out = ops.layernorm(pre, self.layernorm.weight.float(), self.layernorm.bias.float(), self.layernorm.eps, x2.dtype)
         return out.reshape(shp)
@@ -101,6 +112,12 @@ class Attention(nn.Module):
                                   "fused TransformerProjector path (zero-padded heads)")
         kv = hidden_states if kv_hidden_states is None else kv_hidden_states
         xq, xkv = hidden_states[0], kv[0]
+        if _wants_grad(self, hidden_states, kv):
+            from ... import _autograd as ag
+            k_, v_ = ag.project_kv([self], xkv)[0]
+            out, st = ag.attention_block(self, xq, k_, v_, want_stats=output_attentions)
+            stats = FusedAttentionStats(st[0].detach(), st[1].detach(), st[2], self.num_attention_heads) if st else None
+            return out[None], stats
         q = ops.linear(xq, self.q_proj.weight, self.q_proj.bias.float())
         k = ops.linear(xkv, self.k_proj.weight, self.k_proj.bias.float())
         v = ops.linear(xkv, self.v_proj.weight, self.v_proj.bias.float())
@@ -126,6 +143,9 @@ class TransformerLayer(nn.Module):
 
     def forward(self, query_states, kv_states):
         a, stats = self.memory_segment_fusion_attention(query_states, kv_hidden_states=kv_states, output_attentions=True)
+        if _wants_grad(self, query_states, kv_states):
+            from ... import _autograd as ag
+            return ag.mlp_block(self, a[0])[None], stats
         h = ops.linear(a[0], self.mlp[0].weight, self.mlp[0].bias.float(), capi.EPI_RELU)
         return self.residual(h[None], a), stats
 

@@ -60,5 +60,10 @@ class TemporalPositionalEncoding(nn.Module):
         idx = frame_indices.reshape(-1).to(device=x.device, dtype=torch.int64)
         tab = self.table().to(device=x.device, dtype=x.dtype)  # `.to(x.dtype)`, position_encoding.py:58
         x3 = x.contiguous().reshape(-1, x.shape[-2], x.shape[-1])
+        if torch.is_grad_enabled() and (x.requires_grad or (self.learnable and tab.requires_grad)):
+            # a gradient has to flow (learnable table, or frame features that are not detached): the gather + add is
+            # index plumbing, left to autograd; the reference configuration (fixed table, detached features,
+            # llava_arch.py:150,302) never takes this branch
+            return (x3 + tab[idx][:, None, :]).reshape(x.shape)
         out = ops.row_add(x3, tab.contiguous(), idx=idx)
         return out.reshape(x.shape)

@@ -24,8 +24,9 @@ class IdentityMap(nn.Module):
 
 
 class MlpGeluProjector(nn.Sequential):
-    """Linear(mm_hidden, D) [GELU Linear(D, D)]*(depth-1); forward only (the reference detaches its output,
-    llava_arch.py:302)."""
+    """Linear(mm_hidden, D) [GELU Linear(D, D)]*(depth-1).  The reference detaches this module's output
+    (llava_arch.py:302), so the hot path only needs the forward; with autograd recording and trainable parameters the
+    same GEMMs run as autograd Functions (backward in HIP, _autograd.py) so that nothing is silently constant."""
 
     def __init__(self, mm_hidden: int, hidden: int, depth: int):
         mods = [nn.Linear(mm_hidden, hidden)]
@@ -38,9 +39,16 @@ class MlpGeluProjector(nn.Sequential):
         y = x.reshape(-1, x.shape[-1])
         if not y.is_contiguous():
             y = y.contiguous()
+        import torch
+        train = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if train:
+            from ... import _autograd as ag
         for i, m in enumerate(lin):
             last = i == len(lin) - 1
-            y = ops.linear(y, m.weight, m.bias.float(), capi.EPI_BIAS if last else capi.EPI_GELU)
+            if train:
+                y = ag.LinearFn.apply(y, m.weight.to(y.dtype), m.bias, ag.ACT_NONE if last else ag.ACT_GELU)
+            else:
+                y = ops.linear(y, m.weight, m.bias.float(), capi.EPI_BIAS if last else capi.EPI_GELU)
         return y.reshape(*x.shape[:-1], y.shape[-1])
 
 

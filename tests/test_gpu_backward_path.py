@@ -220,3 +220,66 @@ def test_fp32_master_parameters_with_16bit_activations():
         assert p.grad.dtype == torch.float32
         if g16[name] is not None and not name.endswith("k_proj.bias"):
             assert O.rel_l2(g16[name], g32[name]) < 4e-3, name
+
+
+def test_standalone_modules_are_differentiable():
+    """A maintainer who only swaps the reference's imports keeps llava_arch.py's own calls, e.g.
+    `self.get_model().memory_fuser(memory_tokens)` (:546) - those stand-alone forwards must record a graph too, not
+    silently return constants.  MemoryFuserMLP, TransformerLayer (Attention + Residual inside) against torch autograd
+    of the same modules in fp32."""
+    from memory_augmented_vlm_amd.model.memory_module.MemoryController import Config, TransformerLayer
+    torch.manual_seed(3)
+    D = 256
+    fuser = arch.MemoryFuserMLP(D).cuda().to(torch.bfloat16)
+    ref = torch.nn.Sequential(torch.nn.Linear(D, 4 * D), torch.nn.GELU(), torch.nn.Linear(4 * D, D)).cuda()
+    ref.load_state_dict({k: v.float() for k, v in fuser.state_dict().items()})
+    x = (torch.randn(3, 196, D, device="cuda") * 0.5).bfloat16().requires_grad_()
+    xr = x.detach().float().requires_grad_()
+    g = (torch.randn(3, 196, D, device="cuda") * 0.1).bfloat16()
+    y = fuser(x)
+    assert y.requires_grad
+    y.backward(g)
+    ref(xr).backward(g.float())
+    assert O.rel_l2(to_np(x.grad), to_np(xr.grad)) < 2e-2
+    for (n, p), (_, pr) in zip(fuser.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and O.rel_l2(to_np(p.grad), to_np(pr.grad)) < 2e-2, n
+    with torch.no_grad():
+        assert not fuser(x).requires_grad                        # inference path unchanged
+    import types
+    from memory_augmented_vlm_amd.model.multimodal_projector import build_vision_projector
+    proj = build_vision_projector(types.SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=1152,
+                                                        hidden_size=256)).cuda().to(torch.bfloat16)
+    feats = (torch.randn(2, 729, 1152, device="cuda") * 0.5).bfloat16()
+    proj(feats).float().square().mean().backward()               # trainable projector: gradients exist
+    assert all(p.grad is not None and torch.isfinite(p.grad.float()).all() and p.grad.abs().sum() > 0 for p in proj.parameters())
+
+    c = Config()
+    c.mm_hidden_size, c.mm_intermediate_size, c.mm_num_attention_heads, c.mm_dtype = 256, 1024, 2, torch.float32
+    layer = TransformerLayer(c).cuda().to(torch.bfloat16)
+    q = (torch.randn(1, 300, 256, device="cuda") * 0.5).bfloat16().requires_grad_()
+    kv = (torch.randn(1, 400, 256, device="cuda") * 0.5).bfloat16()
+    out, stats = layer(q, kv)
+    assert out.requires_grad and stats is not None and stats.column_sums().shape == (400,)
+    out.float().square().mean().backward()
+    assert q.grad is not None and all(p.grad is not None and torch.isfinite(p.grad.float()).all() for p in layer.parameters())
+    with torch.no_grad():
+        out2, _ = layer(q, kv)
+    assert torch.equal(out2, out.detach())                       # same kernels, same bits
+
+
+def test_learnable_positional_encoding_is_differentiable():
+    """position_encoding.py:26-27 allows a learnable table (the reference uses the fixed one): with autograd on the
+    table receives its gradient; the fixed-table inference result is unchanged."""
+    from memory_augmented_vlm_amd.model.memory_module.position_encoding import TemporalPositionalEncoding
+    pe = TemporalPositionalEncoding(max_frames=50, embed_dim=128, learnable=True).cuda().to(torch.bfloat16)
+    x = (torch.randn(6, 196, 128, device="cuda") * 0.5).bfloat16()
+    idx = torch.tensor([0, 3, 3, 10, 49, 7])
+    y = pe(x, idx)
+    assert y.requires_grad
+    y.float().sum().backward()
+    g = pe.frame_embed.weight.grad.float()
+    want = torch.zeros(50, device="cuda")
+    want.index_add_(0, idx.cuda(), torch.full((6,), 196.0, device="cuda"))
+    assert torch.allclose(g.sum(dim=1) / 128, want)
+    with torch.no_grad():
+        assert torch.equal(pe(x, idx), y.detach())
