@@ -356,9 +356,13 @@ class TransformerProjector(nn.Module):
             e.version = v
         return e
 
-    def _apply(self, fn, *a, **k):   # .to() / .cuda() / .half(): parameters move, packed pointers would dangle
+    def _apply(self, fn, *a, **k):   # .to() / .cuda() / .half(): parameters may move, packed pointers would dangle
+        before = [(p.data_ptr(), p.dtype, p.device) for p in self.parameters()]
         out = super()._apply(fn, *a, **k)
-        if getattr(self, "_engine", None) is not None:
+        after = [(p.data_ptr(), p.dtype, p.device) for p in self.parameters()]
+        # the reference calls `.to(self.device)` on this module on EVERY forward (llava_arch.py:530): a no-op move must
+        # not throw the engine (packed weights, rings, workspace) away
+        if before != after and getattr(self, "_engine", None) is not None:
             self._engine = None           # also ends a video in progress: its FIFO lived in the old engine
             self._memory_cache = []
             self._evo_kv = []

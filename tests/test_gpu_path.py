@@ -619,3 +619,19 @@ def test_long_video_1024_frames():
     assert torch.isfinite(eager.float()).all()
     g = arch.GraphedVideoMemory(model, T, idx)
     assert torch.equal(g(x, mp, fp, model.image_newline), eager)
+
+
+def test_noop_module_move_keeps_the_engine():
+    """The reference calls `recurrent_memory_transformer.to(self.device)` on every forward (llava_arch.py:530): a move
+    that changes nothing keeps the engine (no re-packing, no re-allocation); a real one (dtype) drops it."""
+    cfg = O.PathConfig(hidden=256, heads=2, mem_tokens=2, depth=2)
+    proj = make_projector(cfg, O.make_weights(cfg, seed=77), "bf16")
+    seg = to_dev(O.bf16_round(O.hash_normal_like((2, 196, 256), 7700)))
+    proj.memory_cache = []
+    a = proj(seg)[0][-1].clone()
+    eng = proj._engine
+    assert proj.to("cuda") is proj and proj._engine is eng and len(proj.memory_cache) == 1
+    proj.memory_cache = []
+    assert torch.equal(proj(seg)[0][-1], a) and proj._engine is eng
+    proj.to(torch.float16)
+    assert proj._engine is None and proj.memory_cache == []
