@@ -16,6 +16,7 @@ Out of scope here (stay with the backbone / next rows of SURVEY.md §8f): buildi
 the image (non-video) merge modes, anyres unpadding.  Those branches raise NotImplementedError.
 """
 import math
+import random
 from typing import List, Optional
 
 import torch
@@ -155,7 +156,11 @@ def video_memory_tokens(model, image: torch.Tensor, frame_idx_cpu: torch.Tensor,
     rm.memory_cache = []                                                                  # :532
     for i in range(len(bounds) - 1):                                                      # :534-537
         rm(x[bounds[i]:bounds[i + 1]])
-    if rm._cache_mode == "autograd":
+    if rm._cache_mode == "autograd" or _tail_wants_grad(model, memory_prompt_embeds, frame_prompt_embeds, image_newline):
+        # training.  With `recurrent_memory_transformer` frozen but a trainable fuser / token-type embedding / newline /
+        # prompt embedding (mm_tunable_parts="larimar_model", train.py:1708-1713) the chunks above ran on the engine
+        # (nothing to differentiate there) and only the tail below records a graph - on CLONES of the ring views, which
+        # the next video would overwrite before backward.
         return _video_memory_tokens_autograd(model, rm, x, fine_cpu, memory_prompt_embeds, frame_prompt_embeds,
                                              image_newline, with_frames, out)
     eng = rm.engine(image.device, image.dtype)
@@ -183,6 +188,22 @@ def video_memory_tokens(model, image: torch.Tensor, frame_idx_cpu: torch.Tensor,
     return out, info
 
 
+def _tail_wants_grad(model, *tensors) -> bool:
+    """Can anything AFTER the recurrent steps receive a gradient?  (`memory_fuser`, `token_type_embedding`, and the
+    tensors the caller hands in: prompt embeddings of a trainable `embed_tokens`, `image_newline`.)"""
+    if not torch.is_grad_enabled():
+        return False
+    mods = (getattr(model, "memory_fuser", None), getattr(model, "token_type_embedding", None))
+    return any(p.requires_grad for m in mods if m is not None for p in m.parameters()) or \
+        any(t is not None and t.requires_grad for t in tensors)
+
+
+def path_wants_grad(model, *tensors) -> bool:
+    """Any gradient consumer on the memory path: the recurrent transformer or the tail (see _tail_wants_grad)."""
+    return torch.is_grad_enabled() and (any(p.requires_grad for p in model.recurrent_memory_transformer.parameters())
+                                        or _tail_wants_grad(model, *tensors))
+
+
 def _video_memory_tokens_autograd(model, rm, x, fine_cpu, memory_prompt_embeds, frame_prompt_embeds, image_newline,
                                   with_frames, out):
     """Training-mode tail of video_memory_tokens (llava_arch.py:545-554,620-629): the fuser MLP runs as HIP autograd
@@ -192,6 +213,7 @@ def _video_memory_tokens_autograd(model, rm, x, fine_cpu, memory_prompt_embeds, 
     P, D = x.shape[1], x.shape[2]
     dt = x.dtype
     temb = model.token_type_embedding.weight
+    # engine-mode cache entries are ring views: torch.cat copies them (the graph must not alias the ring)
     mem = torch.cat(rm.memory_cache, dim=0)                                               # :545
     fused = ag.fuser_mlp(model.memory_fuser, mem, temb[0]).reshape(-1, D)                  # :546-553
     nl = image_newline.to(device=x.device, dtype=dt).reshape(1, D)
@@ -370,11 +392,10 @@ class LlavaMetaForCausalLM:
         frame_prompt = model.embed_tokens(torch.tensor([FRAME_PROMPT_IDS], device=dev)).squeeze(0)  # :714-715
         training = bool(getattr(self, "training", False))
         dropout_frames = getattr(self.config, "dropout_frames", False)
-        if training and dropout_frames:
-            drop = self.get_synced_dropout_decision(prob=0.5)                                    # :719
-        else:
-            torch.rand(1)   # keep the reference's per-forward RNG draw; the broadcast cannot change the result here
-            drop = False
+        # :719 - called on EVERY forward, inference included, exactly as the reference: without a process group one local
+        # draw; with one, rank 0 draws and every rank joins the 1-element broadcast (ranks of the reference and of this
+        # build can therefore be mixed in one job, and the RNG streams of the non-zero ranks stay the reference's)
+        drop = self.get_synced_dropout_decision(prob=0.5) and training and bool(dropout_frames)   # :720
         # Step after the path.  Fast path = what the reference's memory branch supports anyway
         # (batch 1, one image placeholder, llava_arch.py:436): the final [1, L, D] buffer is allocated once and the
         # HIP path writes the video block straight into it; everything else goes through the general splice.
@@ -390,7 +411,7 @@ class LlavaMetaForCausalLM:
                      attention_mask, past_key_values, labels):
         if input_ids.shape[0] != 1:
             return None
-        if torch.is_grad_enabled() and any(p.requires_grad for p in model.recurrent_memory_transformer.parameters()):
+        if path_wants_grad(model, mem_prompt, frame_prompt, getattr(model, "image_newline", None)):
             return None                                    # training: tokens must stay in the autograd graph
         mask = torch.ones_like(input_ids, dtype=torch.bool) if attention_mask is None else attention_mask.bool()
         ids = input_ids[0][mask[0]]
@@ -423,7 +444,24 @@ class LlavaMetaForCausalLM:
                                                                   dtype=attention_mask.dtype)
         out_pos = None if position_ids is None else torch.arange(total, device=position_ids.device,
                                                                  dtype=position_ids.dtype)[None]
+        out_pos = _pos_skipping(self, out_pos, emb)
         return None, out_pos, out_mask, past_key_values, emb, out_labels
+
+
+def _pos_skipping(lm, position_ids, emb):
+    """`use_pos_skipping` (llava_arch.py:869-875, training only): position ids 0..L-1 with a random offset in front of
+    and behind a random split point (long-context extension trick of the reference's trainer).  Same three draws from
+    Python's `random`, in the same order."""
+    if not (getattr(lm.config, "use_pos_skipping", False) and getattr(lm, "training", False)):
+        return position_ids
+    L = emb.size(1)
+    position_ids = torch.arange(L, device=emb.device).unsqueeze(0)
+    split_position = random.randint(0, L)
+    left_add = random.randint(0, lm.config.pos_skipping_range)
+    right_add = random.randint(left_add, lm.config.pos_skipping_range)
+    position_ids[:, :split_position] += left_add
+    position_ids[:, split_position:] += right_add
+    return position_ids
 
 
 def splice_into_text(lm, model, image_features: List[torch.Tensor], input_ids, position_ids, attention_mask,
@@ -488,5 +526,5 @@ def splice_into_text(lm, model, image_features: List[torch.Tensor], input_ids, p
         pos[i, sl] = torch.arange(0, n, dtype=pos.dtype, device=pos.device)
     out_labels = None if _labels is None else lab_pad
     out_mask = None if _attention_mask is None else mask.to(dtype=_attention_mask.dtype)
-    out_pos = None if _position_ids is None else pos
+    out_pos = _pos_skipping(lm, None if _position_ids is None else pos, emb)
     return None, out_pos, out_mask, past_key_values, emb, out_labels

@@ -19,7 +19,8 @@ Deliberate deviations from the reference (documented in DESIGN.md):
     `num_memory_tokens % 8 == 0` / `heads == 8` requirement (reshape(8,-1,8), :109) does not apply.
   * tensors in the returned `memory_cache` are views into a ring buffer owned by the module: an entry is
     overwritten once it has been evicted from the FIFO (the reference drops the evicted tensor, :153-154).
-  * forward only (inference).  Calling it in training mode with autograd enabled raises.
+  * with autograd recording and trainable parameters the same kernels run as autograd Functions (_autograd.py,
+    DESIGN.md §9); the forward activations are bit-identical to the inference path.
 """
 import math
 from typing import List
@@ -305,6 +306,14 @@ class TransformerProjector(nn.Module):
         self._train_steps = 0                 # training path: memories produced since the last reset
         self._engine = None
         self._fuser_refs = None               # (memory_fuser, token_type_embedding) bound by the glue
+        # Staleness of the engine's packed weight COPIES (fp32 biases / LayerNorm affines, mem0, concatenated and
+        # head-padded matrices).  In-place updates through autograd-visible ops bump `p._version` and are seen by
+        # _param_version(); updates through `.data` (DeepSpeed ZeRO-1/2 copy their bf16 partitions back with
+        # `p.data.copy_()`) change neither the version nor the pointer.  Such updates only happen in training jobs, so:
+        # every video that starts while the module is in training mode, or after it has been in training / autograd mode
+        # since the last pack, re-packs.  One dict shared with the replicas of spawn_replica().
+        self._train_state = {"epoch": 0, "training": self.training}
+        self._packed_epoch = -1
 
     # -- the reference's reset protocol: `module.memory_cache = []` ----------------------------------------
     @property
@@ -322,6 +331,21 @@ class TransformerProjector(nn.Module):
         self._cache_mode = "engine"
         if self._engine is not None:
             capi.check(capi.lib().mavlm_reset(self._engine.ctx), "mavlm_reset")
+            if self._weights_maybe_stale():
+                self._engine.version = None          # re-pack on the first step of this video
+
+    def train(self, mode: bool = True):
+        st = self.__dict__.get("_train_state")
+        if st is not None:
+            st["training"] = bool(mode)
+            if mode:
+                st["epoch"] += 1
+        return super().train(mode)
+
+    def _weights_maybe_stale(self) -> bool:
+        st = self._train_state
+        fuser_training = any(m.training for m in (self._fuser_refs or ()))
+        return st["training"] or fuser_training or st["epoch"] != self._packed_epoch
 
     # -- engine management -------------------------------------------------------------------------------
     def bind_fuser(self, memory_fuser, token_type_embedding):
@@ -354,6 +378,7 @@ class TransformerProjector(nn.Module):
             fuser, temb = self._fuser_refs if self._fuser_refs is not None else (None, None)
             e.pack(self, fuser, temb)
             e.version = v
+            self._packed_epoch = self._train_state["epoch"]
         return e
 
     def _apply(self, fn, *a, **k):   # .to() / .cuda() / .half(): parameters may move, packed pointers would dangle
@@ -420,6 +445,7 @@ class TransformerProjector(nn.Module):
             raise capi.MavlmError("memory_cache holds ring views of an inference-mode video: reset it "
                                   "(`memory_cache = []`) before running the training path")
         self._cache_mode = "autograd"
+        self._train_state["epoch"] += 1          # an optimizer step may follow: packed copies are suspect afterwards
         F, P, D = image_features.shape
         R = self.num_memory_tokens * P
         dt = image_features.dtype

@@ -1,1 +1,1 @@
-from .builder import build_vision_projector, IdentityMap, MlpGeluProjector  # noqa: F401
+from .builder import build_vision_projector, IdentityMap, LinearProjector, MlpGeluProjector  # noqa: F401

@@ -1,8 +1,8 @@
 """Step before the path: the vision projector that feeds `get_2dPool`.
 
 Mirrors `llava/model/multimodal_projector/builder.py:32-65` for the projector types the memory path is trained with
-(`mlp{N}x_gelu`, `linear`, `identity`).  State-dict keys are those of the reference's `nn.Sequential`
-(`0.weight, 0.bias, 2.weight, ...`), so a LLaVA-OneVision `mm_projector.*` checkpoint loads unchanged; forward runs on
+(`mlp{N}x_gelu`, `linear`, `identity`).  State-dict keys are those of the reference's modules (`nn.Sequential`:
+`0.weight, 0.bias, 2.weight, ...`; `linear`: a bare `nn.Linear`, `weight, bias`), so a LLaVA-OneVision `mm_projector.*` checkpoint loads unchanged; forward runs on
 the MFMA GEMMs of the HIP library with the exact-erf GELU fused into the producing epilogue.  `pooler` and the
 `res` variants are not used by the memory-path configurations and raise.
 """
@@ -52,10 +52,27 @@ class MlpGeluProjector(nn.Sequential):
         return y.reshape(*x.shape[:-1], y.shape[-1])
 
 
+class LinearProjector(nn.Linear):
+    """`mm_projector_type="linear"`: the reference returns a bare `nn.Linear` (builder.py:35-36), state-dict keys
+    `weight` / `bias` - kept, so such a checkpoint loads; forward = one HIP GEMM."""
+
+    def forward(self, x):
+        import torch
+        y = x.reshape(-1, x.shape[-1])
+        if not y.is_contiguous():
+            y = y.contiguous()
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from ... import _autograd as ag
+            y = ag.LinearFn.apply(y, self.weight.to(y.dtype), self.bias, ag.ACT_NONE)
+        else:
+            y = ops.linear(y, self.weight, self.bias.float(), capi.EPI_BIAS)
+        return y.reshape(*x.shape[:-1], y.shape[-1])
+
+
 def build_vision_projector(config, delay_load=False, **kwargs):
     kind = getattr(config, "mm_projector_type", "linear")
     if kind == "linear":
-        return MlpGeluProjector(config.mm_hidden_size, config.hidden_size, 1)
+        return LinearProjector(config.mm_hidden_size, config.hidden_size)
     m = re.match(r"^mlp(\d+)x_gelu$", kind)
     if m:
         return MlpGeluProjector(config.mm_hidden_size, config.hidden_size, int(m.group(1)))

@@ -365,9 +365,33 @@ def split_plan_wide(R: int, S: int, heads: int) -> Tuple[int, int]:
     return ns, (tps if ns > 1 else 0)
 
 
+ROW_BLOCK_ELEMS = 1 << 28   # score elements per (head, query block) above which the queries are processed in blocks
+
+
 def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mode: str = "fp32",
                     want_colsum: bool = False, want_probs: bool = False, kv_tile: Optional[int] = None,
                     wave_rows: Optional[int] = None):
+    """Query-blocked driver of ``_attention_heads``: attention rows are independent (the wave-uniform rescale decision
+    couples groups of ``wave_rows`` = 32 / 16 consecutive queries only, and the key-split plan depends on the TOTAL
+    row count, which is passed down), so large problems (BASELINE configs[4]: 25 088 queries x 250 880 keys) run in
+    blocks of 3136 queries instead of materialising a [R, Lk] score matrix per head; column sums add up over blocks."""
+    R, Lk = Q.shape[0], K.shape[0]
+    blk = 3136                                     # multiple of 32 and of 16
+    if want_probs or R * Lk <= ROW_BLOCK_ELEMS or R <= blk:
+        return _attention_heads(Q, K, V, heads, mode, want_colsum, want_probs, kv_tile, wave_rows, R)
+    ctxs, lses, cs = [], [], None
+    for r0 in range(0, R, blk):
+        c_, l_, s_, _ = _attention_heads(Q[r0:r0 + blk], K, V, heads, mode, want_colsum, False, kv_tile, wave_rows, R)
+        ctxs.append(c_)
+        lses.append(l_)
+        if want_colsum:
+            cs = s_.astype(np.float64) if cs is None else cs + s_
+    return (np.concatenate(ctxs, axis=0), np.concatenate(lses, axis=1), (cs.astype(F32) if want_colsum else None), None)
+
+
+def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mode: str = "fp32",
+                     want_colsum: bool = False, want_probs: bool = False, kv_tile: Optional[int] = None,
+                     wave_rows: Optional[int] = None, plan_rows: Optional[int] = None):
     """softmax(Q K^T / sqrt(d)) V per head (MemoryController.py:51-54).  Returns
     (ctx [R,H*d] unrounded float32, lse2 [H,R] log2-domain log-sum-exp, colsum [H,Lk] | None, probs | None).
 
@@ -417,9 +441,9 @@ def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mod
                 return acc, m, l
 
             if kv_tile == KV_TILE:            # attention3.hip (head_dim <= 128)
-                ns, tps = split_plan(R, Lk, heads)
+                ns, tps = split_plan(plan_rows or R, Lk, heads)
             elif kv_tile == 32:               # attention_hd.hip
-                ns, tps = split_plan_wide(R, Lk, heads)
+                ns, tps = split_plan_wide(plan_rows or R, Lk, heads)
             else:
                 ns, tps = 1, 0
             if ns == 1:

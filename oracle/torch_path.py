@@ -29,13 +29,11 @@ def params_from(w: Dict[str, np.ndarray], dtype=torch.float64) -> Dict[str, torc
 
 
 def _lin(x, p, name):
-    return x @ p[f"{name}.weight"].T + p[f"{name}.bias"]
+    return torch.nn.functional.linear(x, p[f"{name}.weight"], p[f"{name}.bias"])          # what nn.Linear calls
 
 
 def _ln(x, p, name, eps):
-    mu = x.mean(dim=-1, keepdim=True)
-    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
-    return (x - mu) / torch.sqrt(var + eps) * p[f"{name}.weight"] + p[f"{name}.bias"]
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), p[f"{name}.weight"], p[f"{name}.bias"], eps)   # nn.LayerNorm
 
 
 def mha(xq, xkv, p, prefix, heads, eps):
@@ -83,6 +81,22 @@ def fuse(p, cache: List[torch.Tensor]) -> torch.Tensor:
     u = torch.nn.functional.gelu(_lin(mem, p, "memory_fuser.0"))
     y = _lin(u, p, "memory_fuser.2") + p["token_type_embedding.weight"][0]
     return y.reshape(-1, y.shape[-1])
+
+
+def cpu_reference_step_timer(cfg, w: Dict[str, np.ndarray], segs: List[np.ndarray], dtype=torch.float32):
+    """bench.py's `cpu_baseline` leg: the same ATen call sequence the reference executes on CPU (F.linear, matmul, the
+    score division, softmax, F.layer_norm - MemoryController.py:47-57,69-72,118-158), without autograd, in `dtype`
+    (float32, or bfloat16 as the reference runs under `torch_dtype=bfloat16`).  Returns a zero-argument callable that
+    runs the recurrent steps once and returns the newest memory."""
+    with torch.no_grad():
+        p = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype) for k, v in w.items()
+             if k.startswith(PFX) and v.dtype.kind == "f"}
+    xs = [np.ascontiguousarray(s_, dtype=np.float32) for s_ in segs]
+
+    def run():
+        with torch.no_grad():
+            return run_steps(p, cfg, xs)[-1]
+    return run
 
 
 def grads(p: Dict[str, torch.Tensor], loss: torch.Tensor) -> Dict[str, np.ndarray]:

@@ -283,3 +283,62 @@ def test_learnable_positional_encoding_is_differentiable():
     assert torch.allclose(g.sum(dim=1) / 128, want)
     with torch.no_grad():
         assert torch.equal(pe(x, idx), y.detach())
+
+
+def test_frozen_recurrent_model_trainable_fuser_gets_gradients():
+    """mm_tunable_parts="larimar_model" (train.py:1708-1713): `memory_fuser` + `token_type_embedding` train while the
+    recurrent transformer is frozen.  The chunks run on the inference engine, the tail records a graph: every trainable
+    tensor of the tail gets a gradient (nothing silently constant) that matches the torch oracle, and the frozen
+    parameters get none.  The tail's inputs are CLONES of the FIFO ring: running another video before backward must not
+    change the gradients."""
+    cfg = O.PathConfig(hidden=256, heads=8, mem_tokens=2, depth=2)
+    w = O.make_weights(cfg, seed=29)
+    model, _ = _tiny_host(cfg, w)
+    model.train()
+    for n_, p_ in model.named_parameters():
+        p_.requires_grad_(not n_.startswith("recurrent_memory_transformer"))
+    model.embed_tokens.weight.requires_grad_(False)
+    rows = sorted(set(O.MEM_PROMPT_IDS + O.FRAME_PROMPT_IDS))
+    emb = np.zeros((48900, 256), np.float32)
+    emb[rows] = O.bf16_round(O.hash_normal_like((len(rows), 256), 91, 0.02))
+    with torch.no_grad():
+        model.embed_tokens.weight.copy_(to_dev(emb))
+        model.image_newline.copy_(to_dev(w["image_newline"]))
+    T = 36
+    x = O.bf16_round(O.hash_normal_like((T, 196, 256), 93))
+    idx = O.subsample_indices(40)[:T]
+    mp = model.embed_tokens(torch.tensor(O.MEM_PROMPT_IDS, device="cuda"))
+    fp = model.embed_tokens(torch.tensor(O.FRAME_PROMPT_IDS, device="cuda"))
+    rm = model.recurrent_memory_transformer
+    toks, info = arch.video_memory_tokens(model, to_dev(x), torch.from_numpy(idx), mp, fp, model.image_newline)
+    assert rm._cache_mode == "engine"                       # the chunks took the inference engine
+    assert toks.requires_grad
+    cot = O.bf16_round(O.hash_normal_like(tuple(toks.shape), 94, 0.05))
+    loss = (toks.float() * torch.from_numpy(cot).cuda()).sum()
+    # another video overwrites the FIFO ring before backward runs
+    with torch.no_grad():
+        other = O.bf16_round(O.hash_normal_like((T, 196, 256), 95))
+        arch.video_memory_tokens(model, to_dev(other), torch.from_numpy(idx), mp.detach(), fp.detach(),
+                                 model.image_newline.detach())
+    loss.backward()
+    named = dict(model.named_parameters())
+    assert all(p_.grad is None for n_, p_ in named.items() if n_.startswith("recurrent_memory_transformer"))
+
+    p = TP.params_from(w)
+    xpe = O.pe_add(x, idx, w["positional_encoding.frame_embed"], "bf16")
+    bounds = O.uniform_segment_variant(T, 32)
+    with torch.no_grad():
+        cache = [c.detach() for c in TP.run_steps(p, cfg, [xpe[bounds[i]:bounds[i + 1]] for i in range(len(bounds) - 1)])]
+    fused = TP.fuse(p, cache)
+    fine = torch.from_numpy(xpe[O.fine_frame_indices(T)]).double() + p["token_type_embedding.weight"][1]
+    nl = p["image_newline"].reshape(1, -1)
+    e = torch.from_numpy(emb).double()
+    t_toks = torch.cat([e[list(O.MEM_PROMPT_IDS)], fused, nl, e[list(O.FRAME_PROMPT_IDS)], fine.reshape(-1, 256), nl])
+    t_loss = (t_toks * torch.from_numpy(cot).double()).sum()
+    ref = TP.grads(p, t_loss)
+    assert abs(float(loss.detach()) - float(t_loss.detach())) <= 2e-2 * abs(float(t_loss.detach())) + 1e-2
+    for name, tol in (("memory_fuser.0.weight", 6e-2), ("memory_fuser.0.bias", 6e-2), ("memory_fuser.2.weight", 6e-2),
+                      ("memory_fuser.2.bias", 6e-2), ("token_type_embedding.weight", 1e-2), ("image_newline", 1e-2)):
+        assert named[name].grad is not None, name
+        err = O.rel_l2(to_np(named[name].grad), ref[name])
+        assert err < tol, (name, err)

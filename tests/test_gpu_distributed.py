@@ -12,7 +12,10 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_dir):
+FRAMES = {1024: [3, 2, 3, 1, 2], 3584: [2, 1, 1, 2]}      # chunks per width; FIFO cap 3 -> the ring wraps in both
+
+
+def _worker(rank, world, port, out_dir, hidden=1024):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -25,12 +28,14 @@ def _worker(rank, world, port, out_dir):
     from test_gpu_path import make_projector
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=8, depth=2, cache_cap=3)
+    cfg = O.PathConfig(hidden=hidden, heads=8, mem_tokens=8, depth=2, cache_cap=3)
     w = O.make_weights(cfg, seed=71)
     proj = make_projector(cfg, w, "bf16", cache_cap=3)
     sharded = D.RowShardedMemory(proj)
-    frames = [3, 2, 3, 1, 2]
-    segs = [to_dev(O.bf16_round(O.hash_normal_like((f, 196, 1024), 7100 + t))) for t, f in enumerate(frames)]
+    frames = FRAMES[hidden]
+    segs = [to_dev(O.bf16_round(O.hash_normal_like((f, 196, hidden), 7100 + t))) for t, f in enumerate(frames)]
+    oracle_ref = os.path.join(out_dir, "oracle_mem.npy")
+    omem = np.load(oracle_ref) if os.path.exists(oracle_ref) else None
     with torch.no_grad():
         proj.memory_cache = []
         ref = []
@@ -42,7 +47,11 @@ def _worker(rank, world, port, out_dir):
             assert len(cache) == ref[t][2]
             err = float((cache[-1].float() - ref[t][0].float()).norm() / ref[t][0].float().norm())
             serr = float((scores.float() - ref[t][1].float()).norm() / ref[t][1].float().norm())
-            np.save(os.path.join(out_dir, f"err_{rank}_{t}.npy"), np.array([err, serr]))
+            oerr = -1.0
+            if omem is not None:          # newest memory of step t against the CPU oracle (computed once, by the parent)
+                o = torch.from_numpy(omem[t]).to(cache[-1].device)
+                oerr = float((cache[-1].float().reshape(-1) - o.reshape(-1)).norm() / o.norm())
+            np.save(os.path.join(out_dir, f"err_{rank}_{t}.npy"), np.array([err, serr, oerr]))
         # every rank holds the same full FIFO
         mine = torch.stack(list(cache)).float().cpu()
         gathered = [torch.empty_like(mine) for _ in range(world)]
@@ -52,13 +61,39 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_row_sharded_video_matches_single_gpu(world, tmp_path):
-    """5 chunks, FIFO cap 3 (wraps): the sharded recurrence tracks the single-GPU engine within the 16-bit chain
-    noise (different kernel plans at 1/W of the rows -> different fp32 summation order; no systematic drift)."""
-    port = 29600 + world
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+_ORACLE = {}
+
+
+def _oracle_chain(hidden, out_dir):
+    """The same chunks through the CPU oracle (emulation mode), once per width, in the parent: newest memory per step and
+    the calibrated chain tolerance (oracle with float64 accumulation against itself, test_gpu_path.chain_tol)."""
+    if hidden not in _ORACLE:
+        from oracle import memory_path as O
+        from test_gpu_path import chain_tol, run_oracle_steps
+        cfg = O.PathConfig(hidden=hidden, heads=8, mem_tokens=8, depth=2, cache_cap=3)
+        w = O.make_weights(cfg, seed=71)
+        segs = [O.bf16_round(O.hash_normal_like((f, 196, hidden), 7100 + t)) for t, f in enumerate(FRAMES[hidden])]
+        ref = run_oracle_steps(cfg, w, "bf16", segs, np.float32)
+        alt = run_oracle_steps(cfg, w, "bf16", segs, np.float64)
+        _ORACLE[hidden] = (np.stack([r[0][-1] for r in ref]),
+                           [chain_tol(O.rel_l2(a[0][-1], r[0][-1])) for a, r in zip(alt, ref)])
+    np.save(os.path.join(out_dir, "oracle_mem.npy"), _ORACLE[hidden][0])
+    return _ORACLE[hidden][1]
+
+
+@pytest.mark.parametrize("world,hidden,with_oracle", [(2, 1024, True), (4, 1024, True), (2, 3584, False)])
+def test_row_sharded_video_matches_single_gpu(world, hidden, with_oracle, tmp_path):
+    """FIFO cap 3 over 4-5 chunks (wraps): the sharded recurrence tracks the single-GPU engine within the 16-bit chain
+    noise (different kernel plans at 1/W of the rows -> different fp32 summation order; no systematic drift), and
+    - independent of the engine - the CPU oracle within the calibrated chain tolerance (D = 1024).  hidden = 3584 is the
+    LLaVA-OneVision-7B width of BASELINE.json configs[3] (wide-head kernels; the single-GPU engine it is compared
+    with is itself checked against the oracle at this width in test_gpu_configs_fullsize.py)."""
+    tols = _oracle_chain(hidden, str(tmp_path)) if with_oracle else None
+    port = 29600 + world + (hidden // 1024)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), hidden), nprocs=world, join=True)
     for rank in range(world):
-        for t in range(5):
-            err, serr = np.load(tmp_path / f"err_{rank}_{t}.npy")
+        for t in range(len(FRAMES[hidden])):
+            err, serr, oerr = np.load(tmp_path / f"err_{rank}_{t}.npy")
             assert err < 6e-3 and serr < 5e-3, (rank, t, err, serr)
+            if with_oracle:
+                assert 0 <= oerr < tols[t], (rank, t, oerr, tols[t])

@@ -635,3 +635,38 @@ def test_noop_module_move_keeps_the_engine():
     assert torch.equal(proj(seg)[0][-1], a) and proj._engine is eng
     proj.to(torch.float16)
     assert proj._engine is None and proj.memory_cache == []
+
+
+def test_data_copy_parameter_update_is_seen_by_the_engine():
+    """DeepSpeed ZeRO-1/2 write updated bf16 partitions back with `p.data.copy_()`, which changes neither `p._version`
+    nor the pointer.  The engine holds COPIES of some parameters (fp32 biases / LayerNorm affines, mem0, the packed K/V
+    matrices), so a video that starts after the module has been in training mode re-packs: the inference path then
+    follows the new weights (checked against the oracle with the new weights)."""
+    cfg = O.PathConfig(hidden=256, heads=2, mem_tokens=2, depth=2)
+    w0 = O.make_weights(cfg, seed=31)
+    w1 = O.make_weights(cfg, seed=32)
+    proj = make_projector(cfg, w0, "bf16")
+    segs = [O.bf16_round(O.hash_normal_like((f, 196, 256), 3100 + t)) for t, f in enumerate((2, 1))]
+    proj.memory_cache = []
+    for s_ in segs:
+        old = proj(to_dev(s_))[0][-1].clone()
+    proj.train()                                           # a training phase ...
+    pfx = "recurrent_memory_transformer."
+    with torch.no_grad():
+        for k, p_ in proj.named_parameters():
+            v0 = p_._version
+            p_.data.copy_(torch.from_numpy(w1[pfx + k]).to(p_.dtype))      # ... updates every parameter through .data
+            assert p_._version == v0
+    proj.eval()
+    proj.memory_cache = []
+    for s_ in segs:
+        new = proj(to_dev(s_))[0][-1]
+    ref = run_oracle_steps(cfg, w1, "bf16", segs, np.float32)[-1][0][-1]
+    alt = run_oracle_steps(cfg, w1, "bf16", segs, np.float64)[-1][0][-1]
+    assert O.rel_l2(to_np(new), ref) < chain_tol(O.rel_l2(alt, ref))
+    assert O.rel_l2(to_np(old), ref) > 0.1                 # the old weights give something else entirely
+    eng = proj._engine
+    proj.memory_cache = []                                 # eval mode, nothing happened since the pack: no re-pack
+    ver = eng.version
+    proj(to_dev(segs[0]))
+    assert eng.version is ver or eng.version == ver

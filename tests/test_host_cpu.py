@@ -195,3 +195,18 @@ def test_adjusted_segment_host_logic_matches_reference():
     import inspect
     for name in ("segment", "adjusted_segment", "uniform_segment", "uniform_segment_variant", "sample_scenes_priority"):
         assert callable(getattr(S, name))                 # the five names llava_arch.py:34 imports
+
+
+def test_vision_projector_state_dict_keys_per_type():
+    """`build_vision_projector` keeps the reference's state-dict keys for every projector type it builds
+    (multimodal_projector/builder.py:35-48): a bare nn.Linear for "linear", an nn.Sequential for "mlpNx_gelu"."""
+    import types
+    from memory_augmented_vlm_amd.model.multimodal_projector import build_vision_projector
+    cfg = types.SimpleNamespace(mm_hidden_size=64, hidden_size=128, mm_projector_type="linear")
+    lin = build_vision_projector(cfg)
+    assert isinstance(lin, torch.nn.Linear) and sorted(lin.state_dict()) == ["bias", "weight"]
+    assert tuple(lin.weight.shape) == (128, 64)
+    cfg.mm_projector_type = "mlp2x_gelu"
+    assert sorted(build_vision_projector(cfg).state_dict()) == ["0.bias", "0.weight", "2.bias", "2.weight"]
+    cfg.mm_projector_type = "identity"
+    assert not build_vision_projector(cfg).state_dict()

@@ -172,3 +172,19 @@ def test_g9_scene_similarity_oracle_matches_reference():
         feats = V.scene_features(Tn, meta["seg_P"], meta["seg_D"], slen, meta["seg_seed"])
         sims = V.adjacent_cosine(V.frame_means(feats))
         np.testing.assert_allclose(sims, z[tag + "_sims"], atol=2e-6)
+
+
+def test_query_blocked_attention_equals_unblocked(monkeypatch):
+    """The oracle processes very large attentions (BASELINE configs[4]) in blocks of 3136 queries: same values as the
+    one-shot evaluation, in both arithmetic modes, column sums included."""
+    from oracle import memory_path as O
+    R, Lk, H, d = 3136 * 2 + 40, 192, 2, 64
+    Q = O.bf16_round(O.hash_normal_like((R, H * d), 1))
+    K = O.bf16_round(O.hash_normal_like((Lk, H * d), 2))
+    V = O.bf16_round(O.hash_normal_like((Lk, H * d), 3))
+    for mode in ("fp32", "bf16"):
+        ref = O._attention_heads(Q, K, V, H, mode, True, False, None, None, R)
+        monkeypatch.setattr(O, "ROW_BLOCK_ELEMS", 1)
+        got = O.attention_heads(Q, K, V, H, mode, want_colsum=True)
+        monkeypatch.undo()
+        assert O.rel_l2(got[0], ref[0]) < 1e-6 and O.rel_l2(got[1], ref[1]) < 1e-6 and O.rel_l2(got[2], ref[2]) < 1e-6
