@@ -248,6 +248,19 @@ def timed_blocks(step, sync, args, world, device):
     return times
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands each job a
+    share of its host: oversubscribing it with one thread per hardware thread makes the BLAS threads fight)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_model_string():
     try:
         for line in open("/proc/cpuinfo"):
@@ -263,8 +276,8 @@ def cpu_baseline():
     transformer (formation, depth 2, no evolution at step 0), 8 frames x 196 tokens x 1024, 64 memory tokens, H = 8.
     What is timed is the oracle's torch restatement (oracle/torch_path.py: the same ATen call sequence the reference
     executes, pinned against the imported reference in tests/) - the reference's own Python never travels to this box.
-    fp32 and bf16, all host cores and one thread, 2 warm-ups then the median of 5 (single-thread legs: 1 + 3 - a
-    bounded sample, stated in `sample`)."""
+    fp32 and bf16, all usable host cores and one thread, 2 warm-ups then the median of 5 (single-thread legs: fewer
+    runs - a bounded sample of ~20-30 s in total, stated per leg)."""
     import numpy as np
     import torch
     from oracle import memory_path as O
@@ -274,7 +287,7 @@ def cpu_baseline():
     w = O.make_weights(cfg, seed=77)
     seg = O.bf16_round(O.hash_normal_like((F, PATCHES, HIDDEN), 78))
     flop = DEPTH * (20.0 * cfg.mem_rows * HIDDEN ** 2 + 4.0 * F * PATCHES * HIDDEN ** 2 + 4.0 * cfg.mem_rows * F * PATCHES * HIDDEN)
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cpus()
     legs = {}
     t_start = time.perf_counter()
 
@@ -297,13 +310,15 @@ def cpu_baseline():
 
     leg("fp32_all_cores", torch.float32, cores, 2, 5)
     leg("bf16_all_cores", torch.bfloat16, cores, 2, 5)
-    leg("fp32_1_thread", torch.float32, 1, 1, 3)
-    leg("bf16_1_thread", torch.bfloat16, 1, 1, 3)
+    leg("fp32_1_thread", torch.float32, 1, 0, 1)          # ~7 s per run on a 5 GHz core: one cold run
+    leg("bf16_1_thread", torch.bfloat16, 1, 1, 2)
     torch.set_num_threads(cores)
     best = max(("fp32_all_cores", "bf16_all_cores"), key=lambda k: legs[k]["frames_per_s"])
     return {"value": legs[best]["frames_per_s"], "unit": "frames/s", "cores": cores, "kind": "port",
             "cpu_model": cpu_model_string(), "best_leg": best, "legs": legs,
-            "protocol": "BASELINE.md §3: 2 warm-ups + median of 5 (1 + 3 for the single-thread legs)",
+            "host_threads_visible": len(os.sched_getaffinity(0)),
+            "protocol": "BASELINE.md §3: 2 warm-ups + median of 5 on all usable cores (affinity capped by the cgroup CPU "
+                        "quota); single-thread legs bounded to 1 cold run (fp32) / 1 warm-up + 2 runs (bf16)",
             "sample": f"C1 = one recurrent step (formation, depth {DEPTH}): {F} frames x {PATCHES} tokens x {HIDDEN}, "
                       f"M={MEM_TOKENS}, H={HEADS}; {flop / 1e9:.1f} GFLOP per step; torch {torch.__version__} CPU ATen "
                       f"path of oracle/torch_path.py; whole baseline took {time.perf_counter() - t_start:.1f} s"}

@@ -239,6 +239,9 @@ int mavlm_set_attention_bwd_fused(int32_t on);
  * 0 = automatic choice by grid size and epilogue).  Results are identical
  * up to fp32 summation order. */
 int mavlm_set_gemm_tile(int32_t tile);
+/* tuning hook: height of the 256-column GEMM workgroup tile - 256, 224 (= 7 x 32: divides M_tokens x 196 rows when
+ * M_tokens % 8 == 0), or 0 = automatic (fewer row-rounds on 256 CUs).  Results are bit-identical. */
+int mavlm_set_gemm_rows(int32_t rows);
 /* tuning hook: attention forward kernel - 2 = register-staged (attention.hip), 3 = software-pipelined LDS-DMA
  * (attention3.hip), 0 = default (3).  Same rounding points; results equal up to fp32 summation order. */
 int mavlm_set_attention_impl(int32_t impl);

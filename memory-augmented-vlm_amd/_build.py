@@ -39,6 +39,31 @@ def _stale(out: str) -> bool:
         return True
 
 
+def _compile_one(hipcc, src, obj, verbose):
+    """One translation unit -> object file, skipped when the object was built from the same bytes (source, headers,
+    flags) - so editing one kernel file recompiles one file."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in [src] + [os.path.join(_HERE, "csrc", x) for x in HEADERS]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    stamp = obj + ".srchash"
+    try:
+        if os.path.exists(obj) and open(stamp).read().strip() == h.hexdigest():
+            return None
+    except OSError:
+        pass
+    cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", "-o", obj, src]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        return "hipcc failed on " + src + ":\n" + r.stdout + r.stderr
+    with open(stamp, "w") as fh:
+        fh.write(h.hexdigest())
+    return None
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     out = library_path()
     if not force and not _stale(out):
@@ -47,22 +72,36 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libmavlm.so (ROCm toolchain required)")
     os.makedirs(os.path.dirname(out), exist_ok=True)
+    objdir = os.path.join(os.path.dirname(out), "obj")
+    os.makedirs(objdir, exist_ok=True)
     # several ranks of one job may import the package at once: one builds, the others wait and then find it fresh
     import fcntl
+    from concurrent.futures import ThreadPoolExecutor
     with open(os.path.join(os.path.dirname(out), ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if not force and not _stale(out):
                 return out
+            srcs = [os.path.join(_HERE, "csrc", s) for s in SOURCES]
+            objs = [os.path.join(objdir, os.path.splitext(s)[0] + ".o") for s in SOURCES]
+            if force:
+                for o in objs:
+                    if os.path.exists(o + ".srchash"):
+                        os.remove(o + ".srchash")
+            workers = max(1, min(6, (os.cpu_count() or 2) - 1))
+            with ThreadPoolExecutor(workers) as ex:
+                errs = [e for e in ex.map(lambda so: _compile_one(hipcc, so[0], so[1], verbose), zip(srcs, objs)) if e]
+            if errs:
+                raise RuntimeError("\n".join(errs))
             tmp = f"{out}.tmp.{os.getpid()}"
-            cmd = [hipcc] + FLAGS + ["-o", tmp] + [os.path.join(_HERE, "csrc", s) for s in SOURCES]
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
             if verbose:
-                print(" ".join(cmd))
+                print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 if os.path.exists(tmp):
                     os.remove(tmp)
-                raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+                raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
             os.replace(tmp, out)
             with open(out + ".srchash", "w") as fh:
                 fh.write(_src_hash())

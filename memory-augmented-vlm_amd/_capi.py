@@ -88,6 +88,7 @@ SIGNATURES = {
     "mavlm_gru_sequence": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mavlm_set_attention_bwd_fused": (C.c_int, [i32]),
     "mavlm_set_gemm_tile": (C.c_int, [i32]),
+    "mavlm_set_gemm_rows": (C.c_int, [i32]),
     "mavlm_set_attention_impl": (C.c_int, [i32]),
     "mavlm_prof_enable": (C.c_int, [i32]),
     "mavlm_prof_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),

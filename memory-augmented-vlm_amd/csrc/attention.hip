@@ -416,13 +416,13 @@ hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream
 }
 
 static hipError_t launch_attention2(const mavlm_attn_args& a, int dtype, hipStream_t s, float c, dim3 grid) {
-  static bool done[2] = {false, false};
+  static mavlm_per_device_once once[2];
   if (dtype == MAVLM_F16) {
-    if (!done[1]) { hipError_t e = set_lds(attn_fwd_kernel<F16>, ATTN_LDS); if (e != hipSuccess) return e; done[1] = true; }
+    { hipError_t e = once[1].dyn_lds((const void*)attn_fwd_kernel<F16>, ATTN_LDS); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(attn_fwd_kernel<F16>, grid, dim3(256), ATTN_LDS, s, (const uint16_t*)a.Q, a.ldq,
                        (const uint16_t*)a.K, a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c);
   } else {
-    if (!done[0]) { hipError_t e = set_lds(attn_fwd_kernel<BF16>, ATTN_LDS); if (e != hipSuccess) return e; done[0] = true; }
+    { hipError_t e = once[0].dyn_lds((const void*)attn_fwd_kernel<BF16>, ATTN_LDS); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(attn_fwd_kernel<BF16>, grid, dim3(256), ATTN_LDS, s, (const uint16_t*)a.Q, a.ldq,
                        (const uint16_t*)a.K, a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c);
   }

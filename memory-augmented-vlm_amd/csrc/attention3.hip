@@ -422,12 +422,11 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
   float* opart = a.split_ws;
   float* lpart = ns > 1 ? a.split_ws + (size_t)ns * a.R * a.H * HD3 : nullptr;
   dim3 grid(((a.R + 127) / 128) * a.H, ns);
-  static bool done[2] = {false, false};
+  static mavlm_per_device_once once[2];
   if (dtype == MAVLM_F16) {
-    if (!done[1]) {
-      hipError_t e = hipFuncSetAttribute((const void*)attn_fwd3_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN3_LDS);
+    {
+      hipError_t e = once[1].dyn_lds((const void*)attn_fwd3_kernel<F16>, ATTN3_LDS);
       if (e != hipSuccess) return e;
-      done[1] = true;
     }
     hipLaunchKernelGGL(attn_fwd3_kernel<F16>, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
                        a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps);
@@ -435,10 +434,9 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
       hipLaunchKernelGGL(attn_combine_kernel<F16>, dim3((a.R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
                          a.lse2, a.R, a.H, HD3, ns);
   } else {
-    if (!done[0]) {
-      hipError_t e = hipFuncSetAttribute((const void*)attn_fwd3_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN3_LDS);
+    {
+      hipError_t e = once[0].dyn_lds((const void*)attn_fwd3_kernel<BF16>, ATTN3_LDS);
       if (e != hipSuccess) return e;
-      done[0] = true;
     }
     hipLaunchKernelGGL(attn_fwd3_kernel<BF16>, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
                        a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps);

@@ -270,13 +270,13 @@ void launch_mode(dim3 grid, hipStream_t s, const void* X, int ldx, const void* X
 template <typename T>
 hipError_t launch_all(const mavlm_attn_bwd_args& a, hipStream_t s) {
   const float c = a.scale * 1.44269504088896340736f;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
-    attr_done = true;
+  static mavlm_per_device_once once[4];
+  {
+    hipError_t e = once[0].dyn_lds((const void*)attn_bwd_kernel<T, 0>, BWD_LDS);
+    if (e == hipSuccess) e = once[1].dyn_lds((const void*)attn_bwd_kernel<T, 1>, BWD_LDS);
+    if (e == hipSuccess) e = once[2].dyn_lds((const void*)attn_bwd_kernel<T, 2>, BWD_LDS);
+    if (e == hipSuccess) e = once[3].dyn_lds((const void*)attn_bwd_kernel<T, 3>, BWD_LDS);
+    if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((a.R + 3) / 4), dim3(256), 0, s, (const uint16_t*)a.O, a.ldo,
                      (const uint16_t*)a.dO, a.lddo, a.delta, a.R, a.H);

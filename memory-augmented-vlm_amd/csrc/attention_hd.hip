@@ -321,11 +321,10 @@ template <typename T, int HD>
 hipError_t launch_fwd_hd(const mavlm_attn_args& a, hipStream_t s) {
   constexpr int LDS = 4 * ((HD + 127) / 128) * KTH * 256;
   auto kern = attn_fwd_hd_kernel<T, HD>;
-  static bool done = false;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  static mavlm_per_device_once once;
+  {
+    hipError_t e = once.dyn_lds((const void*)kern, LDS);
     if (e != hipSuccess) return e;
-    done = true;
   }
   const float c = a.scale * 1.44269504088896340736f;
   int tps = 0;
@@ -344,11 +343,10 @@ template <typename T, int HD>
 hipError_t launch_colsum_hd(const mavlm_colsum_args& a, hipStream_t s) {
   constexpr int LDS = 2 * ((HD + 127) / 128) * KTH * 256;
   auto kern = attn_colsum_hd_kernel<T, HD>;
-  static bool done = false;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  static mavlm_per_device_once once;
+  {
+    hipError_t e = once.dyn_lds((const void*)kern, LDS);
     if (e != hipSuccess) return e;
-    done = true;
   }
   const float c = a.scale * 1.44269504088896340736f;
   hipLaunchKernelGGL(kern, dim3(((a.S + 127) / 128) * a.H), dim3(256), LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,

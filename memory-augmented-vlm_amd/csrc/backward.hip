@@ -325,12 +325,10 @@ hipError_t launch_ln_bwd(const uint16_t* dy, const float* x, const uint16_t* res
   const size_t lds = (size_t)3 * 2 * D * sizeof(float);
 #define LNB(NV)                                                                                                     \
   do {                                                                                                              \
-    static bool attr_done = false;                                                                                  \
-    if (!attr_done && lds > 65536) {                                                                                \
-      hipError_t ae = hipFuncSetAttribute((const void*)layernorm_bwd_kernel<T, NV>,                                 \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 4096 * 4);            \
+    static mavlm_per_device_once once;                                                                              \
+    if (lds > 65536) {                                                                                              \
+      hipError_t ae = once.dyn_lds((const void*)layernorm_bwd_kernel<T, NV>, 3 * 2 * 4096 * 4);                     \
       if (ae != hipSuccess) return ae;                                                                              \
-      attr_done = true;                                                                                             \
     }                                                                                                               \
     hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), grid, block, lds, s, dy, x, res, ldr, gamma, dz, part, rows,   \
                        D, eps);                                                                                     \

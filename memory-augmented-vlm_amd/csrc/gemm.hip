@@ -153,11 +153,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const uint16_t* __restr
 template <typename T, int EPI>
 hipError_t launch(const mavlm_gemm_args& g, hipStream_t s) {
   auto kern = gemm_tn_kernel<T, EPI>;
-  static bool attr_done = false;   // per instantiation
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+  static mavlm_per_device_once once;   // per instantiation
+  {
+    hipError_t e = once.dyn_lds((const void*)kern, GEMM_LDS);
     if (e != hipSuccess) return e;
-    attr_done = true;
   }
   const int ntm = (g.M + BM - 1) / BM, ntn = g.N / BN;
   hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(256), GEMM_LDS, s, (const uint16_t*)g.A, g.lda, (const uint16_t*)g.W,
@@ -168,11 +167,10 @@ hipError_t launch(const mavlm_gemm_args& g, hipStream_t s) {
 template <typename T>
 hipError_t launch_splitk(const mavlm_gemm_args& g, int splits, int ksplit, hipStream_t s) {
   auto kern = gemm_tn_kernel<T, MAVLM_EPI_F32>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+  static mavlm_per_device_once once;
+  {
+    hipError_t e = once.dyn_lds((const void*)kern, GEMM_LDS);
     if (e != hipSuccess) return e;
-    attr_done = true;
   }
   const int ntm = (g.M + BM - 1) / BM, ntn = g.N / BN;
   hipLaunchKernelGGL(kern, dim3(ntm * ntn, splits), dim3(256), GEMM_LDS, s, (const uint16_t*)g.A, g.lda,
@@ -233,6 +231,7 @@ static bool use_256(const mavlm_gemm_args& g) {
   return tiles >= 192;
 }
 
+
 int mavlm_gemm_splits(int M, int N, int K, int epilogue, int ldc) {
   if (M <= 0 || N % BN || K % BK || ldc != N || epilogue == MAVLM_EPI_RES_F32) return 1;
   const long tiles = (long)((M + BM - 1) / BM) * (N / BN);
@@ -280,7 +279,8 @@ hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s)
   if (use_256(g)) {
     // persistent kernel when workgroups get more than one tile each (its pipeline never drains between tiles);
     // with at most one tile per CU the plain kernel is the same work with less code in flight
-    const long tiles = (long)((g.M + 255) / 256) * (g.N / 256);
+    const int rows = mavlm_gemm_tile_rows(g.M, g.N);
+    const long tiles = (long)((g.M + rows - 1) / rows) * (g.N / 256);
     const bool want_p = g_mavlm_gemm_tile == 257 || (g_mavlm_gemm_tile == 0 && tiles > 256);
     if (want_p && mavlm_gemm256p_supported(g)) return mavlm_launch_gemm256p(g, dtype, s);
     return mavlm_launch_gemm256(g, dtype, s);

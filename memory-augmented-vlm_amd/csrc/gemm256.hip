@@ -59,7 +59,14 @@ constexpr int GEMM256_LDS = 2 * STAGE2;      // 128 KiB
 
 __device__ __forceinline__ float gelu_erf2(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <typename T, int EPI>
+// MT1 = 16-row MFMA tiles in the SECOND 64-row slice of a wave's rows: 4 -> 256-row workgroup tile (wave tile 128x64),
+// 3 -> 224-row tile (wave tile 112x64; phases 3 and 4 run 12 MFMAs).  224 = 7 * 32 divides R = M_tokens * 196 whenever
+// M_tokens % 8 == 0: R = 12 544 is 56 x 224 but 49 x 256, so on 256 CUs a 224-row grid is 224 / 448 / 896 tiles where
+// the 256-row grid is 196 / 392 / 784 - the same number of rounds at 7/8 of the work per round (mavlm_gemm_tile_rows).
+// The LDS image keeps its 128-row half-tile slots (rows 112-127 of a slot are staged but never read), so the DMA
+// instruction count - and with it every counted vmcnt - is the same for both heights.  Each output element sums its
+// K products in the same order for both heights: results are bit-identical.
+template <typename T, int EPI, int MT1>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restrict__ A, int lda,
                                                          const uint16_t* __restrict__ W, int ldw,
                                                          const float* __restrict__ bias,
@@ -70,11 +77,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+  constexpr int MHALF = 64 + 16 * MT1;        // rows per wave group (= valid rows of an A half-tile slot)
+  constexpr int BMT = 2 * MHALF;              // workgroup tile height
 
   const int ntn = N / BN2;
-  const int ntm = (M + BM2 - 1) / BM2;
+  const int ntm = (M + BMT - 1) / BMT;
   const int wg = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (wg / ntn) * BM2;
+  const int m0 = (wg / ntn) * BMT;
   const int n0 = (wg % ntn) * BN2;
 
   // ---- LDS-DMA sources: wave w stages 8-row groups g = 2w, 2w+1 of every half-tile
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
     for (int j = 0; j < 2; ++j) {
       const int row = (wave * 2 + j) * 8 + srow;          // row inside the half-tile
       const int c = sp ^ ((row >> 1) & 7);                // logical 16-B chunk stored at physical chunk sp
-      int ar = m0 + h * 128 + row;
+      int ar = m0 + h * MHALF + row;            // (rows >= MHALF of a slot: staged, never read)
       ar = ar < M ? ar : M - 1;
       gA[h][j] = A + (size_t)ar * lda + c * 8;
       gB[h][j] = W + (size_t)(n0 + h * 128 + row) * ldw + c * 8;
@@ -110,9 +119,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   const int offA = wm * HALF + fr * 128;                               // + mh*8192 + mt*2048
   const int offB = 2 * HALF + (wn >> 1) * HALF + ((wn & 1) * 64 + fr) * 128;   // + nh*4096 + nt*2048
 
-  f32x4 acc[8][4];
+  f32x4 acc[4 + MT1][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 4 + MT1; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -135,6 +144,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   auto read_a = [&](const char* st, int mh) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
+      if (mh == 1 && mt >= MT1) continue;     // (mh is a literal at every call site)
       af[mt][0] = *(const typename T::vec8*)(st + offA + mh * 8192 + mt * 2048 + ck0);
       af[mt][1] = *(const typename T::vec8*)(st + offA + mh * 8192 + mt * 2048 + ck1);
     }
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   {                                                                                         \
     __builtin_amdgcn_s_setprio(1);                                                          \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
-    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                        \
+    _Pragma("unroll") for (int mt = 0; mt < (MH ? MT1 : 4); ++mt)                           \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                        \
       acc[MH * 4 + mt][NH * 2 + nt] = T::mfma16(bf[NH * 2 + nt][ks], af[mt][ks], acc[MH * 4 + mt][NH * 2 + nt]); \
     __builtin_amdgcn_s_setprio(0);                                                          \
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   if (!trailing) MAVLM_BAR();          // matches the trailing group's last barrier
 #undef MAVLM_QUADRANT
 
-  // ---- epilogue: lane holds C[m][n..n+3], m = m0 + wm*128 + 16 i + fr, n = n0 + wn*64 + 16 j + 4 fq.
+  // ---- epilogue: lane holds C[m][n..n+3], m = m0 + wm*MHALF + 16 i + fr, n = n0 + wn*64 + 16 j + 4 fq.
   // 16-bit outputs: column blocks (j, j+1) are exchanged between lane groups (widen_pair) so that every lane stores
   // 16 contiguous bytes - half the store instructions, 64-byte instead of 32-byte row segments.
   auto act = [&](float v) {
@@ -207,8 +217,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
 #pragma unroll
   for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(bias + n0 + wn * 64 + j * 16 + fq * 4);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wm * 128 + i * 16 + fr;
+  for (int i = 0; i < 4 + MT1; ++i) {
+    const int m = m0 + wm * MHALF + i * 16 + fr;
     if (EPI == MAVLM_EPI_RES_F32 || EPI == MAVLM_EPI_F32) {
       if (m >= M) continue;
 #pragma unroll
@@ -234,19 +244,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   }
 }
 
-template <typename T, int EPI>
-hipError_t launch256(const mavlm_gemm_args& g, hipStream_t s) {
-  auto kern = gemm256_kernel<T, EPI>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS);
+template <typename T, int EPI, int MT1>
+hipError_t launch256h(const mavlm_gemm_args& g, hipStream_t s) {
+  auto kern = gemm256_kernel<T, EPI, MT1>;
+  constexpr int BMT = 2 * (64 + 16 * MT1);
+  static mavlm_per_device_once once;
+  {
+    hipError_t e = once.dyn_lds((const void*)kern, GEMM256_LDS);
     if (e != hipSuccess) return e;
-    attr_done = true;
   }
-  const int ntm = (g.M + BM2 - 1) / BM2, ntn = g.N / BN2;
+  const int ntm = (g.M + BMT - 1) / BMT, ntn = g.N / BN2;
   hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(512), GEMM256_LDS, s, (const uint16_t*)g.A, g.lda, (const uint16_t*)g.W,
                      g.ldw, g.bias, (const uint16_t*)g.res, g.ldr, g.C, g.ldc, g.M, g.N, g.K);
   return hipGetLastError();
+}
+
+template <typename T, int EPI>
+hipError_t launch256(const mavlm_gemm_args& g, hipStream_t s) {
+  return mavlm_gemm_tile_rows(g.M, g.N) == 224 ? launch256h<T, EPI, 3>(g, s) : launch256h<T, EPI, 4>(g, s);
 }
 
 template <typename T>
@@ -264,6 +279,18 @@ hipError_t launch256_epi(const mavlm_gemm_args& g, hipStream_t s) {
 }  // namespace
 
 bool mavlm_gemm256_supported(const mavlm_gemm_args& g) { return g.N % BN2 == 0 && g.K % BK2 == 0 && g.M >= 1; }
+
+// Height of the workgroup tile (256 or 224 rows) for an M x N output on 256 CUs at one workgroup per CU: the height
+// whose grid costs fewer row-rounds, rounds x height (ties -> 256).  Pure function of the shape; the result of the GEMM
+// does not depend on it.
+int g_mavlm_gemm_rows = 0;      // diagnostics: 0 = automatic, 224 / 256 = forced
+int mavlm_gemm_tile_rows(int M, int N) {
+  if (g_mavlm_gemm_rows == 224 || g_mavlm_gemm_rows == 256) return g_mavlm_gemm_rows;
+  const long ntn = N / BN2;
+  const long t256 = (long)((M + 255) / 256) * ntn, t224 = (long)((M + 223) / 224) * ntn;
+  const long c256 = ((t256 + 255) / 256) * 256, c224 = ((t224 + 255) / 256) * 224;
+  return c224 < c256 ? 224 : 256;
+}
 
 hipError_t mavlm_launch_gemm256(const mavlm_gemm_args& g, int dtype, hipStream_t s) {
   return dtype == MAVLM_F16 ? launch256_epi<F16>(g, s) : launch256_epi<BF16>(g, s);

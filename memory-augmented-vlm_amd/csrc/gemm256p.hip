@@ -72,7 +72,8 @@ constexpr int GEMM256P_LDS = GEMM256_LDS + 2048;
 
 __device__ __forceinline__ float gelu_erf2p(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <typename T, int EPI>
+// MT1: 4 -> 256-row tiles, 3 -> 224-row tiles (see gemm256_kernel)
+template <typename T, int EPI, int MT1>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __restrict__ A, int lda,
                                                           const uint16_t* __restrict__ W, int ldw,
                                                           const float* __restrict__ bias, void* __restrict__ Cout,
@@ -82,6 +83,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+  constexpr int MHALF = 64 + 16 * MT1;
+  constexpr int BMT = 2 * MHALF;
 
   const int ntn = N / BN2;
   const int G = gridDim.x;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
     int lin = (int)blockIdx.x + it * G;
     // XCD-aware order inside every full window of G tiles (blocks b, b+8 share an XCD)
     if ((it + 1) * G <= total_tiles && (G & 7) == 0) lin = it * G + xcd_remap((int)blockIdx.x, G);
-    m0 = (lin / ntn) * BM2;
+    m0 = (lin / ntn) * BMT;
     n0 = (lin % ntn) * BN2;
   };
   auto set_offsets = [&](int which, int m0, int n0) {
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
       for (int j = 0; j < 2; ++j) {
         const int row = (wave * 2 + j) * 8 + srow;
         const int c = sp ^ ((row >> 1) & 7);
-        int ar = m0 + h * 128 + row;
+        int ar = m0 + h * MHALF + row;
         ar = ar < M ? ar : M - 1;
         offA[which][h][j] = ar * lda + c * 8;
         offB[which][h][j] = (n0 + h * 128 + row) * ldw + c * 8;
@@ -141,9 +144,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
   const int offA_f = wm * HALF + fr * 128;                               // + mh*8192 + mt*2048
   const int offB_f = 2 * HALF + (wn >> 1) * HALF + ((wn & 1) * 64 + fr) * 128;   // + nh*4096 + nt*2048
 
-  f32x4 acc[8][4];
+  f32x4 acc[4 + MT1][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 4 + MT1; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -169,6 +172,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
   auto read_a = [&](const char* st, int mh) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
+      if (mh == 1 && mt >= MT1) continue;
       af[mt][0] = *(const typename T::vec8*)(st + offA_f + mh * 8192 + mt * 2048 + ck0);
       af[mt][1] = *(const typename T::vec8*)(st + offA_f + mh * 8192 + mt * 2048 + ck1);
     }
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
   {                                                                                         \
     __builtin_amdgcn_s_setprio(1);                                                          \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
-    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                        \
+    _Pragma("unroll") for (int mt = 0; mt < (MH ? MT1 : 4); ++mt)                           \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                        \
       acc[MH * 4 + mt][NH * 2 + nt] = T::mfma16(bf[NH * 2 + nt][ks], af[mt][ks], acc[MH * 4 + mt][NH * 2 + nt]); \
     __builtin_amdgcn_s_setprio(0);                                                          \
@@ -241,8 +245,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
       return v;
     };
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0c + wm * 128 + i * 16 + fr;
+    for (int i = 0; i < 4 + MT1; ++i) {
+      const int m = m0c + wm * MHALF + i * 16 + fr;
       if (EPI == MAVLM_EPI_F32) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -282,26 +286,33 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
 #undef MAVLM_QUADRANT
 }
 
-template <typename T, int EPI>
-hipError_t launch256p(const mavlm_gemm_args& g, hipStream_t s) {
-  auto kern = gemm256p_kernel<T, EPI>;
-  static bool attr_done = false;
-  static int cus = 0;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256P_LDS);
+template <typename T, int EPI, int MT1>
+hipError_t launch256ph(const mavlm_gemm_args& g, hipStream_t s) {
+  auto kern = gemm256p_kernel<T, EPI, MT1>;
+  constexpr int BMT = 2 * (64 + 16 * MT1);
+  static mavlm_per_device_once once;
+  static int cus = 0;          // MI355X: 256 on every device of a node
+  {
+    hipError_t e = once.dyn_lds((const void*)kern, GEMM256P_LDS);
     if (e != hipSuccess) return e;
-    int dev = 0;
-    e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess || cus <= 0) return hipErrorInvalidValue;
-    attr_done = true;
+    if (cus <= 0) {
+      int dev = 0;
+      e = hipGetDevice(&dev);
+      if (e != hipSuccess) return e;
+      e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      if (e != hipSuccess || cus <= 0) return hipErrorInvalidValue;
+    }
   }
-  const int tiles = ((g.M + BM2 - 1) / BM2) * (g.N / BN2);
+  const int tiles = ((g.M + BMT - 1) / BMT) * (g.N / BN2);
   const int grid = tiles < cus ? tiles : cus;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), GEMM256P_LDS, s, (const uint16_t*)g.A, g.lda, (const uint16_t*)g.W,
                      g.ldw, g.bias, g.C, g.ldc, g.M, g.N, g.K, tiles);
   return hipGetLastError();
+}
+
+template <typename T, int EPI>
+hipError_t launch256p(const mavlm_gemm_args& g, hipStream_t s) {
+  return mavlm_gemm_tile_rows(g.M, g.N) == 224 ? launch256ph<T, EPI, 3>(g, s) : launch256ph<T, EPI, 4>(g, s);
 }
 
 }  // namespace

@@ -16,6 +16,7 @@ struct mavlm_ctx {
   int steps = 0;
   // workspace carve (byte offsets)
   size_t o_kv, o_q, o_ctx, o_a, o_h, o_pre, o_mA, o_mB, o_lse, o_part, o_split, o_gsplit, gsplit_floats, total;
+  int fuse_mems = 1;   // cached memories the Memory-Fuser MLP takes per GEMM launch (mavlm_fuse_emit)
 };
 
 namespace {
@@ -42,6 +43,17 @@ inline bool wide_heads(const mavlm_config& c) { return c.hidden / c.heads > 128;
 inline int padded_width(const mavlm_config& c) { return wide_heads(c) ? c.hidden : c.heads * 128; }
 inline float attn_scale(const mavlm_config& c) { return 1.0f / sqrtf((float)(c.hidden / c.heads)); }
 
+// Memory-Fuser batching: the fuser MLP is row-independent, and the FIFO ring is one contiguous [cap, R, D] buffer, so
+// cached memories that sit in consecutive slots go through ONE pair of GEMMs.  At the reference's 8 memory tokens
+// (R = 1568) a launch per memory fills 7 of 256 CUs' worth of 256-row tiles; up to FUSE_ROWS rows per launch fill the chip.
+constexpr int FUSE_ROWS = 16384;
+inline int fuse_mems_per_launch(const mavlm_config& c) {
+  const int R = c.mem_tokens * c.patches;
+  int k = FUSE_ROWS / R;
+  if (k < 1) k = 1;
+  return k > c.cache_cap ? c.cache_cap : k;
+}
+
 void carve(mavlm_ctx* x) {
   const mavlm_config& c = x->cfg;
   const size_t R = (size_t)c.mem_tokens * c.patches, S = (size_t)c.max_chunk_frames * c.patches, D = c.hidden,
@@ -51,7 +63,8 @@ void carve(mavlm_ctx* x) {
   x->o_q = o;    o += al(R * Dp * 2);
   x->o_ctx = o;  o += al(R * Dp * 2);
   x->o_a = o;    o += al(R * D * 2);
-  x->o_h = o;    o += al(R * I * 2);
+  x->fuse_mems = fuse_mems_per_launch(c);
+  x->o_h = o;    o += al((size_t)x->fuse_mems * R * I * 2);     // MLP hidden of a step (R rows) / of a fuser batch
   x->o_pre = o;  o += al(R * D * 4);
   x->o_mA = o;   o += al(R * D * 2);
   x->o_mB = o;   o += al(R * D * 2);
@@ -153,6 +166,12 @@ int mavlm_set_attention_bwd_fused(int32_t on) {
 int mavlm_set_gemm_tile(int32_t tile) {
   if (tile != 0 && tile != 128 && tile != 256 && tile != 257) return MAVLM_E_ARG;
   g_mavlm_gemm_tile = tile;
+  return 0;
+}
+
+int mavlm_set_gemm_rows(int32_t rows) {
+  if (rows != 0 && rows != 224 && rows != 256) return MAVLM_E_ARG;
+  g_mavlm_gemm_rows = rows;
   return 0;
 }
 
@@ -316,13 +335,19 @@ int mavlm_fuse_emit(mavlm_ctx* x, const void* x_pe, const int64_t* fine_idx, int
   if (n_mem_prompt) MAVLM_TRY(hipMemcpyAsync(o, mem_prompt, rowb * n_mem_prompt, hipMemcpyDeviceToDevice, s));
   row += n_mem_prompt;
   const int oldest = x->steps <= cap ? 0 : x->steps % cap;
-  for (int i = 0; i < n; ++i) {   // torch.cat(memory_cache) order = oldest first (llava_arch.py:545)
-    const int slot = (oldest + i) % cap;
+  // torch.cat(memory_cache) order = oldest first (llava_arch.py:545) = ring slots oldest..cap-1, then 0..oldest-1: at most
+  // two contiguous slot ranges, each fused in batches of up to fuse_mems memories per GEMM pair (llava_arch.py:546)
+  for (int done = 0; done < n;) {
+    const int slot = (oldest + done) % cap;
+    int run = n - done < cap - slot ? n - done : cap - slot;
+    if (run > x->fuse_mems) run = x->fuse_mems;
+    const int rows_ = run * R;
     const char* mem = (const char*)x->b.mem_ring + (size_t)slot * R * rowb;
-    MAVLM_TRY(gemm_x(x, s, mem, D, x->w.w_f1, D, x->w.b_f1, ws(x, x->o_h), I, R, I, D, MAVLM_EPI_GELU));
-    MAVLM_TRY(gemm_x(x, s, ws(x, x->o_h), I, x->w.w_f2, I, x->w.b_f2_type0, o + (size_t)row * rowb, D, R, D, I,
+    MAVLM_TRY(gemm_x(x, s, mem, D, x->w.w_f1, D, x->w.b_f1, ws(x, x->o_h), I, rows_, I, D, MAVLM_EPI_GELU));
+    MAVLM_TRY(gemm_x(x, s, ws(x, x->o_h), I, x->w.w_f2, I, x->w.b_f2_type0, o + (size_t)row * rowb, D, rows_, D, I,
                      MAVLM_EPI_BIAS));
-    row += R;
+    row += rows_;
+    done += run;
   }
   MAVLM_TRY(hipMemcpyAsync(o + (size_t)row * rowb, newline, rowb, hipMemcpyDeviceToDevice, s));
   row += 1;

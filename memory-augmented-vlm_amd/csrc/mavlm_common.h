@@ -4,6 +4,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// One-time kernel attributes (hipFuncAttributeMaxDynamicSharedMemorySize) are per DEVICE, not per process: a process
+// that drives a second GPU must set them there as well, or its 64-128 KiB-LDS kernels fail to launch on that device.
+struct mavlm_per_device_once {
+  unsigned long long seen[4] = {0, 0, 0, 0};           // one bit per device ordinal (256 ordinals)
+  // returns hipSuccess once `bytes` of dynamic LDS are allowed for `fn` on the CURRENT device
+  hipError_t dyn_lds(const void* fn, int bytes) {
+    int d = 0;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (d & 63);
+    if (seen[(d >> 6) & 3] & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) seen[(d >> 6) & 3] |= bit;
+    return e;
+  }
+};
+
+
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

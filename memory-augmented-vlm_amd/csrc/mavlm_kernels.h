@@ -31,6 +31,9 @@ hipError_t mavlm_launch_gemm256p(const mavlm_gemm_args& g, int dtype, hipStream_
 hipError_t mavlm_launch_gemm_splitk(const mavlm_gemm_args& g, int splits, float* ws, const float* zero_bias, int dtype,
                                     hipStream_t s);
 extern int g_mavlm_gemm_tile;   // 0 = auto, 128 / 256 = forced non-persistent, 257 = forced persistent (tuning hook)
+// height of the 256-column workgroup tile for an M x N output: 256 or 224 rows (gemm256.hip); same results either way
+int mavlm_gemm_tile_rows(int M, int N);
+extern int g_mavlm_gemm_rows;   // 0 = auto, 224 / 256 = forced (tuning hook)
 
 struct mavlm_attn_args {
   const void* Q; int ldq;        // [R, >=H*128] 16-bit; head h at column h*128

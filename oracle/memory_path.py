@@ -412,9 +412,28 @@ def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mo
     lse2 = np.empty((heads, R), dtype=F32)
     colsum = np.zeros((heads, Lk), dtype=np.float64) if want_colsum else None
     probs = np.empty((heads, R, Lk), dtype=F32) if want_probs else None
+    lazy = mode != "fp32" and not want_probs and R * Lk > (1 << 24)
     for h in range(heads):
         sl = slice(h * d, (h + 1) * d)
-        s = _mm(Q[:, sl], K[:, sl].T) * scale                                # :51
+        if lazy:
+            # large problems (emulation modes): scores are produced tile by tile instead of as one [R, Lk] matrix whose
+            # 64-column slices would be strided by Lk * 4 bytes
+            s = None
+            Qh, Kh = np.ascontiguousarray(Q[:, sl]), np.ascontiguousarray(K[:, sl])
+            chunk = {"k0": -1, "s": None}       # scores of the 4096-key chunk that holds the requested tile
+
+            def tile_scores(k0, k1, Qh=Qh, Kh=Kh, chunk=chunk):
+                c0 = (k0 // 4096) * 4096
+                if chunk["k0"] != c0:
+                    chunk["k0"], chunk["s"] = c0, _mm(Qh, Kh[c0:c0 + 4096].T) * scale
+                if k1 - c0 > 4096:             # (a request that straddles chunks: the column-sum sweep is chunk-aligned,
+                    return _mm(Qh, Kh[k0:k1].T) * scale     #  64-key tiles never straddle)
+                return chunk["s"][:, k0 - c0:k1 - c0]
+        else:
+            s = _mm(Q[:, sl], K[:, sl].T) * scale                            # :51
+
+            def tile_scores(k0, k1, s=s):
+                return s[:, k0:k1]
         if mode == "fp32":
             m = s.max(axis=1, keepdims=True)
             p = np.exp(s - m, dtype=F32)
@@ -426,7 +445,7 @@ def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mo
                 l = np.zeros((R, 1), dtype=F32)
                 acc = np.zeros((R, d), dtype=F32)
                 for k0 in range(k_lo, k_hi, kv_tile):
-                    st = s[:, k0:min(k0 + kv_tile, k_hi)]
+                    st = tile_scores(k0, min(k0 + kv_tile, k_hi))
                     cand = np.maximum(m, st.max(axis=1, keepdims=True))
                     need = ((cand - m) * F32(1.4426950408889634) > F32(RESCALE_LOG2)).reshape(-1)
                     pad = (-R) % wave_rows
@@ -463,7 +482,11 @@ def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mo
         ctx[:, sl] = acc / l                                                 # :53
         lse = m + np.log(l)
         lse2[h] = (lse / F32(math.log(2.0))).reshape(-1)
-        if want_colsum or want_probs:
+        if lazy and want_colsum:
+            for k0 in range(0, Lk, 4096):
+                k1 = min(k0 + 4096, Lk)
+                colsum[h, k0:k1] = np.exp(tile_scores(k0, k1) - lse, dtype=F32).sum(axis=0, dtype=np.float64)
+        elif want_colsum or want_probs:
             pn = np.exp(s - lse, dtype=F32)                                  # :52 normalised probabilities
             if want_colsum:
                 colsum[h] = pn.sum(axis=0, dtype=np.float64)

@@ -50,9 +50,10 @@ if what in ("colsum", "all"):
     timeit(lambda: ops.attention_colsum(q, kv[:, :D], lse, H), 2.0 * R * S * D, f"colsum impl {impl} R={R} S={S}")
   capi.lib().mavlm_set_attention_impl(0)
 if what in ("gemm", "all"):
-  for tile in (256, 257):
+  for tile, rows in ((256, 256), (256, 224), (257, 256), (257, 224), (0, 0)):
     capi.lib().mavlm_set_gemm_tile(tile)
-    print("tile", tile)
+    capi.lib().mavlm_set_gemm_rows(rows)
+    print("tile", tile, "rows", rows)
     for (M, N, K, epi) in [(S, 4 * D, D, 0), (R, D, D, 0), (R, D, D, 4), (R, 4 * D, D, 1), (R, D, 4 * D, 4), (R, 2 * D, D, 0),
                            (R, 4 * D, D, 2)]:
       a = torch.randn(M, K, device=dev).bfloat16()

@@ -125,8 +125,9 @@ def test_forward_and_generate_through_real_qwen2_backbone(name, hidden, layers, 
 
 def test_training_step_through_the_backbone_reaches_the_memory_parameters():
     """`forward(labels=...)` with autograd on (the reference's training entry, llava_qwen.py:80-114): the loss of the
-    Qwen2 backbone back-propagates through inputs_embeds into the HIP backward of the memory path.  Forward activations
-    are the inference ones (same kernels), so the training-mode embeddings equal the inference-mode ones bit for bit."""
+    Qwen2 backbone back-propagates through inputs_embeds into the HIP backward of the memory path.  The training-mode
+    embeddings equal the inference-mode ones: bit for bit outside the fused-memory rows, and inside them up to the one
+    extra 16-bit rounding of the fuser's GELU pre-activation that the backward needs."""
     m = build(896, 2, 14, 2, 4864)
     m.train()
     for n_, p_ in m.named_parameters():               # mm_tunable_parts = recurrent_model + larimar_model (train.py:1708-1724)
@@ -145,7 +146,12 @@ def test_training_step_through_the_backbone_reaches_the_memory_parameters():
     with torch.no_grad():
         m.eval()
         ref = standalone_embeds(m, video, ids, p)
-    assert torch.equal(seen["emb"], ref)
+    rows = arch.video_token_rows(64, 8)
+    a, b = p + len(arch.MEMORY_PROMPT_IDS), p + len(arch.MEMORY_PROMPT_IDS) + 2 * 8 * 196       # fused memory rows
+    assert seen["emb"].shape == ref.shape == (1, ids.shape[1] - 1 + rows, 896)
+    assert torch.equal(seen["emb"][0, :a], ref[0, :a]) and torch.equal(seen["emb"][0, b:], ref[0, b:])
+    d = (seen["emb"][0, a:b].float() - ref[0, a:b].float()).norm() / ref[0, a:b].float().norm()
+    assert float(d) < 2e-3
     got = {n_: p_.grad for n_, p_ in m.named_parameters() if p_.requires_grad}
     assert got and all(g is not None and torch.isfinite(g.float()).all() for g in got.values())
     nz = [n_ for n_, g in got.items() if float(g.float().abs().max()) > 0]

@@ -22,13 +22,17 @@ def _int_mat(shape, seed, lo=-4, hi=4):
     return np.floor(O.hash_uniform(shape, seed, lo, hi + 0.999)).astype(np.float32)
 
 
-@pytest.fixture(params=[128, 256, 257])
+@pytest.fixture(params=[(128, 0), (256, 256), (256, 224), (257, 256), (257, 224)], ids=lambda p: f"tile{p[0]}-rows{p[1]}")
 def gemm_tile(request):
-    """Run the GEMM tests once per kernel: 128^2 4-wave, 256^2 8-wave LDS-DMA pipeline, 256^2 persistent (257;
-    shapes / epilogues it does not take fall through to the non-persistent kernels)."""
-    capi.check(capi.lib().mavlm_set_gemm_tile(request.param), "set tile")
-    yield request.param
+    """Run the GEMM tests once per kernel: 128^2 4-wave, 256-column 8-wave LDS-DMA pipeline with 256- and 224-row
+    workgroup tiles, and its persistent form (257; shapes / epilogues it does not take fall through to the
+    non-persistent kernels)."""
+    tile, rows = request.param
+    capi.check(capi.lib().mavlm_set_gemm_tile(tile), "set tile")
+    capi.check(capi.lib().mavlm_set_gemm_rows(rows), "set rows")
+    yield tile
     capi.lib().mavlm_set_gemm_tile(0)
+    capi.lib().mavlm_set_gemm_rows(0)
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
@@ -51,6 +55,31 @@ def test_linear_integer_exact(mode, M, N, K, gemm_tile):
     np.testing.assert_array_equal(to_np(out_f32), ref)
     out_b = ops.linear(to_dev(A, mode), to_dev(W, mode), f32_dev(b), capi.EPI_BIAS)
     np.testing.assert_array_equal(to_np(out_b), r(ref))
+
+
+def test_gemm_tile_height_is_a_pure_speed_choice():
+    """The 224-row and 256-row workgroup tiles give bit-identical results (same K order per output element), on random
+    data, for ragged M (not a multiple of either height), in both the plain and the persistent kernel."""
+    lib = capi.lib()
+    M, N, K = 12544 + 37, 1024, 320
+    a = to_dev(O.bf16_round(O.hash_normal_like((M, K), 71)))
+    w = to_dev(O.bf16_round(O.hash_uniform((N, K), 72, -0.1, 0.1)))
+    b = f32_dev(O.hash_uniform((N,), 73, -0.1, 0.1))
+    outs = []
+    try:
+        for tile in (256, 257):
+            for rows in (256, 224):
+                lib.mavlm_set_gemm_tile(tile)
+                lib.mavlm_set_gemm_rows(rows)
+                outs.append(ops.linear(a, w, b, capi.EPI_GELU).clone())
+                outs.append(ops.linear(a, w, b, capi.EPI_F32).clone().view(torch.int32))
+    finally:
+        lib.mavlm_set_gemm_tile(0)
+        lib.mavlm_set_gemm_rows(0)
+    for o in outs[2::2]:
+        assert torch.equal(o, outs[0])
+    for o in outs[3::2]:
+        assert torch.equal(o, outs[1])
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(1568, 1024, 1024, "bias"), (588, 4096, 1024, "bias"), (777, 512, 4096, "gelu"),
