@@ -22,6 +22,16 @@ constexpr int HD3 = 128, KT3 = 64;
 constexpr int TILE3 = KT3 * HD3 * 2;          // 16 KiB
 constexpr int ATTN3_LDS = 4 * TILE3;          // K0 K1 V0 V1
 constexpr float RESCALE3_LOG2 = 8.0f;         // same deferred-rescale rule as attn_fwd_kernel (mirrored by the oracle)
+// LDS read-ahead, in MFMA steps, of the K fragments (phase A) and of the transposed V fragments (phase B).  One MFMA
+// step is 32-64 clocks of matrix pipe, an LDS read under load returns after 100-200: with a read-ahead of ONE step every
+// MFMA waited for its own operand (the ISA showed `s_waitcnt lgkmcnt(0)` in front of each of the 32 MFMAs of a tile and
+// the kernel ran at 5.1k clocks per tile and wave against 1.0k of MFMA work).  4 VGPRs per step of read-ahead.
+#ifndef MAVLM_ATTN3_KPF
+#define MAVLM_ATTN3_KPF 3
+#endif
+#ifndef MAVLM_ATTN3_VPF
+#define MAVLM_ATTN3_VPF 3
+#endif
 
 __device__ __forceinline__ int img3_x(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
@@ -67,29 +77,44 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
   // ---- LDS-DMA geometry: instruction i (0..3) of wave w writes the 1 KiB block of rows 16 i + 4 w + (lane>>4).
   // Physical 16-B chunk p = lane & 15 of row `row` holds logical chunk p ^ x(row), x = ((row&3)<<2) | ((row>>2)&3)
   // = ((lane>>4)<<2) | w: independent of i, so the four sources of a tile differ by the uniform stride 16*ld.
+  //
+  // The DMAs are BUFFER loads (`buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds`): a wave-uniform descriptor of this
+  // head's K (V) columns, ONE loop-invariant 32-bit lane offset, and a scalar offset that carries the tile and the piece.
+  // Issuing a piece is then `s_mov m0` + the load - no vector address arithmetic.  (In-kernel stamps of the previous
+  // form - `global_load_lds` with 64-bit lane addresses rebuilt by VALU for every piece, scalars reloaded from spill
+  // lanes - showed 980 of a wave's 3 700 clocks per tile going into ISSUING the eight DMAs.)  The descriptor ends after
+  // the last valid row: rows past S of a ragged last tile read as zeros (they are masked to -inf / multiplied by p = 0).
   const int drow = 4 * wave + (lane >> 4);                    // + 16 i
   const int dch = (lane & 15) ^ (((lane >> 4) << 2) | wave);
-  // byte offset of instruction 0 inside a tile: loop-invariant, 32-bit (added to a wave-uniform 64-bit base that
-  // the scalar unit advances, so a DMA costs no vector address arithmetic)
-  const unsigned koff = (unsigned)(drow * ldk + h * HD3 + dch * 8) * 2u;
-  const unsigned voff = (unsigned)(drow * ldv + h * HD3 + dch * 8) * 2u;
-  auto dma_tile = [&](const uint16_t* base, int ld, unsigned off, int t, char* dst) {
-    char* d = dst + wave * 1024;
-    if ((t + 1) * KT3 <= S) {                                 // full tile: uniform base + one per-lane offset
-      const char* b = (const char*)base + (size_t)t * KT3 * ld * 2;
+  auto head_rsrc = [&](const uint16_t* base, int ld) {
+    const uintptr_t a = (uintptr_t)(base + h * HD3);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const uint32_t bytes = __builtin_amdgcn_readfirstlane((uint32_t)(S - 1) * (uint32_t)ld * 2u + (uint32_t)HD3 * 2u);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, bytes, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t krs = head_rsrc(K, ldk), vrs = head_rsrc(V, ldv);
+  // lane offsets (bytes) of the four pieces of a tile: loop-invariant VGPRs (registers the kernel has to spare - scalar
+  // registers it has not: with per-piece scalar offsets and LDS addresses hoisted out of the loop the compiler spilled
+  // 64 SGPRs to vector lanes and read 38 of them back per tile)
+  int koff[4], voff[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)(b + (size_t)i * 32 * ld + off),
-                                         (MAVLM_LDS void*)(d + i * 4096), 16, 0, 0);
-    } else {                                                  // ragged last tile: clamp the row (masked later)
+  for (int i = 0; i < 4; ++i) {
+    koff[i] = ((drow + 16 * i) * ldk + dch * 8) * 2;
+    voff[i] = ((drow + 16 * i) * ldv + dch * 8) * 2;
+  }
+  const unsigned lds_wave = (unsigned)(uintptr_t)(MAVLM_LDS char*)smem + wave * 1024;     // + slot + i * 4096
+  // piece i (0..3) of the tile at scalar byte offset `toff`: rows 16 i .. 16 i + 15.  A tile past the last one lies
+  // entirely behind the descriptor's end: issuing it writes zeros into a slot nobody reads again, so the steady-state loop
+  // needs no "is there a next tile" branch.
+  auto dma_piece = [&](__amdgpu_buffer_rsrc_t rs, const int (&off)[4], int toff, int slot_off, int i) {
+    unsigned base = lds_wave;
+    asm volatile("" : "+s"(base));            // keep M0 = base + constant a one-instruction recompute (no hoisting)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (MAVLM_LDS void*)(uintptr_t)(base + slot_off + i * 4096), 16, off[i], toff, 0, 0);
+  };
+  auto dma_tile = [&](__amdgpu_buffer_rsrc_t rs, const int (&off)[4], int ld, int t, int slot_off) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int row = t * KT3 + drow + 16 * i;
-        row = row < S ? row : S - 1;
-        const uint16_t* p = base + (size_t)row * ld + h * HD3 + dch * 8;
-        __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)p, (MAVLM_LDS void*)(d + i * 4096), 16, 0, 0);
-      }
-    }
+    for (int i = 0; i < 4; ++i) dma_piece(rs, off, t * KT3 * ld * 2, slot_off, i);
   };
   char* const kbuf = smem;                 // K slots at 0, TILE3
   char* const vbuf = smem + 2 * TILE3;     // V slots at 2*TILE3, 3*TILE3
@@ -99,6 +124,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
   int kaddr[8];                                               // K row read: + TILE3*slot + 8192*b
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) kaddr[ks] = 256 * r + 16 * ((2 * ks + hh) ^ xr);
+  unsigned kad[8];                                            // the same as 32-bit LDS addresses (inline-asm reads)
+  const unsigned kbase = (unsigned)(uintptr_t)(MAVLM_LDS const char*)kbuf;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kad[ks] = kbase + (unsigned)kaddr[ks];
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
   const int v_rd = 256 * (4 * hh + tq) + 8 * (tp & 1) + 16 * ((tp >> 1) ^ hh);
   unsigned vaddr[4][2];                                       // [db][jj]: + TILE3*slot + 256*(32b+16s)
@@ -163,9 +192,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
   };
 
   // ---- prologue: K(0), V(0), K(1) ; S(0) ; reference maximum for tile 0
-  dma_tile(K, ldk, koff, 0, kbuf);
-  dma_tile(V, ldv, voff, 0, vbuf);
-  if (nt > 1) dma_tile(K, ldk, koff, 1, kbuf + TILE3);
+  dma_tile(krs, koff, ldk, 0, 0);
+  dma_tile(vrs, voff, ldv, 0, 2 * TILE3);
+  if (nt > 1) dma_tile(krs, koff, ldk, 1, TILE3);
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));   // Q resident before the loop (see attention.hip)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -181,31 +210,61 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
     constexpr int P = decltype(par)::value;
     constexpr int N = P ^ 1;
     const bool has_next = t + 1 < nt;
-    // K(t+2) -> K slot (t&1) == P ; V(t+1) -> V slot N.  Both slots were last read before the previous barrier.
-    if (t + 2 < nt) dma_tile(K, ldk, koff, t + 2, kbuf + P * TILE3);
-    if (has_next) dma_tile(V, ldv, voff, t + 1, vbuf + N * TILE3);
+    const int ktile = (t + 2) * KT3 * ldk * 2, vtile = (t + 1) * KT3 * ldv * 2;     // scalar byte offsets of K(t+2), V(t+1)
+    // K(t+2) -> K slot (t&1) == P ; V(t+1) -> V slot N.  Both slots were last read before the previous barrier.  The
+    // eight DMA pieces are issued ONE PER TWO MFMA STEPS of phase A, not as a burst at the top: the vector-memory path of
+    // a CU takes a 1 KiB piece per ~16 clocks, and four waves issuing eight pieces each right after the barrier stalled
+    // in issue for ~1 000 clocks per tile (in-kernel stamps) before their first MFMA.
 
     const float mc = m_run * c;
     // [A] S'(t+1) = K(t+1).Q^T  ||  p = exp2(s*c - mc) for tile t (2 elements per MFMA).  The order is pinned with
     // sched_barrier(0): left alone hipcc hoists all 32 v_exp in front of the MFMA chain (no overlap at all) and sinks
-    // the fragment reads to their use; K fragments are read KPF steps ahead.
+    // the fragment reads to their use; K fragments are read KPF steps ahead (MAVLM_ATTN3_KPF).
     if (has_next) {
-      const char* kb = kbuf + N * TILE3;                      // K(t+1) sits in slot (t+1)&1 == N
+      // K(t+1) sits in slot (t+1)&1 == N.  Like the V reads of [B] the K fragment reads are inline asm with hand-counted
+      // lgkmcnt waits: left to hipcc, a read-ahead deeper than one step still ends in `s_waitcnt lgkmcnt(0)` (it drains
+      // the reads it has just issued).  These are the only LGKM operations in flight in this block (one per step), so
+      // the counts are exact: step i issues the read of step i + KPF, then waits until only the younger ones are out.
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int i = 0; i < 16; ++i) st[N][b][i] = 0.f;
-      constexpr int KPF = 1;
-      typename T::vec8 kfr[16];
-#pragma unroll
-      for (int i = 0; i < KPF; ++i) kfr[i] = *(const typename T::vec8*)(kb + kaddr[i >> 1] + 8192 * (i & 1));
+      constexpr int KPF = MAVLM_ATTN3_KPF;
+      static_assert(KPF >= 1 && KPF <= 15, "lgkmcnt is a 4-bit counter");
+      u32x4 kfr[16];
+      auto kread = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int off = N * TILE3 + 8192 * (i & 1);
+        const unsigned a = kad[i >> 1];
+        u32x4 v;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "i"(off));
+        kfr[i] = v;
+      };
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      kread(IC<0>{});
+      if constexpr (KPF > 1) kread(IC<1>{});
+      if constexpr (KPF > 2) kread(IC<2>{});
+      if constexpr (KPF > 3) kread(IC<3>{});
+      if constexpr (KPF > 4) kread(IC<4>{});
+      if constexpr (KPF > 5) kread(IC<5>{});
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (i + KPF < 16)
-          kfr[i + KPF] = *(const typename T::vec8*)(kb + kaddr[(i + KPF) >> 1] + 8192 * ((i + KPF) & 1));
-        st[N][i & 1] = T::mfma32(kfr[i], qf[i >> 1], st[N][i & 1]);
-        const int e0 = 2 * i, e1 = 2 * i + 1;                 // elements (b = e>>4, idx = e&15) of tile t
+      auto astep = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int ahead = (15 - i) < KPF ? (15 - i) : KPF;
+        if constexpr (i + KPF < 16) kread(IC<(i + KPF < 16 ? i + KPF : 15)>{});
+        if constexpr (ahead == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if constexpr (ahead == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        else if constexpr (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else if constexpr (ahead == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        else if constexpr (ahead == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else if constexpr (ahead == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        static_assert(KPF <= 6, "extend the wait table");
+        __builtin_amdgcn_sched_barrier(0);                    // keep the MFMA below the wait (rule 18)
+        st[N][i & 1] = T::mfma32(__builtin_bit_cast(typename T::vec8, kfr[i]), qf[i >> 1], st[N][i & 1]);
+        if constexpr ((i & 1) == 0 && i < 8) dma_piece(krs, koff, ktile, P * TILE3, i >> 1);
+        if constexpr ((i & 1) == 0 && i >= 8) dma_piece(vrs, voff, vtile, (2 + N) * TILE3, (i >> 1) - 4);
+        constexpr int e0 = 2 * i, e1 = 2 * i + 1;             // elements (b = e>>4, idx = e&15) of tile t
         // The two empty asm statements are ordered against sched_barrier (both have side effects); the pure
         // fma/exp between them cannot be hoisted in front of the MFMA chain or sunk behind it.
         float x0 = st[P][e0 >> 4][e0 & 15], x1 = st[P][e1 >> 4][e1 & 15];
@@ -216,7 +275,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
         st[P][e0 >> 4][e0 & 15] = x0;
         st[P][e1 >> 4][e1 & 15] = x1;
         __builtin_amdgcn_sched_barrier(0);
-      }
+      };
+      astep(IC<0>{}); astep(IC<1>{}); astep(IC<2>{}); astep(IC<3>{}); astep(IC<4>{}); astep(IC<5>{}); astep(IC<6>{});
+      astep(IC<7>{}); astep(IC<8>{}); astep(IC<9>{}); astep(IC<10>{}); astep(IC<11>{}); astep(IC<12>{});
+      astep(IC<13>{}); astep(IC<14>{}); astep(IC<15>{});
     } else {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
@@ -256,18 +318,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
         pf[bs] = __builtin_bit_cast(typename T::vec8, w);
       };
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // nothing older than the reads below is outstanding
+      constexpr int VPF = MAVLM_ATTN3_VPF;                    // read-ahead in steps (2 reads per step, lgkmcnt <= 15)
+      static_assert(VPF >= 1 && VPF <= 7, "lgkmcnt is a 4-bit counter");
       vread(IC<0>{});
+      if constexpr (VPF > 1) vread(IC<1>{});
+      if constexpr (VPF > 2) vread(IC<2>{});
+      if constexpr (VPF > 3) vread(IC<3>{});
+      if constexpr (VPF > 4) vread(IC<4>{});
+      if constexpr (VPF > 5) vread(IC<5>{});
+      if constexpr (VPF > 6) vread(IC<6>{});
       cvt(0);
       __builtin_amdgcn_sched_barrier(0);
       auto step = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int bs = i >> 2, db = i & 3;
-        if constexpr (i + 1 < 16) {
-          vread(IC<i + 1>{});
-          asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
+        // after issuing the reads of step i + VPF, the reads of steps i+1 .. min(i+VPF, 15) may stay outstanding
+        constexpr int ahead = (15 - i) < VPF ? (15 - i) : VPF;
+        if constexpr (i + VPF < 16) vread(IC<(i + VPF < 16 ? i + VPF : 15)>{});
+        if constexpr (ahead == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if constexpr (ahead == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else if constexpr (ahead == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else if constexpr (ahead == 3) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        else if constexpr (ahead == 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        else if constexpr (ahead == 5) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+        else if constexpr (ahead == 6) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);                    // keep the MFMA below the wait (rule 18)
         u32x4 both;
         both[0] = vlo[i][0]; both[1] = vlo[i][1]; both[2] = vhi[i][0]; both[3] = vhi[i][1];
@@ -415,6 +490,9 @@ size_t mavlm_attention_split_ws_floats(int R, int S, int H) {
 }
 
 hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStream_t s) {
+  // K / V are addressed through 32-bit buffer offsets (one descriptor per head): the key block must span < 4 GiB
+  // (2 GiB: the scalar offset of the tile after the last one must not wrap either)
+  if ((double)a.S * a.ldk * 2.0 >= 2147483648.0 || (double)a.S * a.ldv * 2.0 >= 2147483648.0) return hipErrorInvalidValue;
   const float c = a.scale * 1.44269504088896340736f;
   int tps = 0;
   int ns = a.split_ws != nullptr ? mavlm_attention_splits(a.R, a.S, a.H, &tps) : 1;

@@ -86,30 +86,42 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   const int m0 = (wg / ntn) * BMT;
   const int n0 = (wg % ntn) * BN2;
 
-  // ---- LDS-DMA sources: wave w stages 8-row groups g = 2w, 2w+1 of every half-tile
+  // ---- LDS-DMA sources: wave w stages 8-row groups g = 2w, 2w+1 of every half-tile.  Buffer loads
+  // (`buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds`): one descriptor per operand over the rows of this tile, a
+  // loop-invariant 32-bit lane offset per (half, instruction) and the K-tile as the scalar offset - a DMA is `s_mov m0`
+  // + the load, no 64-bit vector address arithmetic per piece.  The A descriptor ends after row M-1: rows past M read
+  // as zeros (their outputs are never stored).
   const int srow = lane >> 3, sp = lane & 7;
-  const uint16_t* gA[2][2];   // [half][inst]
-  const uint16_t* gB[2][2];
+  int oA[2][2], oB[2][2];     // [half][inst] byte offsets from the tile's first row
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int row = (wave * 2 + j) * 8 + srow;          // row inside the half-tile
       const int c = sp ^ ((row >> 1) & 7);                // logical 16-B chunk stored at physical chunk sp
-      int ar = m0 + h * MHALF + row;            // (rows >= MHALF of a slot: staged, never read)
-      ar = ar < M ? ar : M - 1;
-      gA[h][j] = A + (size_t)ar * lda + c * 8;
-      gB[h][j] = W + (size_t)(n0 + h * 128 + row) * ldw + c * 8;
+      oA[h][j] = ((h * MHALF + row) * lda + c * 8) * 2;   // (rows >= MHALF of a slot: staged, never read)
+      oB[h][j] = ((h * 128 + row) * ldw + c * 8) * 2;
     }
+  auto tile_rsrc = [&](const uint16_t* base, int row0, int rows, int ld) {
+    const uintptr_t a = (uintptr_t)(base + (size_t)row0 * ld);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const uint32_t bytes = __builtin_amdgcn_readfirstlane((uint32_t)(rows - 1) * (uint32_t)ld * 2u + (uint32_t)K * 2u);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, bytes, 0x00020000);
+  };
+  const int arows = M - m0 < BMT ? M - m0 : BMT;
+  const __amdgpu_buffer_rsrc_t rsA = tile_rsrc(A, m0, arows, lda), rsB = tile_rsrc(W, n0, BN2, ldw);
+  const unsigned lds_wave = (unsigned)(uintptr_t)(MAVLM_LDS char*)smem + wave * 2048;
   // half-tile ids: 0 = A0, 1 = A1, 2 = B0, 3 = B1
   auto dma = [&](int stage, int half_id, int kt) {
-    char* dst = smem + stage * STAGE2 + half_id * HALF + wave * 2048;
+    unsigned base = lds_wave;
+    asm volatile("" : "+s"(base));            // M0 = base + constant stays a one-instruction recompute (no SGPR hoisting)
+    const unsigned dst = base + stage * STAGE2 + half_id * HALF;
     const int h = half_id & 1;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const uint16_t* src = (half_id < 2 ? gA[h][j] : gB[h][j]) + (size_t)kt * BK2;
-      __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)src, (MAVLM_LDS void*)(dst + j * 1024), 16, 0, 0);
-    }
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(half_id < 2 ? rsA : rsB, (MAVLM_LDS void*)(uintptr_t)(dst + j * 1024), 16,
+                                               half_id < 2 ? oA[h][j] : oB[h][j], kt * BK2 * 2, 0, 0);
   };
 
   // ---- fragment read offsets
@@ -278,7 +290,10 @@ hipError_t launch256_epi(const mavlm_gemm_args& g, hipStream_t s) {
 
 }  // namespace
 
-bool mavlm_gemm256_supported(const mavlm_gemm_args& g) { return g.N % BN2 == 0 && g.K % BK2 == 0 && g.M >= 1; }
+// (operand tiles are addressed through 32-bit buffer offsets: 256 rows x leading dimension must stay below 2 GiB)
+bool mavlm_gemm256_supported(const mavlm_gemm_args& g) {
+  return g.N % BN2 == 0 && g.K % BK2 == 0 && g.M >= 1 && (double)g.lda * 512.0 < 2.0e9 && (double)g.ldw * 512.0 < 2.0e9;
+}
 
 // Height of the workgroup tile (256 or 224 rows) for an M x N output on 256 CUs at one workgroup per CU: the height
 // whose grid costs fewer row-rounds, rounds x height (ties -> 256).  Pure function of the shape; the result of the GEMM

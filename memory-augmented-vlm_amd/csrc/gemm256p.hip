@@ -111,24 +111,36 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
       for (int j = 0; j < 2; ++j) {
         const int row = (wave * 2 + j) * 8 + srow;
         const int c = sp ^ ((row >> 1) & 7);
-        int ar = m0 + h * MHALF + row;
-        ar = ar < M ? ar : M - 1;
-        offA[which][h][j] = ar * lda + c * 8;
-        offB[which][h][j] = (n0 + h * 128 + row) * ldw + c * 8;
+        // byte offsets from the operand's base (32-bit: host check); rows past M lie behind the A descriptor's end and
+        // read as zeros (never stored)
+        offA[which][h][j] = (int)(((unsigned)(m0 + h * MHALF + row) * (unsigned)lda + (unsigned)(c * 8)) * 2u);
+        offB[which][h][j] = (int)(((unsigned)(n0 + h * 128 + row) * (unsigned)ldw + (unsigned)(c * 8)) * 2u);
       }
   };
+  // Buffer loads (see gemm256_kernel): one descriptor per operand, 32-bit lane offsets, the K-tile as scalar offset
+  auto whole_rsrc = [&](const uint16_t* base, int rows, int ld) {
+    const uintptr_t a = (uintptr_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const uint32_t bytes = __builtin_amdgcn_readfirstlane((uint32_t)(rows - 1) * (uint32_t)ld * 2u + (uint32_t)K * 2u);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, bytes, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsA = whole_rsrc(A, M, lda), rsB = whole_rsrc(W, N, ldw);
+  const unsigned lds_wave = (unsigned)(uintptr_t)(MAVLM_LDS char*)smem + wave * 2048;
   // half-tile ids: 0 = A0, 1 = A1, 2 = B0, 3 = B1 ; u = virtual K-tile ; it = tile being computed
   auto dma = [&](int half_id, int u, int it) {
     const int which = u >= (it + 1) * nk;                           // wave-uniform: next tile?
     const int kt = u - (it + which) * nk;
-    char* dst = smem + (u & 1) * STAGE2 + half_id * HALF + wave * 2048;
+    unsigned base = lds_wave;
+    asm volatile("" : "+s"(base));            // M0 = base + constant: recomputed, not hoisted into scarce SGPRs
+    const unsigned dst = base + (u & 1) * STAGE2 + half_id * HALF;
     const int h = half_id & 1;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int oa = which ? offA[1][h][j] : offA[0][h][j];     // (static indices: runtime-indexed arrays go to scratch)
       const int ob = which ? offB[1][h][j] : offB[0][h][j];
-      const uint16_t* src = (half_id < 2 ? A + oa : W + ob) + (size_t)kt * BK2;
-      __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)src, (MAVLM_LDS void*)(dst + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(half_id < 2 ? rsA : rsB, (MAVLM_LDS void*)(uintptr_t)(dst + j * 1024), 16,
+                                               half_id < 2 ? oa : ob, kt * BK2 * 2, 0, 0);
     }
   };
   auto dma_bias = [&](int it, int n0) {                             // 256 floats = 64 lanes x 16 B, wave 0 only
@@ -322,7 +334,7 @@ hipError_t launch256p(const mavlm_gemm_args& g, hipStream_t s) {
 bool mavlm_gemm256p_supported(const mavlm_gemm_args& g) {
   if (g.N % BN2 != 0 || g.K % BK2 != 0 || g.K < 2 * BK2 || g.M < 1) return false;
   if (g.epilogue == MAVLM_EPI_RES_F32) return false;
-  if ((double)g.M * g.lda >= 2.0e9 || (double)g.N * g.ldw >= 2.0e9) return false;
+  if ((double)(g.M + 256) * g.lda * 2.0 >= 4.0e9 || (double)g.N * g.ldw * 2.0 >= 4.0e9) return false;   // 32-bit byte offsets
   return true;
 }
 

@@ -305,7 +305,9 @@ def g5_g6():
 # --------------------------------------------------------------------------- G7
 def g7():
     res = {}
-    for tag, M, F, steps in (("m8f32", 8, 32, 3), ("m64f8", 64, 8, 1)):
+    # m64f32 = the exact bench.py workload (BASELINE.json configs[1]): M = 64, two 32-frame chunks (formation, then
+    # evolution over the FIFO + formation)
+    for tag, M, F, steps in (("m8f32", 8, 32, 3), ("m64f8", 64, 8, 1), ("m64f32", 64, 32, 2)):
         cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=M, depth=2)
         w = O.make_weights(cfg, seed=71)
         m = ref_projector(cfg, w)
