@@ -526,28 +526,41 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// attn_colsum3_kernel: column sums of the normalised probabilities (frame scores, MemoryController.py:135-139),
-// software-pipelined like attn_fwd3_kernel.  A wave keeps 32 keys in registers (A operand) and streams the queries:
-// 64-query Q tiles and their 64 lse2 values arrive by LDS-DMA into a 2-slot ring; S^T(qb) for the next 32-query
-// block is computed (8 MFMAs) while exp2(s*c - lse2) of the previous block is accumulated per key in registers.
+// attn_colsum3_kernel: column sums of the normalised probabilities (frame scores, MemoryController.py:135-139).
+// A wave keeps 32 keys in registers (A operand) and streams the queries: 64-query Q tiles and their 64 lse2 values arrive
+// by LDS-DMA into a 2-slot ring; S^T(qb) for the next 32-query block is computed (8 MFMAs) while exp2(s*c - lse2) of the
+// previous block is accumulated per key in registers.
+//   * Q fragments are read from LDS QPF steps ahead of their MFMA with hand-counted lgkmcnt waits (inline asm: the ISA of
+//     the plain-C++ form waited `lgkmcnt(0)` for every fragment right after issuing its read).
+//   * The DMAs are buffer loads (descriptor + 32-bit lane offset + scalar tile offset) issued between MFMA steps, not as
+//     a burst (see attn_fwd3_kernel).
+//   * The QUERY range is split over blockIdx (2 halves) when (key blocks x heads) alone would leave most of the chip's
+//     workgroup slots empty (392 workgroups at S = 6272 against 1024 slots): both halves add into `part`, zeroed by the
+//     launcher.  Two addends per element: the float sum does not depend on their order, so the result is deterministic.
 namespace {
 
 constexpr int CS3_LSE = 2 * TILE3;             // 2 x 256 B of lse2 behind the two Q slots
 constexpr int CS3_LDS = 2 * TILE3 + 512;
+constexpr int CS3_QPF = 2;                     // LDS read-ahead of the Q fragments, in MFMA steps (4 VGPRs each; the
+                                               // kernel must stay within 128 VGPRs for four workgroups per CU)
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void attn_colsum3_kernel(const uint16_t* __restrict__ Q, int ldq,
+__global__ __launch_bounds__(256, 4) void attn_colsum3_kernel(const uint16_t* __restrict__ Q, int ldq,
                                                               const uint16_t* __restrict__ K, int ldk,
                                                               const float* __restrict__ lse2, float* __restrict__ part,
-                                                              int R, int S, int H, float c) {
+                                                              int R, int S, int H, float c, int nkb, int tps, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.x % H;
-  const int k0 = (blockIdx.x / H) * 128 + wave * 32;
+  const int kb = (blockIdx.x / H) % nkb;
+  const int qsp = blockIdx.x / (H * nkb);                       // query split
+  const int k0 = kb * 128 + wave * 32;
   const int r = lane & 31, hh = lane >> 5;
-  const int nt = (R + KT3 - 1) / KT3;
+  const int ntq = (R + KT3 - 1) / KT3;
+  const int tq0 = qsp * tps;                                    // first query tile of this workgroup
+  const int nt = (ntq - tq0 < tps) ? ntq - tq0 : tps;           // >= 1 (launcher)
 
   typename T::vec8 kf[8];
   {
@@ -558,76 +571,100 @@ __global__ __launch_bounds__(256, 2) void attn_colsum3_kernel(const uint16_t* __
     for (int ks = 0; ks < 8; ++ks) kf[ks] = *(const typename T::vec8*)(kp + 16 * ks);
   }
 
-  // Q tile DMA: same geometry as dma_tile of attn_fwd3_kernel
+  // Q tile / lse2 DMA: same LDS image as the K tiles of attn_fwd3_kernel; rows past R read as zeros (masked below)
+  auto rsrc_of = [&](const void* base, uint32_t bytes) {
+    const uintptr_t a = (uintptr_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes),
+                                             0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t qrs = rsrc_of(Q + h * HD3, (uint32_t)(R - 1) * (uint32_t)ldq * 2u + (uint32_t)HD3 * 2u);
+  const __amdgpu_buffer_rsrc_t lrs = rsrc_of(lse2 + (size_t)h * R, (uint32_t)R * 4u);
   const int drow = 4 * wave + (lane >> 4);
   const int dch = (lane & 15) ^ (((lane >> 4) << 2) | wave);
-  const int qoff = drow * ldq + h * HD3 + dch * 8;
-  const float* lrow = lse2 + (size_t)h * R;
+  const int qo = (drow * ldq + dch * 8) * 2;                   // lane offset; tile and piece go into the scalar offset
+  const unsigned lds0 = (unsigned)(uintptr_t)(MAVLM_LDS char*)smem;   // (this kernel is short of VGPRs, not of SGPRs)
+  auto dma_piece = [&](int t, int slot_off, int i) {            // t: tile index inside this workgroup's range
+    unsigned base = lds0 + wave * 1024;
+    asm volatile("" : "+s"(base));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (MAVLM_LDS void*)(uintptr_t)(base + slot_off + i * 4096), 16, qo,
+                                             ((tq0 + t) * KT3 + 16 * i) * ldq * 2, 0, 0);
+  };
+  auto dma_lse = [&](int t, int slot) {                         // 64 lse2 values of the tile: 4 bytes per lane, wave 0
+    if (wave == 0) {
+      unsigned base = lds0;
+      asm volatile("" : "+s"(base));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, (MAVLM_LDS void*)(uintptr_t)(base + CS3_LSE + slot * 256), 4, lane * 4,
+                                               (tq0 + t) * KT3 * 4, 0, 0);
+    }
+  };
   auto dma_q = [&](int t, int slot) {
-    char* d = smem + slot * TILE3 + wave * 1024;
-    if ((t + 1) * KT3 <= R) {
-      const uint16_t* b = Q + (size_t)t * KT3 * ldq;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)(b + (size_t)i * 16 * ldq + qoff),
-                                         (MAVLM_LDS void*)(d + i * 4096), 16, 0, 0);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int row = t * KT3 + drow + 16 * i;
-        row = row < R ? row : R - 1;
-        const uint16_t* p = Q + (size_t)row * ldq + h * HD3 + dch * 8;
-        __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)p, (MAVLM_LDS void*)(d + i * 4096), 16, 0, 0);
-      }
-    }
-    if (wave == 0) {                                           // 64 lse2 values of the tile: one 4-byte DMA per lane
-      int qi = t * KT3 + lane;
-      qi = qi < R ? qi : R - 1;
-      __builtin_amdgcn_global_load_lds((const MAVLM_GLOBAL void*)(lrow + qi), (MAVLM_LDS void*)(smem + CS3_LSE + slot * 256),
-                                       4, 0, 0);
-    }
+    for (int i = 0; i < 4; ++i) dma_piece(t, slot * TILE3, i);
+    dma_lse(t, slot);
   };
 
   const int xr = img3_x(r);
-  int qaddr[8];
+  unsigned qad[8];                                              // LDS byte address of fragment ks: + slot + block
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) qaddr[ks] = 256 * r + 16 * ((2 * ks + hh) ^ xr);
+  for (int ks = 0; ks < 8; ++ks) qad[ks] = lds0 + 256 * r + 16 * ((2 * ks + hh) ^ xr);
 
   float acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   f32x16 st[2];
 
-  auto qk = [&](auto pc, const char* qb) {                      // st[P] = K . Q(block)^T, 8 MFMAs
-    constexpr int P = decltype(pc)::value;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) st[P][i] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const typename T::vec8 qf = *(const typename T::vec8*)(qb + qaddr[ks]);
-      st[P] = T::mfma32(kf[ks], qf, st[P]);
-    }
-  };
-  // st[P] of block (t, qb) -> acc, while st[P^1] of the following block is being produced
-  auto qk_overlap = [&](auto pc, const char* qb_next, float l2, bool ok) {
-    constexpr int P = decltype(pc)::value;
-    constexpr int N = P ^ 1;
+  // One phase = the 8 MFMAs of S^T for the 32-query block at LDS offset OFF into st[P^1], with the exp2 / accumulate of the
+  // block in st[P] (2 elements per MFMA) in their shadow.  DSLOT >= 0: the five DMAs of tile `tdma` into slot DSLOT are
+  // issued after MFMA steps 0, 2, 4, 6 (Q pieces) and 1 (lse2).  FIRST: no previous block to accumulate.
+  auto phase = [&](auto pc, auto offc, auto dslotc, auto firstc, float l2, bool ok, int tdma) {
+    constexpr int P = decltype(pc)::value, N = P ^ 1, OFF = decltype(offc)::value, DSLOT = decltype(dslotc)::value;
+    constexpr bool FIRST = decltype(firstc)::value != 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) st[N][i] = 0.f;
     const float l2m = ok ? l2 : INFINITY;                       // masked query: exp2(-inf) = 0
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const typename T::vec8 qf = *(const typename T::vec8*)(qb_next + qaddr[ks]);
-      st[N] = T::mfma32(kf[ks], qf, st[N]);
-      float x0 = st[P][2 * ks], x1 = st[P][2 * ks + 1];
-      asm volatile("" : "+v"(x0), "+v"(x1));
-      x0 = __builtin_amdgcn_exp2f(x0 * c - l2m);
-      x1 = __builtin_amdgcn_exp2f(x1 * c - l2m);
-      asm volatile("" : "+v"(x0), "+v"(x1));
-      acc[2 * ks] += x0;
-      acc[2 * ks + 1] += x1;
+    u32x4 qf[8];
+    auto rd = [&](auto ic) {
+      constexpr int ks = decltype(ic)::value;
+      const unsigned a = qad[ks];
+      u32x4 v;
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "i"(OFF));
+      qf[ks] = v;
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    rd(IC<0>{});
+    if constexpr (CS3_QPF > 1) rd(IC<1>{});
+    if constexpr (CS3_QPF > 2) rd(IC<2>{});
+    static_assert(CS3_QPF >= 1 && CS3_QPF <= 3, "read-ahead prologue / wait table are written for 1..3");
+    __builtin_amdgcn_sched_barrier(0);
+    auto step = [&](auto ic) {
+      constexpr int ks = decltype(ic)::value;
+      constexpr int ahead = (7 - ks) < CS3_QPF ? (7 - ks) : CS3_QPF;
+      if constexpr (ks + CS3_QPF < 8) rd(IC<(ks + CS3_QPF < 8 ? ks + CS3_QPF : 7)>{});
+      if constexpr (ahead == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else if constexpr (ahead == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+      else if constexpr (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-    }
+      st[N] = T::mfma32(kf[ks], __builtin_bit_cast(typename T::vec8, qf[ks]), st[N]);
+      if constexpr (DSLOT >= 0) {
+        if constexpr ((ks & 1) == 0) dma_piece(tdma, DSLOT * TILE3, ks >> 1);
+        if constexpr (ks == 1) dma_lse(tdma, DSLOT);
+      }
+      if constexpr (!FIRST) {
+        float x0 = st[P][2 * ks], x1 = st[P][2 * ks + 1];
+        asm volatile("" : "+v"(x0), "+v"(x1));
+        x0 = __builtin_amdgcn_exp2f(x0 * c - l2m);
+        x1 = __builtin_amdgcn_exp2f(x1 * c - l2m);
+        asm volatile("" : "+v"(x0), "+v"(x1));
+        acc[2 * ks] += x0;
+        acc[2 * ks + 1] += x1;
+        asm volatile("" : "+v"(acc[2 * ks]), "+v"(acc[2 * ks + 1]));   // add here (else 16 exp results stay live to the end)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{}); step(IC<4>{}); step(IC<5>{}); step(IC<6>{}); step(IC<7>{});
   };
   auto drain = [&](auto pc, float l2, bool ok) {                // last block: no MFMAs to hide behind
     constexpr int P = decltype(pc)::value;
@@ -645,16 +682,19 @@ __global__ __launch_bounds__(256, 2) void attn_colsum3_kernel(const uint16_t* __
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  qk(IC<0>{}, smem + 0);                                       // block (0, 0)
+  phase(IC<1>{}, IC<0>{}, IC<-1>{}, IC<1>{}, 0.f, false, 0);    // block (0, 0) -> st[0]
 
-  for (int t = 0; t < nt; ++t) {
-    const int slot = t & 1;
-    const char* qs = smem + slot * TILE3;
-    const float* ls = (const float*)(smem + CS3_LSE + slot * 256);
-    const float l0 = ls[r], l1 = ls[32 + r];
-    const bool ok0 = t * KT3 + r < R, ok1 = t * KT3 + 32 + r < R;
+  // tile t (index inside this workgroup's query range) in slot SLOT; its block 0 already sits in st[0]
+  auto tile = [&](auto slotc, int t) {
+    constexpr int SLOT = decltype(slotc)::value;
+    const float* ls = (const float*)(smem + CS3_LSE + SLOT * 256);
+    float l0 = ls[r], l1 = ls[32 + r];
+    // no LDS read of this wave may be in flight when the hand-counted reads of the phases start
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l0), "+v"(l1)::"memory");
+    const int q0 = (tq0 + t) * KT3 + r;
+    const bool ok0 = q0 < R, ok1 = q0 + 32 < R;
     // block (t,0) accumulated under the MFMAs of block (t,1)
-    qk_overlap(IC<0>{}, qs + 8192, l0, ok0);
+    phase(IC<0>{}, IC<SLOT * TILE3 + 8192>{}, IC<-1>{}, IC<0>{}, l0, ok0, 0);
     if (t + 1 < nt) {
       // tile t+1 must be visible before its block 0 is read: this wave's DMAs + barrier
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -662,13 +702,20 @@ __global__ __launch_bounds__(256, 2) void attn_colsum3_kernel(const uint16_t* __
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       // every wave has passed the barrier, i.e. finished reading tile t (its block 1 fed the MFMAs above, its lse2
-      // values are in registers): the slot can be refilled while block (t,1) is accumulated
-      if (t + 2 < nt) dma_q(t + 2, slot);
-      qk_overlap(IC<1>{}, smem + (slot ^ 1) * TILE3, l1, ok1);   // block (t,1) under the MFMAs of block (t+1,0)
+      // values are in registers): the slot is refilled (tile t+2) while block (t,1) is accumulated under the MFMAs of
+      // block (t+1,0).  No DMA is issued that the loop would not wait for (a wave must not end with one in flight).
+      if (t + 2 < nt) phase(IC<1>{}, IC<(SLOT ^ 1) * TILE3>{}, IC<SLOT>{}, IC<0>{}, l1, ok1, t + 2);
+      else phase(IC<1>{}, IC<(SLOT ^ 1) * TILE3>{}, IC<-1>{}, IC<0>{}, l1, ok1, 0);
     } else {
       drain(IC<1>{}, l1, ok1);
     }
+  };
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    tile(IC<0>{}, t);
+    tile(IC<1>{}, t + 1);
   }
+  if (t < nt) tile(IC<0>{}, t);
 
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -681,21 +728,40 @@ __global__ __launch_bounds__(256, 2) void attn_colsum3_kernel(const uint16_t* __
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-      if (key < S) part[(size_t)h * S + key] = acc[i];
+      if (key < S) {
+        if (nsplit > 1) atomicAdd(part + (size_t)h * S + key, acc[i]);
+        else part[(size_t)h * S + key] = acc[i];
+      }
     }
   }
 }
 
 }  // namespace
 
+// Query-split plan of the column-sum pass (pure function of the shape): 2 halves when key blocks x heads would fill less
+// than ~60 % of the 1024 workgroup slots (4 per CU), else 1.  At most two addends per output element -> deterministic.
+int mavlm_colsum_splits(int R, int S, int H) {
+  const int nkb = (S + 127) / 128, ntq = (R + KT3 - 1) / KT3;
+  return (nkb * H < 600 && ntq >= 8) ? 2 : 1;
+}
+
 hipError_t mavlm_launch_colsum3(const mavlm_colsum_args& a, int dtype, hipStream_t s) {
+  if ((double)a.R * a.ldq * 2.0 >= 2147483648.0) return hipErrorInvalidValue;      // 32-bit buffer offsets
   const float c = a.scale * 1.44269504088896340736f;
-  dim3 grid(((a.S + 127) / 128) * a.H);
+  const int nkb = (a.S + 127) / 128, ntq = (a.R + KT3 - 1) / KT3;
+  const int ns = mavlm_colsum_splits(a.R, a.S, a.H);
+  const int tps = (ntq + ns - 1) / ns;
+  const int nsplit = (ntq + tps - 1) / tps;
+  if (nsplit > 1) {
+    hipError_t e = hipMemsetAsync(a.part, 0, (size_t)a.H * a.S * sizeof(float), s);
+    if (e != hipSuccess) return e;
+  }
+  dim3 grid(nkb * a.H * nsplit);
   if (dtype == MAVLM_F16)
     hipLaunchKernelGGL(attn_colsum3_kernel<F16>, grid, dim3(256), CS3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
-                       a.ldk, a.lse2, a.part, a.R, a.S, a.H, c);
+                       a.ldk, a.lse2, a.part, a.R, a.S, a.H, c, nkb, tps, nsplit);
   else
     hipLaunchKernelGGL(attn_colsum3_kernel<BF16>, grid, dim3(256), CS3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
-                       a.ldk, a.lse2, a.part, a.R, a.S, a.H, c);
+                       a.ldk, a.lse2, a.part, a.R, a.S, a.H, c, nkb, tps, nsplit);
   return hipGetLastError();
 }
