@@ -412,7 +412,7 @@ def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mo
     lse2 = np.empty((heads, R), dtype=F32)
     colsum = np.zeros((heads, Lk), dtype=np.float64) if want_colsum else None
     probs = np.empty((heads, R, Lk), dtype=F32) if want_probs else None
-    lazy = mode != "fp32" and not want_probs and R * Lk > (1 << 24)
+    lazy = mode != "fp32" and not want_probs and R * Lk > (1 << 27)     # (eager is faster while [R, Lk] fits comfortably)
     for h in range(heads):
         sl = slice(h * d, (h + 1) * d)
         if lazy:

@@ -126,7 +126,7 @@ def test_g6_glue_end_to_end():
         assert O.rel_l2(parts["frame_scores"][-1], z[f"scores_{F0}"][0]) < TOL
 
 
-@pytest.mark.parametrize("tag,M,F,steps", [("m8f32", 8, 32, 3), ("m64f8", 64, 8, 1)])
+@pytest.mark.parametrize("tag,M,F,steps", [("m8f32", 8, 32, 3), ("m64f8", 64, 8, 1), ("m64f32", 64, 32, 2)])
 def test_g7_fullsize_samples(tag, M, F, steps):
     z, m = load_golden("g7_fullsize.npz")
     cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=M, depth=2)
