@@ -245,6 +245,10 @@ int mavlm_set_gemm_rows(int32_t rows);
 /* tuning hook: attention forward kernel - 2 = register-staged (attention.hip), 3 = software-pipelined LDS-DMA
  * (attention3.hip), 0 = default (3).  Same rounding points; results equal up to fp32 summation order. */
 int mavlm_set_attention_impl(int32_t impl);
+/* tuning / test hook: the head_dim-128 forward switches to its stream-K schedule (persistent workgroups over equal ranges of
+ * the global key-tile sequence) when there are more units than workgroup slots AND at least this many 64-key
+ * tiles per unit (default 128).  The schedule is part of the result (fp32 summation order): set it before sizing workspaces. */
+int mavlm_set_attention_streamk_min_tiles(int32_t tiles);
 
 /* --- measurement hooks (bench.py only; new - the reference has no profiling) ------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on its own stream.  Kinds: 0 GEMM, 1 attention

@@ -38,31 +38,70 @@ __device__ __forceinline__ int img3_x(int row) { return ((row & 3) << 2) | ((row
 template <int V>
 struct IC { static constexpr int value = V; };
 
+// A workgroup runs one or more SEGMENTS.  A segment = one unit (head h, 128-query block) x a contiguous range of its key
+// tiles, computed with a fresh online-softmax state; a segment that covers all key tiles of its unit writes O / lse2, any
+// other writes a NORMALISED fp32 partial + its log-sum-exp for a merge kernel.  Three schedules (sk_wgs / tps):
+//   * plain (tps == 0, sk_wgs == 0): grid = units, one whole-unit segment per workgroup.
+//   * split-KV (tps > 0; small grids): blockIdx.y owns the key tiles [y*tps, (y+1)*tps); attn_combine_kernel merges.
+//   * stream-K (sk_wgs > 0; more units than the chip has workgroup slots): sk_wgs persistent workgroups, workgroup v owns
+//     the global tile range [v*TT/G, (v+1)*TT/G) of the head-major tile order (TT = units x tiles per unit), i.e. the tail
+//     of one unit, whole units, and the head of another.  784 units on 512 slots take two rounds (the second at 53 %
+//     occupancy) as a plain grid; as 512 equal tile ranges they take 1.53.  At most ONE range boundary falls inside a unit
+//     (the launcher uses this schedule only when units >= workgroups), so a unit has at most two partials:
+//     attn_combine_sk_kernel merges them.  Static schedule, no atomics, no queue: deterministic, and the oracle mirrors it.
 template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __restrict__ Q, int ldq,
-                                                           const uint16_t* __restrict__ K, int ldk,
-                                                           const uint16_t* __restrict__ V, int ldv,
+                                                           const uint16_t* __restrict__ Kall, int ldk,
+                                                           const uint16_t* __restrict__ Vall, int ldv,
                                                            uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
-                                                           int R, int S, int H, float c, float* __restrict__ Opart,
-                                                           float* __restrict__ lse_part, int tps) {
+                                                           int R, int S_all, int H, float c, float* __restrict__ Opart,
+                                                           float* __restrict__ lse_part, int tps, int sk_wgs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // split-KV (small grids, tps > 0): blockIdx.y owns the keys [y*tps*64, (y+1)*tps*64) and writes a NORMALISED fp32
-  // partial + its log-sum-exp; attn_combine_kernel merges the splits.  The body below is unchanged: only the K/V
-  // base and the key count move.
-  const int split = blockIdx.y;
-  if (tps > 0) {
-    const int k0 = split * tps * KT3;
-    K += (size_t)k0 * ldk;
-    V += (size_t)k0 * ldv;
-    S = (S - k0 < tps * KT3) ? S - k0 : tps * KT3;
-  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = blockIdx.x % H;                               // one head per XCD L2 when H == 8
-  const int q0 = (blockIdx.x / H) * 128 + wave * 32;
   const int r = lane & 31, hh = lane >> 5;
-  const int nt = (S + KT3 - 1) / KT3;
+  const int nt_all = (S_all + KT3 - 1) / KT3;
+  const int nqb = (R + 127) / 128;
+
+  // ---- schedule
+  long long sk_pos = 0, sk_end = 0;                           // stream-K: global tile range of this workgroup
+  int sk_v = 0;
+  if (sk_wgs > 0) {
+    sk_v = xcd_remap((int)blockIdx.x, sk_wgs);                // XCD x owns a contiguous range of the head-major order:
+    const long long TT = (long long)nqb * H * nt_all;         // its L2 holds the K / V of ~H/8 heads
+    sk_pos = TT * sk_v / sk_wgs;
+    sk_end = TT * (sk_v + 1) / sk_wgs;
+  }
+  bool more_segments = true;
+  while (more_segments) {
+  // ---- this segment: unit (h, q-block), key tiles [t_lo, t_lo + nt)
+  int h, qblk, t_lo, nt, out_kind, split = 0;                 // out_kind 0: O/lse2, 1: split-KV partial, 2: stream-K partial
+  int sk_slot = 0;
+  if (sk_wgs > 0) {
+    const int u = (int)(sk_pos / nt_all);
+    t_lo = (int)(sk_pos - (long long)u * nt_all);
+    const long long left = sk_end - sk_pos;
+    nt = (nt_all - t_lo < left) ? nt_all - t_lo : (int)left;
+    h = u / nqb;
+    qblk = u - h * nqb;
+    out_kind = (nt == nt_all) ? 0 : 2;
+    sk_slot = 2 * sk_v + (t_lo > 0 ? 0 : 1);                  // tail of a unit = first segment, head = last segment
+    sk_pos += nt;
+    more_segments = sk_pos < sk_end;
+  } else {
+    h = blockIdx.x % H;                                       // one head per XCD L2 when H == 8
+    qblk = blockIdx.x / H;
+    split = blockIdx.y;
+    t_lo = tps > 0 ? split * tps : 0;
+    nt = tps > 0 ? ((nt_all - t_lo < tps) ? nt_all - t_lo : tps) : nt_all;
+    out_kind = tps > 0 ? 1 : 0;
+    more_segments = false;
+  }
+  const uint16_t* K = Kall + (size_t)t_lo * KT3 * ldk;
+  const uint16_t* V = Vall + (size_t)t_lo * KT3 * ldv;
+  const int S = (S_all - t_lo * KT3 < nt * KT3) ? S_all - t_lo * KT3 : nt * KT3;      // keys of this segment
+  const int q0 = qblk * 128 + wave * 32;
 
   // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0+r][h*128 + 16ks + 8hh + 0..7]
   typename T::vec8 qf[8];
@@ -392,8 +431,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
   const float l_tot = xhalf_sum(l_run);
   const float inv = 1.0f / l_tot;
   const int q = q0 + r;
-  if (q < R) {
-    if (tps > 0) {
+  if (out_kind == 2) {                                        // stream-K partial: [slot][128 rows][128] + [slot][128]
+    float* pp = Opart + ((size_t)sk_slot * 128 + wave * 32 + r) * HD3 + 4 * hh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(f32x4*)(pp + 32 * db + 8 * g) = f32x4{ot[db][4 * g] * inv, ot[db][4 * g + 1] * inv, ot[db][4 * g + 2] * inv,
+                                                ot[db][4 * g + 3] * inv};
+    if (hh == 0) lse_part[(size_t)sk_slot * 128 + wave * 32 + r] = m_run * c + log2f(l_tot);
+  } else if (q < R) {
+    if (out_kind == 1) {
       float* pp = Opart + ((size_t)split * R + q) * (H * HD3) + h * HD3 + 4 * hh;
 #pragma unroll
       for (int db = 0; db < 4; ++db)
@@ -413,6 +461,41 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
       if (lse2 != nullptr && hh == 0) lse2[(size_t)h * R + q] = m_run * c + log2f(l_tot);
     }
   }
+  }   // segment loop (every tile iteration ends with a barrier: the LDS slots are free for the next segment's prologue)
+}
+
+// Stream-K merge: boundary g (1 .. G-1) of the global tile order cuts unit u = (g*TT/G) / nt_all at tile a = (g*TT/G) %
+// nt_all; a == 0: the boundary coincides with a unit boundary, nothing to do.  Otherwise the unit's head [0, a) is slot
+// 2(g-1)+1 (last segment of workgroup g-1) and its tail [a, nt_all) is slot 2g (first segment of workgroup g):
+// O = w0 O0 + w1 O1, w = 2^(lse_i - lse), head first.  One workgroup per boundary, 2 threads per query row.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_combine_sk_kernel(const float* __restrict__ Opart, const float* __restrict__ lse_part,
+                                                              uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
+                                                              int R, int H, int nt_all, int G) {
+  const int g = blockIdx.x + 1;
+  const int nqb = (R + 127) / 128;
+  const long long TT = (long long)nqb * H * nt_all;
+  const long long bpos = TT * g / G;
+  const int u = (int)(bpos / nt_all);
+  if (bpos - (long long)u * nt_all == 0) return;
+  const int h = u / nqb, qblk = u - h * nqb;
+  const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+  const int q = qblk * 128 + row;
+  if (q >= R) return;
+  const size_t s0 = (size_t)(2 * (g - 1) + 1), s1 = (size_t)(2 * g);
+  const float l0 = lse_part[s0 * 128 + row], l1 = lse_part[s1 * 128 + row];
+  const float mx = fmaxf(l0, l1);
+  const float lse = mx + log2f(__builtin_amdgcn_exp2f(l0 - mx) + __builtin_amdgcn_exp2f(l1 - mx));
+  const float w0 = __builtin_amdgcn_exp2f(l0 - lse), w1 = __builtin_amdgcn_exp2f(l1 - lse);
+  const float* p0 = Opart + (s0 * 128 + row) * HD3 + half * 64;
+  const float* p1 = Opart + (s1 * 128 + row) * HD3 + half * 64;
+  uint16_t* op = O + (size_t)q * ldo + h * HD3 + half * 64;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    const f32x4 a = *(const f32x4*)(p0 + 4 * v), b = *(const f32x4*)(p1 + 4 * v);
+    *(u32x2*)(op + 4 * v) = pack4<T>(w0 * a[0] + w1 * b[0], w0 * a[1] + w1 * b[1], w0 * a[2] + w1 * b[2], w0 * a[3] + w1 * b[3]);
+  }
+  if (lse2 != nullptr && half == 0) lse2[(size_t)h * R + q] = lse;
 }
 
 // O[q, h*128+d] = sum_s w_s Opart[s][q][h*128+d], w_s = 2^(lse_s - lse), lse = log2 sum_s 2^lse_s.  One wave per query
@@ -484,7 +567,28 @@ int mavlm_attention_splits(int R, int S, int H, int* tiles_per_split) {
   return ns;
 }
 
+// Stream-K plan: number of persistent workgroups (0 = not used).  Used when the units (128-query blocks x heads) exceed the
+// ATTN3_SK_WGS workgroup slots of the chip (256 CUs x 2) and a plain grid would leave more than 5 % of its last round
+// empty.  units >= workgroups guarantees at most one range boundary inside a unit (two partials).  Pure function of the
+// shape (mirrored by oracle/memory_path.py::streamk_plan).
+constexpr int ATTN3_SK_WGS = 512;
+int g_mavlm_attn_sk_min_tiles = 128;          // tuning / test hook (mavlm_set_attention_streamk_min_tiles)
+#define ATTN3_SK_MIN_TILES g_mavlm_attn_sk_min_tiles
+int mavlm_attention_streamk_wgs(int R, int S, int H) {
+  const long units = (long)((R + 127) / 128) * H;
+  if (units <= ATTN3_SK_WGS) return 0;
+  // The schedule costs a second prologue per workgroup, 64 KiB of fp32 partial per cut and the merge kernel (~25 us at the
+  // bench shape), and the plain grid's under-filled last round already runs ~1.6x faster per workgroup (one per CU):
+  // measured on one device at 784 units, 98 key tiles (S = 6272) 351 -> 363 us, 196 tiles (S = 12 544) 678 -> 640 us.
+  // Worth it from ~128 tiles per unit: the evolution attention over the FIFO (S = n x R keys).
+  if ((S + KT3 - 1) / KT3 < ATTN3_SK_MIN_TILES) return 0;
+  const long rounds = (units + ATTN3_SK_WGS - 1) / ATTN3_SK_WGS;
+  return (double)units / (double)(rounds * ATTN3_SK_WGS) < 0.95 ? ATTN3_SK_WGS : 0;
+}
+
 size_t mavlm_attention_split_ws_floats(int R, int S, int H) {
+  const int g = mavlm_attention_streamk_wgs(R, S, H);
+  if (g > 0) return (size_t)g * 2 * (128 * HD3 + 128);
   const int ns = mavlm_attention_splits(R, S, H, nullptr);
   return ns > 1 ? (size_t)ns * R * H * HD3 + (size_t)ns * H * R : 0;
 }
@@ -494,12 +598,19 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
   // (2 GiB: the scalar offset of the tile after the last one must not wrap either)
   if ((double)a.S * a.ldk * 2.0 >= 2147483648.0 || (double)a.S * a.ldv * 2.0 >= 2147483648.0) return hipErrorInvalidValue;
   const float c = a.scale * 1.44269504088896340736f;
-  int tps = 0;
-  int ns = a.split_ws != nullptr ? mavlm_attention_splits(a.R, a.S, a.H, &tps) : 1;
+  int tps = 0, ns = 1, skg = 0;
+  if (a.split_ws != nullptr) {
+    skg = mavlm_attention_streamk_wgs(a.R, a.S, a.H);
+    if (skg == 0) ns = mavlm_attention_splits(a.R, a.S, a.H, &tps);
+  }
   if (ns <= 1) { ns = 1; tps = 0; }
   float* opart = a.split_ws;
-  float* lpart = ns > 1 ? a.split_ws + (size_t)ns * a.R * a.H * HD3 : nullptr;
-  dim3 grid(((a.R + 127) / 128) * a.H, ns);
+  float* lpart = nullptr;
+  if (skg > 0) lpart = a.split_ws + (size_t)skg * 2 * 128 * HD3;
+  else if (ns > 1) lpart = a.split_ws + (size_t)ns * a.R * a.H * HD3;
+  const int units = ((a.R + 127) / 128) * a.H;
+  const dim3 grid(skg > 0 ? skg : units, skg > 0 ? 1 : ns);
+  const int nt_all = (a.S + KT3 - 1) / KT3;
   static mavlm_per_device_once once[2];
   if (dtype == MAVLM_F16) {
     {
@@ -507,8 +618,11 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(attn_fwd3_kernel<F16>, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
-                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps);
-    if (ns > 1)
+                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps, skg);
+    if (skg > 0)
+      hipLaunchKernelGGL(attn_combine_sk_kernel<F16>, dim3(skg - 1), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo, a.lse2,
+                         a.R, a.H, nt_all, skg);
+    else if (ns > 1)
       hipLaunchKernelGGL(attn_combine_kernel<F16>, dim3((a.R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
                          a.lse2, a.R, a.H, HD3, ns);
   } else {
@@ -517,8 +631,11 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(attn_fwd3_kernel<BF16>, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
-                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps);
-    if (ns > 1)
+                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps, skg);
+    if (skg > 0)
+      hipLaunchKernelGGL(attn_combine_sk_kernel<BF16>, dim3(skg - 1), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo, a.lse2,
+                         a.R, a.H, nt_all, skg);
+    else if (ns > 1)
       hipLaunchKernelGGL(attn_combine_kernel<BF16>, dim3((a.R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
                          a.lse2, a.R, a.H, HD3, ns);
   }

@@ -77,7 +77,14 @@ void carve(mavlm_ctx* x) {
     size_t cap;
     if (!wide_heads(c)) cap = items < 320 ? (512 / items > 8 ? 8 : 512 / items) : 0;      // mavlm_attention_splits
     else cap = items < 200 ? (400 / items > 8 ? 8 : 400 / items) : 0;                      // mavlm_attention_hd_splits
-    if (cap >= 2) o += al(cap * (R * Dp + H * R) * 4);
+    size_t fl = cap >= 2 ? cap * (R * Dp + H * R) : 0;
+    // stream-K partials of the head_dim-128 forward (more units than workgroup slots): independent of the key count
+    if (!wide_heads(c)) {
+      const int s_long = 1 << 20;        // (the schedule only depends on "enough key tiles")
+      const size_t sk = mavlm_attention_split_ws_floats((int)R, s_long, (int)H);
+      if (mavlm_attention_streamk_wgs((int)R, s_long, (int)H) > 0 && sk > fl) fl = sk;
+    }
+    if (fl) o += al(fl * 4);
   }
   // split-K planes of the GEMMs with few output tiles and a long contraction (mavlm_gemm_splits): the I -> D
   // projections (MLP down, fuser second layer) at small R
@@ -166,6 +173,13 @@ int mavlm_set_attention_bwd_fused(int32_t on) {
 int mavlm_set_gemm_tile(int32_t tile) {
   if (tile != 0 && tile != 128 && tile != 256 && tile != 257) return MAVLM_E_ARG;
   g_mavlm_gemm_tile = tile;
+  return 0;
+}
+
+extern int g_mavlm_attn_sk_min_tiles;
+int mavlm_set_attention_streamk_min_tiles(int32_t tiles) {
+  if (tiles < 1) return MAVLM_E_ARG;
+  g_mavlm_attn_sk_min_tiles = tiles;
   return 0;
 }
 

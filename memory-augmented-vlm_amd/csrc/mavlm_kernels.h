@@ -48,6 +48,8 @@ struct mavlm_attn_args {
 hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream_t s);
 // split-KV plan for grids too small to fill the chip (attention3.hip): number of key splits (1 = none)
 int mavlm_attention_splits(int R, int S, int H, int* tiles_per_split);
+// stream-K schedule of the head_dim-128 forward (more units than workgroup slots): persistent workgroups, 0 = not used
+int mavlm_attention_streamk_wgs(int R, int S, int H);
 size_t mavlm_attention_split_ws_floats(int R, int S, int H);
 // the same for the wide-head kernel (attention_hd.hip) and the merge kernel both use (attention3.hip)
 int mavlm_attention_hd_splits(int R, int S, int H, int* tiles_per_split);

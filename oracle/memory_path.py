@@ -350,6 +350,38 @@ def split_plan(R: int, S: int, heads: int) -> Tuple[int, int]:
     return ns, (tps if ns > 1 else 0)
 
 
+STREAMK_WGS = 512     # persistent workgroups of the stream-K schedule (csrc/attention3.hip ATTN3_SK_WGS = 256 CUs x 2)
+STREAMK_MIN_TILES = 128   # ... used from this many 64-key tiles per unit (mavlm_set_attention_streamk_min_tiles)
+
+
+def streamk_wgs(R: int, S: int, heads: int) -> int:
+    """Mirrors mavlm_attention_streamk_wgs (csrc/attention3.hip): more units (128-query blocks x heads) than workgroup
+    slots and a plain grid's last round < 95 % full -> the key tiles of ALL units are cut into STREAMK_WGS equal ranges."""
+    units = -(-R // 128) * heads
+    if units <= STREAMK_WGS or -(-S // KV_TILE) < STREAMK_MIN_TILES:
+        return 0
+    rounds = -(-units // STREAMK_WGS)
+    return STREAMK_WGS if units / (rounds * STREAMK_WGS) < 0.95 else 0
+
+
+def streamk_split_tiles(R: int, S: int, heads: int) -> Dict[Tuple[int, int], int]:
+    """{(head, query block): tile a} for the units the stream-K schedule cuts (at most once each): their keys are
+    processed as [0, a) and [a, nt) with independent online-softmax states and merged like split-KV partials.  Order of
+    the global tile sequence: head-major, query block, tile (attn_fwd3_kernel)."""
+    G = streamk_wgs(R, S, heads)
+    out: Dict[Tuple[int, int], int] = {}
+    if not G:
+        return out
+    nqb, nt = -(-R // 128), -(-S // KV_TILE)
+    TT = nqb * heads * nt
+    for g in range(1, G):
+        bpos = TT * g // G
+        u, a = divmod(bpos, nt)
+        if a:
+            out[(u // nqb, u % nqb)] = a
+    return out
+
+
 def split_plan_wide(R: int, S: int, heads: int) -> Tuple[int, int]:
     """(number of key splits, tiles per split) of the wide-head kernel (32-key tiles) - mirrors
     mavlm_attention_hd_splits (csrc/attention_hd.hip)."""
@@ -366,6 +398,7 @@ def split_plan_wide(R: int, S: int, heads: int) -> Tuple[int, int]:
 
 
 ROW_BLOCK_ELEMS = 1 << 28   # score elements per (head, query block) above which the queries are processed in blocks
+LAZY_SCORE_ELEMS = 1 << 27  # ... and above which a block's scores are produced per 4096-key chunk (emulation modes)
 
 
 def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mode: str = "fp32",
@@ -381,7 +414,7 @@ def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mod
         return _attention_heads(Q, K, V, heads, mode, want_colsum, want_probs, kv_tile, wave_rows, R)
     ctxs, lses, cs = [], [], None
     for r0 in range(0, R, blk):
-        c_, l_, s_, _ = _attention_heads(Q[r0:r0 + blk], K, V, heads, mode, want_colsum, False, kv_tile, wave_rows, R)
+        c_, l_, s_, _ = _attention_heads(Q[r0:r0 + blk], K, V, heads, mode, want_colsum, False, kv_tile, wave_rows, R, r0)
         ctxs.append(c_)
         lses.append(l_)
         if want_colsum:
@@ -391,7 +424,7 @@ def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mod
 
 def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mode: str = "fp32",
                      want_colsum: bool = False, want_probs: bool = False, kv_tile: Optional[int] = None,
-                     wave_rows: Optional[int] = None, plan_rows: Optional[int] = None):
+                     wave_rows: Optional[int] = None, plan_rows: Optional[int] = None, row0: int = 0):
     """softmax(Q K^T / sqrt(d)) V per head (MemoryController.py:51-54).  Returns
     (ctx [R,H*d] unrounded float32, lse2 [H,R] log2-domain log-sum-exp, colsum [H,Lk] | None, probs | None).
 
@@ -412,7 +445,7 @@ def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mo
     lse2 = np.empty((heads, R), dtype=F32)
     colsum = np.zeros((heads, Lk), dtype=np.float64) if want_colsum else None
     probs = np.empty((heads, R, Lk), dtype=F32) if want_probs else None
-    lazy = mode != "fp32" and not want_probs and R * Lk > (1 << 27)     # (eager is faster while [R, Lk] fits comfortably)
+    lazy = mode != "fp32" and not want_probs and R * Lk > LAZY_SCORE_ELEMS   # (eager is faster while [R, Lk] fits)
     for h in range(heads):
         sl = slice(h * d, (h + 1) * d)
         if lazy:
@@ -440,17 +473,22 @@ def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mo
             l = p.sum(axis=1, keepdims=True, dtype=F32)
             acc = _mm(p, V[:, sl])
         else:
-            def run(k_lo, k_hi):
-                m = np.full((R, 1), -1e30, dtype=F32)
-                l = np.zeros((R, 1), dtype=F32)
-                acc = np.zeros((R, d), dtype=F32)
+            def run(k_lo, k_hi, rows=None):
+                """online softmax over the keys [k_lo, k_hi) for all queries, or for the index array `rows` (whole
+                32-query waves, ascending)"""
+                n = R if rows is None else len(rows)
+                m = np.full((n, 1), -1e30, dtype=F32)
+                l = np.zeros((n, 1), dtype=F32)
+                acc = np.zeros((n, d), dtype=F32)
                 for k0 in range(k_lo, k_hi, kv_tile):
                     st = tile_scores(k0, min(k0 + kv_tile, k_hi))
+                    if rows is not None:
+                        st = st[rows]
                     cand = np.maximum(m, st.max(axis=1, keepdims=True))
                     need = ((cand - m) * F32(1.4426950408889634) > F32(RESCALE_LOG2)).reshape(-1)
-                    pad = (-R) % wave_rows
+                    pad = (-n) % wave_rows
                     grp = np.concatenate([need, np.zeros(pad, bool)]).reshape(-1, wave_rows).any(axis=1)
-                    move = np.repeat(grp, wave_rows)[:R].reshape(R, 1)
+                    move = np.repeat(grp, wave_rows)[:n].reshape(n, 1)
                     m_new = np.where(move, cand, m).astype(F32)
                     alpha = np.exp(m - m_new, dtype=F32)
                     pt = np.exp(st - m_new, dtype=F32)
@@ -459,13 +497,45 @@ def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mo
                     m = m_new
                 return acc, m, l
 
+            def merge(parts):
+                """normalised fp32 partials + their log-sum-exp -> (acc, lse, 1): weights 2^(lse_s - lse), in order"""
+                mx = np.maximum.reduce([p_[1] for p_ in parts])
+                den = sum(np.exp(p_[1] - mx, dtype=F32) for p_ in parts)
+                lse_t = (mx + np.log(den)).astype(F32)
+                return sum(np.exp(p_[1] - lse_t, dtype=F32) * p_[0] for p_ in parts).astype(F32), lse_t
+
+            sk_cuts = {}
             if kv_tile == KV_TILE:            # attention3.hip (head_dim <= 128)
                 ns, tps = split_plan(plan_rows or R, Lk, heads)
+                sk_cuts = {qb: a for (hh_, qb), a in streamk_split_tiles(plan_rows or R, Lk, heads).items() if hh_ == h}
+                if streamk_wgs(plan_rows or R, Lk, heads):
+                    ns, tps = 1, 0
             elif kv_tile == 32:               # attention_hd.hip
                 ns, tps = split_plan_wide(plan_rows or R, Lk, heads)
             else:
                 ns, tps = 1, 0
-            if ns == 1:
+            if sk_cuts:
+                # stream-K (attention3.hip, more units than workgroup slots): the units a range boundary cuts are computed
+                # as head [0, a) + tail [a, nt) and merged, head first; all other rows see their keys in one sweep
+                cut = np.zeros(R, dtype=np.int64)
+                for qb, a_ in sk_cuts.items():
+                    lo_, hi_ = qb * 128 - row0, (qb + 1) * 128 - row0
+                    cut[max(lo_, 0):max(min(hi_, R), 0)] = a_
+                acc = np.empty((R, d), dtype=F32)
+                m = np.empty((R, 1), dtype=F32)
+                l = np.ones((R, 1), dtype=F32)
+                for a_ in np.unique(cut):
+                    rows = np.nonzero(cut == a_)[0]
+                    if a_ == 0:
+                        ac_, m_, l_ = run(0, Lk, rows)
+                        acc[rows], m[rows] = (ac_ / l_).astype(F32), (m_ + np.log(l_)).astype(F32)
+                    else:
+                        parts = []
+                        for k_lo, k_hi in ((0, int(a_) * kv_tile), (int(a_) * kv_tile, Lk)):
+                            ac_, m_, l_ = run(k_lo, k_hi, rows)
+                            parts.append(((ac_ / l_).astype(F32), (m_ + np.log(l_)).astype(F32)))
+                        acc[rows], m[rows] = merge(parts)
+            elif ns == 1:
                 acc, m, l = run(0, Lk)
             else:
                 # split-KV (attention3.hip, small grids): each split yields a normalised fp32 partial + its
@@ -474,11 +544,8 @@ def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mo
                 for sp in range(ns):
                     a_, m_, l_ = run(sp * tps * kv_tile, min((sp + 1) * tps * kv_tile, Lk))
                     parts.append(((a_ / l_).astype(F32), (m_ + np.log(l_)).astype(F32)))
-                mx = np.maximum.reduce([p_[1] for p_ in parts])
-                den = sum(np.exp(p_[1] - mx, dtype=F32) for p_ in parts)
-                lse_t = (mx + np.log(den)).astype(F32)
-                acc = sum(np.exp(p_[1] - lse_t, dtype=F32) * p_[0] for p_ in parts).astype(F32)
-                m, l = lse_t, np.ones((R, 1), dtype=F32)
+                acc, m = merge(parts)
+                l = np.ones((R, 1), dtype=F32)
         ctx[:, sl] = acc / l                                                 # :53
         lse = m + np.log(l)
         lse2[h] = (lse / F32(math.log(2.0))).reshape(-1)

@@ -169,7 +169,7 @@ def test_attention_split_kv_small_grids(mode, R, S, H):
     same gates as the unsplit kernel against the oracle; the split result stays within 16-bit rounding of the
     unsplit one; the log-sum-exp it hands to the column-sum pass and to the backward is the merged one."""
     lib = capi.lib()
-    assert lib.mavlm_attention_ws_floats(R, S, H) > 0 and lib.mavlm_attention_ws_floats(12544, 6272, 8) == 0
+    assert lib.mavlm_attention_ws_floats(R, S, H) > 0 and lib.mavlm_attention_ws_floats(8192, 6272, 8) == 0
     r = O.rounder(mode)
     q = r(O.hash_normal_like((R, H * 128), 21))
     k = r(O.hash_normal_like((S, H * 128), 22))
@@ -193,6 +193,43 @@ def test_attention_split_kv_small_grids(mode, R, S, H):
     assert lib.mavlm_attention_ws(dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(), dv.stride(0),
                                   plain.data_ptr(), plain.stride(0), 0, R, S, H, 1.0 / math.sqrt(128.0), 0, 0,
                                   ops.dtype_code(dq.dtype), ops.stream_ptr()) == capi.E_ARG
+
+
+@pytest.mark.parametrize("mode,R,S,H", [("bf16", 8320, 256, 8), ("fp16", 8330, 200, 8), ("bf16", 1100, 64 * 9 + 5, 64)])
+def test_attention_stream_k_more_units_than_slots(mode, R, S, H, monkeypatch, request):
+    """More units (128-query blocks x heads) than the chip's 512 workgroup slots (the bench shape: 784): 512 persistent
+    workgroups each own an equal range of the global key-tile sequence, the units a range boundary cuts are computed as
+    head + tail partials and merged (attn_combine_sk_kernel).  The oracle mirrors the cuts (streamk_split_tiles): same
+    gates as the plain kernel; ragged query blocks / key tiles included; the plain entry point agrees within rounding."""
+    lib = capi.lib()
+    assert lib.mavlm_attention_ws_floats(12544, 6272, 8) == 0 and lib.mavlm_attention_ws_floats(12544, 12544, 8) > 0
+    capi.check(lib.mavlm_set_attention_streamk_min_tiles(1), "min tiles")     # (the default, 128 tiles, needs S >= 8192)
+    monkeypatch.setattr(O, "STREAMK_MIN_TILES", 1)
+    request.addfinalizer(lambda: lib.mavlm_set_attention_streamk_min_tiles(128))
+    assert lib.mavlm_attention_ws_floats(R, S, H) == 512 * 2 * (128 * 128 + 128)
+    assert O.streamk_wgs(R, S, H) == 512 and len(O.streamk_split_tiles(R, S, H)) > 100
+    r = O.rounder(mode)
+    q = r(O.hash_normal_like((R, H * 128), 31))
+    k = r(O.hash_normal_like((S, H * 128), 32))
+    v = r(O.hash_normal_like((S, H * 128), 33))
+    q[5] *= 8.0                                       # a few rows whose maximum jumps (deferred-rescale branch);
+    k[S // 2 + 3] *= 4.0                              # powers of two: the data stay on the 16-bit grid
+    ctx, lse2, col = _attn_oracle(q, k, v, H, mode)
+    dq, dk, dv = to_dev(q, mode), to_dev(k, mode), to_dev(v, mode)
+    got, lse = ops.attention(dq, dk, dv, H, want_lse=True)
+    assert O.rel_l2(to_np(got), ctx) < TOL
+    np.testing.assert_allclose(to_np(lse), lse2, rtol=0, atol=2e-3)
+    again, _ = ops.attention(dq, dk, dv, H, want_lse=True)
+    assert torch.equal(again, got)                    # static schedule, no atomics: deterministic
+    part = ops.attention_colsum(dq, dk, lse, H)
+    assert O.rel_l2(to_np(part), col) < TOL and abs(float(part.sum()) - H * R) < 1e-3 * H * R
+    plain = torch.empty_like(got)
+    lse_p = torch.empty_like(lse)
+    capi.check(lib.mavlm_attention(dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(), dv.stride(0),
+                                   plain.data_ptr(), plain.stride(0), lse_p.data_ptr(), R, S, H, 1.0 / math.sqrt(128.0),
+                                   ops.dtype_code(dq.dtype), ops.stream_ptr()), "mavlm_attention")
+    assert O.rel_l2(to_np(got), to_np(plain)) < (3e-3 if mode == "bf16" else 5e-4)
+    np.testing.assert_allclose(to_np(lse), to_np(lse_p), rtol=0, atol=1e-4)
 
 
 def test_attention_strided_kv_and_identity_v(attn_impl):

@@ -186,5 +186,8 @@ def test_query_blocked_attention_equals_unblocked(monkeypatch):
         ref = O._attention_heads(Q, K, V, H, mode, True, False, None, None, R)
         monkeypatch.setattr(O, "ROW_BLOCK_ELEMS", 1)
         got = O.attention_heads(Q, K, V, H, mode, want_colsum=True)
+        monkeypatch.setattr(O, "LAZY_SCORE_ELEMS", 1)          # + scores produced per key chunk instead of as one matrix
+        lazy = O.attention_heads(Q, K, V, H, mode, want_colsum=True)
         monkeypatch.undo()
-        assert O.rel_l2(got[0], ref[0]) < 1e-6 and O.rel_l2(got[1], ref[1]) < 1e-6 and O.rel_l2(got[2], ref[2]) < 1e-6
+        for out in (got, lazy):
+            assert O.rel_l2(out[0], ref[0]) < 1e-6 and O.rel_l2(out[1], ref[1]) < 1e-6 and O.rel_l2(out[2], ref[2]) < 1e-6
