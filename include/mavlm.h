@@ -247,7 +247,7 @@ int mavlm_set_gemm_rows(int32_t rows);
 int mavlm_set_attention_impl(int32_t impl);
 /* tuning / test hook: the head_dim-128 forward switches to its stream-K schedule (persistent workgroups over equal ranges of
  * the global key-tile sequence) when there are more units than workgroup slots AND at least this many 64-key
- * tiles per unit (default 128).  The schedule is part of the result (fp32 summation order): set it before sizing workspaces. */
+ * tiles per unit (default 64).  The schedule is part of the result (fp32 summation order): set it before sizing workspaces. */
 int mavlm_set_attention_streamk_min_tiles(int32_t tiles);
 
 /* --- measurement hooks (bench.py only; new - the reference has no profiling) ------------- */

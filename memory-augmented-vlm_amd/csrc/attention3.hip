@@ -40,22 +40,35 @@ struct IC { static constexpr int value = V; };
 
 // A workgroup runs one or more SEGMENTS.  A segment = one unit (head h, 128-query block) x a contiguous range of its key
 // tiles, computed with a fresh online-softmax state; a segment that covers all key tiles of its unit writes O / lse2, any
-// other writes a NORMALISED fp32 partial + its log-sum-exp for a merge kernel.  Three schedules (sk_wgs / tps):
-//   * plain (tps == 0, sk_wgs == 0): grid = units, one whole-unit segment per workgroup.
+// other writes a NORMALISED fp32 partial + its log-sum-exp for a merge kernel.  Three schedules (plan.wgs / tps):
+//   * plain (tps == 0, plan.wgs == 0): grid = units, one whole-unit segment per workgroup.
 //   * split-KV (tps > 0; small grids): blockIdx.y owns the key tiles [y*tps, (y+1)*tps); attn_combine_kernel merges.
-//   * stream-K (sk_wgs > 0; more units than the chip has workgroup slots): sk_wgs persistent workgroups, workgroup v owns
-//     the global tile range [v*TT/G, (v+1)*TT/G) of the head-major tile order (TT = units x tiles per unit), i.e. the tail
-//     of one unit, whole units, and the head of another.  784 units on 512 slots take two rounds (the second at 53 %
-//     occupancy) as a plain grid; as 512 equal tile ranges they take 1.53.  At most ONE range boundary falls inside a unit
-//     (the launcher uses this schedule only when units >= workgroups), so a unit has at most two partials:
-//     attn_combine_sk_kernel merges them.  Static schedule, no atomics, no queue: deterministic, and the oracle mirrors it.
+//   * levelled stream-K (plan.wgs = G > 0; more units than the chip has workgroup slots, long key sequences).  784 units on
+//     512 slots leave the second round of a plain grid at 53 % occupancy.  Here G persistent workgroups first take
+//     floor(U / G) whole units each; the remaining r = U mod G units are written as r = sum_k d_k G / 2^k (binary digits):
+//     level k gives G / 2^k units to ALL G workgroups, each unit cut into 2^k equal key ranges - every workgroup is busy
+//     for (1 + r / G) unit-times in total.  Unlike equal contiguous ranges of the global tile sequence (the textbook form:
+//     every workgroup at a different key position, so a head's K / V beyond the 4 MiB L2 is re-fetched by everyone - measured
+//     3.4 GB per launch at 12 544 keys, and -11 % at 125 k keys), the pieces of a level start at 2^k key positions only and
+//     the workgroups sharing one advance together: the L2 holds 2^k moving windows.  Static schedule, no atomics, no queue:
+//     deterministic; attn_combine_sk_kernel merges the 2^k partials of a cut unit in key order; the oracle mirrors the plan.
+struct attn3_sk_plan {
+  int wgs;           // G (0 = schedule not used)
+  int full;          // whole units per workgroup
+  int nlev;          // levels in use
+  int k[6];          // level: units are cut into 2^k key ranges
+  int base[6];       // first unit of the level
+  int nun[6];        // units of the level (<= G >> k)
+  int slot[6];       // first partial slot of the level (+ virtual workgroup id)
+};
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __restrict__ Q, int ldq,
                                                            const uint16_t* __restrict__ Kall, int ldk,
                                                            const uint16_t* __restrict__ Vall, int ldv,
                                                            uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
                                                            int R, int S_all, int H, float c, float* __restrict__ Opart,
-                                                           float* __restrict__ lse_part, int tps, int sk_wgs) {
+                                                           float* __restrict__ lse_part, int tps, attn3_sk_plan plan) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -64,31 +77,45 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
   const int nt_all = (S_all + KT3 - 1) / KT3;
   const int nqb = (R + 127) / 128;
 
-  // ---- schedule
-  long long sk_pos = 0, sk_end = 0;                           // stream-K: global tile range of this workgroup
-  int sk_v = 0;
-  if (sk_wgs > 0) {
-    sk_v = xcd_remap((int)blockIdx.x, sk_wgs);                // XCD x owns a contiguous range of the head-major order:
-    const long long TT = (long long)nqb * H * nt_all;         // its L2 holds the K / V of ~H/8 heads
-    sk_pos = TT * sk_v / sk_wgs;
-    sk_end = TT * (sk_v + 1) / sk_wgs;
-  }
-  bool more_segments = true;
-  while (more_segments) {
+  // ---- schedule.  Levelled stream-K: XCD x owns the virtual ids [x G/8, (x+1) G/8), i.e. contiguous units of the
+  // head-major order - its L2 holds the K / V of ~H/8 heads, and the 2^k workgroups that share a unit sit on one XCD.
+  const int sk_v = plan.wgs > 0 ? xcd_remap((int)blockIdx.x, plan.wgs) : 0;
+  const int nseg = plan.wgs > 0 ? plan.full + plan.nlev : 1;
+  for (int si = 0; si < nseg; ++si) {
   // ---- this segment: unit (h, q-block), key tiles [t_lo, t_lo + nt)
   int h, qblk, t_lo, nt, out_kind, split = 0;                 // out_kind 0: O/lse2, 1: split-KV partial, 2: stream-K partial
   int sk_slot = 0;
-  if (sk_wgs > 0) {
-    const int u = (int)(sk_pos / nt_all);
-    t_lo = (int)(sk_pos - (long long)u * nt_all);
-    const long long left = sk_end - sk_pos;
-    nt = (nt_all - t_lo < left) ? nt_all - t_lo : (int)left;
+  if (plan.wgs > 0) {
+    int u;
+    if (si < plan.full) {
+      u = si * plan.wgs + sk_v;
+      t_lo = 0;
+      nt = nt_all;
+      out_kind = 0;
+    } else {
+      const int lv = si - plan.full;
+      int lk = plan.k[0], lbase = plan.base[0], lnun = plan.nun[0], lslot = plan.slot[0];
+#pragma unroll
+      for (int j = 1; j < 6; ++j)                              // (static indices: the plan lives in scalar registers)
+        if (lv == j) { lk = plan.k[j]; lbase = plan.base[j]; lnun = plan.nun[j]; lslot = plan.slot[j]; }
+      const int ul = sk_v >> lk;
+      if (ul >= lnun) continue;                                // this workgroup has no unit on this (partial) level
+      const int piece = sk_v & ((1 << lk) - 1);
+      u = lbase + ul;
+      t_lo = (int)(((long long)piece * nt_all) >> lk);
+      nt = (int)(((long long)(piece + 1) * nt_all) >> lk) - t_lo;
+      out_kind = 2;
+      sk_slot = lslot + sk_v;
+      if (nt == 0) {                                           // fewer key tiles than pieces: a neutral partial (weight 0)
+        float* pp = Opart + ((size_t)sk_slot * 128 + wave * 32 + r) * HD3 + 64 * hh;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) *(f32x4*)(pp + 4 * g) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (hh == 0) lse_part[(size_t)sk_slot * 128 + wave * 32 + r] = -INFINITY;
+        continue;
+      }
+    }
     h = u / nqb;
     qblk = u - h * nqb;
-    out_kind = (nt == nt_all) ? 0 : 2;
-    sk_slot = 2 * sk_v + (t_lo > 0 ? 0 : 1);                  // tail of a unit = first segment, head = last segment
-    sk_pos += nt;
-    more_segments = sk_pos < sk_end;
   } else {
     h = blockIdx.x % H;                                       // one head per XCD L2 when H == 8
     qblk = blockIdx.x / H;
@@ -96,7 +123,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
     t_lo = tps > 0 ? split * tps : 0;
     nt = tps > 0 ? ((nt_all - t_lo < tps) ? nt_all - t_lo : tps) : nt_all;
     out_kind = tps > 0 ? 1 : 0;
-    more_segments = false;
   }
   const uint16_t* K = Kall + (size_t)t_lo * KT3 * ldk;
   const uint16_t* V = Vall + (size_t)t_lo * KT3 * ldv;
@@ -464,38 +490,77 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
   }   // segment loop (every tile iteration ends with a barrier: the LDS slots are free for the next segment's prologue)
 }
 
-// Stream-K merge: boundary g (1 .. G-1) of the global tile order cuts unit u = (g*TT/G) / nt_all at tile a = (g*TT/G) %
-// nt_all; a == 0: the boundary coincides with a unit boundary, nothing to do.  Otherwise the unit's head [0, a) is slot
-// 2(g-1)+1 (last segment of workgroup g-1) and its tail [a, nt_all) is slot 2g (first segment of workgroup g):
-// O = w0 O0 + w1 O1, w = 2^(lse_i - lse), head first.  One workgroup per boundary, 2 threads per query row.
+// Stream-K merge: four workgroups per cut unit (32 query rows each).  Unit `ul` of level j (cut into 2^k key ranges) has its partials in the slots
+// plan.slot[j] + (ul << k) + p, p = 0 .. 2^k - 1 in key order: O = sum_p w_p O_p, w_p = 2^(lse_p - lse), lse = log2 sum_p
+// 2^lse_p (an empty range carries lse = -inf: weight 0).  A 512-byte partial row = 32 lanes x 16 bytes: a wave-instruction
+// covers two whole rows, the workgroup eight.
+// (NP = 2^k is a compile-time constant per level so that the 2^k log-sum-exp loads and the 2^k partial-row loads of a query
+// row are issued back to back: as run-time loops each load waited for the previous one - 96 dependent round trips per row
+// at k = 5, 283 us for the whole merge against 600 us for the attention itself.)
+template <typename T, int NP>
+__device__ __forceinline__ void combine_sk_rows(const float* __restrict__ Opart, const float* __restrict__ lse_part, size_t s0,
+                                                uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2, int R, int h, int qblk,
+                                                int quarter) {
+  const int c4 = threadIdx.x & 31, rsub = threadIdx.x >> 5;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {                             // a workgroup merges 32 of the unit's 128 rows
+    const int row = quarter * 32 + it * 8 + rsub;
+    const int q = qblk * 128 + row;
+    if (q >= R) continue;
+    float l[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) l[p] = lse_part[(s0 + p) * 128 + row];
+    float mx = l[0];
+#pragma unroll
+    for (int p = 1; p < NP; ++p) mx = fmaxf(mx, l[p]);
+    float den = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) den += __builtin_amdgcn_exp2f(l[p] - mx);
+    const float lse = mx + log2f(den);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int CH = NP < 8 ? NP : 8;                        // partial rows in flight per lane
+#pragma unroll
+    for (int p0 = 0; p0 < NP; p0 += CH) {
+      f32x4 a[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) a[j] = *(const f32x4*)(Opart + ((s0 + p0 + j) * 128 + row) * HD3 + 4 * c4);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {                           // key order
+        const float w = __builtin_amdgcn_exp2f(l[p0 + j] - lse);
+        acc[0] += w * a[j][0]; acc[1] += w * a[j][1]; acc[2] += w * a[j][2]; acc[3] += w * a[j][3];
+      }
+    }
+    *(u32x2*)(O + (size_t)q * ldo + h * HD3 + 4 * c4) = pack4<T>(acc[0], acc[1], acc[2], acc[3]);
+    if (lse2 != nullptr && c4 == 0) lse2[(size_t)h * R + q] = lse;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void attn_combine_sk_kernel(const float* __restrict__ Opart, const float* __restrict__ lse_part,
                                                               uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
-                                                              int R, int H, int nt_all, int G) {
-  const int g = blockIdx.x + 1;
-  const int nqb = (R + 127) / 128;
-  const long long TT = (long long)nqb * H * nt_all;
-  const long long bpos = TT * g / G;
-  const int u = (int)(bpos / nt_all);
-  if (bpos - (long long)u * nt_all == 0) return;
-  const int h = u / nqb, qblk = u - h * nqb;
-  const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
-  const int q = qblk * 128 + row;
-  if (q >= R) return;
-  const size_t s0 = (size_t)(2 * (g - 1) + 1), s1 = (size_t)(2 * g);
-  const float l0 = lse_part[s0 * 128 + row], l1 = lse_part[s1 * 128 + row];
-  const float mx = fmaxf(l0, l1);
-  const float lse = mx + log2f(__builtin_amdgcn_exp2f(l0 - mx) + __builtin_amdgcn_exp2f(l1 - mx));
-  const float w0 = __builtin_amdgcn_exp2f(l0 - lse), w1 = __builtin_amdgcn_exp2f(l1 - lse);
-  const float* p0 = Opart + (s0 * 128 + row) * HD3 + half * 64;
-  const float* p1 = Opart + (s1 * 128 + row) * HD3 + half * 64;
-  uint16_t* op = O + (size_t)q * ldo + h * HD3 + half * 64;
+                                                              int R, int H, attn3_sk_plan plan) {
+  int b = blockIdx.x >> 2, lk = 0, lbase = 0, lslot = 0;       // four workgroups per cut unit
+  const int quarter = blockIdx.x & 3;
+  bool found = false;
 #pragma unroll
-  for (int v = 0; v < 16; ++v) {
-    const f32x4 a = *(const f32x4*)(p0 + 4 * v), b = *(const f32x4*)(p1 + 4 * v);
-    *(u32x2*)(op + 4 * v) = pack4<T>(w0 * a[0] + w1 * b[0], w0 * a[1] + w1 * b[1], w0 * a[2] + w1 * b[2], w0 * a[3] + w1 * b[3]);
+  for (int j = 0; j < 6; ++j) {
+    if (!found && j < plan.nlev) {
+      if (b < plan.nun[j]) { lk = plan.k[j]; lbase = plan.base[j]; lslot = plan.slot[j]; found = true; }
+      else b -= plan.nun[j];
+    }
   }
-  if (lse2 != nullptr && half == 0) lse2[(size_t)h * R + q] = lse;
+  if (!found) return;
+  const int nqb = (R + 127) / 128;
+  const int u = lbase + b;
+  const int h = u / nqb, qblk = u - h * nqb;
+  const size_t s0 = (size_t)lslot + ((size_t)b << lk);
+  switch (lk) {
+    case 1: combine_sk_rows<T, 2>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter); break;
+    case 2: combine_sk_rows<T, 4>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter); break;
+    case 3: combine_sk_rows<T, 8>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter); break;
+    case 4: combine_sk_rows<T, 16>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter); break;
+    default: combine_sk_rows<T, 32>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter); break;
+  }
 }
 
 // O[q, h*128+d] = sum_s w_s Opart[s][q][h*128+d], w_s = 2^(lse_s - lse), lse = log2 sum_s 2^lse_s.  One wave per query
@@ -567,28 +632,44 @@ int mavlm_attention_splits(int R, int S, int H, int* tiles_per_split) {
   return ns;
 }
 
-// Stream-K plan: number of persistent workgroups (0 = not used).  Used when the units (128-query blocks x heads) exceed the
-// ATTN3_SK_WGS workgroup slots of the chip (256 CUs x 2) and a plain grid would leave more than 5 % of its last round
-// empty.  units >= workgroups guarantees at most one range boundary inside a unit (two partials).  Pure function of the
-// shape (mirrored by oracle/memory_path.py::streamk_plan).
+// Levelled stream-K plan (see attn_fwd3_kernel).  Used when the units (128-query blocks x heads) exceed the ATTN3_SK_WGS
+// workgroup slots of the chip (256 CUs x 2), a plain grid would leave more than 5 % of its last round empty, and a unit has
+// at least g_mavlm_attn_sk_min_tiles key tiles.  The schedule costs a prologue per segment, 64 KiB of fp32 partial per cut
+// and the merge kernel, and the plain grid's under-filled last round already runs ~1.6x faster per workgroup (one per
+// CU): measured on one device at 784 units, S = 6272 / 12 544 / 25 088 / 62 720 / 125 440 keys: 362 -> 334, 683 -> 612,
+// 1331 -> 1172, 3404 -> 2883, 6964 -> 5710 us (889 -> 964 ... 926 -> 1129 TFLOP/s); below ~64 tiles per unit the fixed
+// costs win.
+// The remainder r = U mod G is served by levels k = 1 .. 5 (2-way .. 32-way cuts); what is left after level 4 (fewer than
+// G/16 units) goes into one or two 32-way levels.  Pure function of the shape (mirrored by oracle/memory_path.py).
 constexpr int ATTN3_SK_WGS = 512;
-int g_mavlm_attn_sk_min_tiles = 128;          // tuning / test hook (mavlm_set_attention_streamk_min_tiles)
-#define ATTN3_SK_MIN_TILES g_mavlm_attn_sk_min_tiles
-int mavlm_attention_streamk_wgs(int R, int S, int H) {
+int g_mavlm_attn_sk_min_tiles = 64;          // tuning / test hook (mavlm_set_attention_streamk_min_tiles)
+static attn3_sk_plan attn3_plan(int R, int S, int H) {
+  attn3_sk_plan p = {};
   const long units = (long)((R + 127) / 128) * H;
-  if (units <= ATTN3_SK_WGS) return 0;
-  // The schedule costs a second prologue per workgroup, 64 KiB of fp32 partial per cut and the merge kernel (~25 us at the
-  // bench shape), and the plain grid's under-filled last round already runs ~1.6x faster per workgroup (one per CU):
-  // measured on one device at 784 units, 98 key tiles (S = 6272) 351 -> 363 us, 196 tiles (S = 12 544) 678 -> 640 us.
-  // Worth it from ~128 tiles per unit: the evolution attention over the FIFO (S = n x R keys).
-  if ((S + KT3 - 1) / KT3 < ATTN3_SK_MIN_TILES) return 0;
-  const long rounds = (units + ATTN3_SK_WGS - 1) / ATTN3_SK_WGS;
-  return (double)units / (double)(rounds * ATTN3_SK_WGS) < 0.95 ? ATTN3_SK_WGS : 0;
+  const int G = ATTN3_SK_WGS;
+  if (units <= G || (S + KT3 - 1) / KT3 < g_mavlm_attn_sk_min_tiles) return p;
+  const long rounds = (units + G - 1) / G;
+  if ((double)units / (double)(rounds * G) >= 0.95) return p;
+  p.wgs = G;
+  p.full = (int)(units / G);
+  int rem = (int)(units % G), base = p.full * G, slot = 0;
+  for (int k = 1; k <= 4; ++k)
+    if (rem >= (G >> k)) {
+      p.k[p.nlev] = k; p.base[p.nlev] = base; p.nun[p.nlev] = G >> k; p.slot[p.nlev] = slot;
+      ++p.nlev; base += G >> k; rem -= G >> k; slot += G;
+    }
+  while (rem > 0) {                                           // < G/16 units left: 32-way levels of up to G/32 units
+    const int n = rem < (G >> 5) ? rem : (G >> 5);
+    p.k[p.nlev] = 5; p.base[p.nlev] = base; p.nun[p.nlev] = n; p.slot[p.nlev] = slot;
+    ++p.nlev; base += n; rem -= n; slot += G;
+  }
+  return p;
 }
+int mavlm_attention_streamk_wgs(int R, int S, int H) { return attn3_plan(R, S, H).wgs; }
 
 size_t mavlm_attention_split_ws_floats(int R, int S, int H) {
-  const int g = mavlm_attention_streamk_wgs(R, S, H);
-  if (g > 0) return (size_t)g * 2 * (128 * HD3 + 128);
+  const attn3_sk_plan pl = attn3_plan(R, S, H);
+  if (pl.wgs > 0) return (size_t)pl.wgs * pl.nlev * (128 * HD3 + 128);
   const int ns = mavlm_attention_splits(R, S, H, nullptr);
   return ns > 1 ? (size_t)ns * R * H * HD3 + (size_t)ns * H * R : 0;
 }
@@ -598,19 +679,22 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
   // (2 GiB: the scalar offset of the tile after the last one must not wrap either)
   if ((double)a.S * a.ldk * 2.0 >= 2147483648.0 || (double)a.S * a.ldv * 2.0 >= 2147483648.0) return hipErrorInvalidValue;
   const float c = a.scale * 1.44269504088896340736f;
-  int tps = 0, ns = 1, skg = 0;
+  int tps = 0, ns = 1;
+  attn3_sk_plan plan = {};
   if (a.split_ws != nullptr) {
-    skg = mavlm_attention_streamk_wgs(a.R, a.S, a.H);
-    if (skg == 0) ns = mavlm_attention_splits(a.R, a.S, a.H, &tps);
+    plan = attn3_plan(a.R, a.S, a.H);
+    if (plan.wgs == 0) ns = mavlm_attention_splits(a.R, a.S, a.H, &tps);
   }
+  const int skg = plan.wgs;
+  int cut_units = 0;
+  for (int j = 0; j < plan.nlev; ++j) cut_units += plan.nun[j];
   if (ns <= 1) { ns = 1; tps = 0; }
   float* opart = a.split_ws;
   float* lpart = nullptr;
-  if (skg > 0) lpart = a.split_ws + (size_t)skg * 2 * 128 * HD3;
+  if (skg > 0) lpart = a.split_ws + (size_t)skg * plan.nlev * 128 * HD3;
   else if (ns > 1) lpart = a.split_ws + (size_t)ns * a.R * a.H * HD3;
   const int units = ((a.R + 127) / 128) * a.H;
   const dim3 grid(skg > 0 ? skg : units, skg > 0 ? 1 : ns);
-  const int nt_all = (a.S + KT3 - 1) / KT3;
   static mavlm_per_device_once once[2];
   if (dtype == MAVLM_F16) {
     {
@@ -618,10 +702,10 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(attn_fwd3_kernel<F16>, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
-                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps, skg);
-    if (skg > 0)
-      hipLaunchKernelGGL(attn_combine_sk_kernel<F16>, dim3(skg - 1), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo, a.lse2,
-                         a.R, a.H, nt_all, skg);
+                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps, plan);
+    if (skg > 0 && cut_units > 0)
+      hipLaunchKernelGGL(attn_combine_sk_kernel<F16>, dim3(4 * cut_units), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
+                         a.lse2, a.R, a.H, plan);
     else if (ns > 1)
       hipLaunchKernelGGL(attn_combine_kernel<F16>, dim3((a.R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
                          a.lse2, a.R, a.H, HD3, ns);
@@ -631,10 +715,10 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(attn_fwd3_kernel<BF16>, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
-                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps, skg);
-    if (skg > 0)
-      hipLaunchKernelGGL(attn_combine_sk_kernel<BF16>, dim3(skg - 1), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo, a.lse2,
-                         a.R, a.H, nt_all, skg);
+                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps, plan);
+    if (skg > 0 && cut_units > 0)
+      hipLaunchKernelGGL(attn_combine_sk_kernel<BF16>, dim3(4 * cut_units), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
+                         a.lse2, a.R, a.H, plan);
     else if (ns > 1)
       hipLaunchKernelGGL(attn_combine_kernel<BF16>, dim3((a.R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
                          a.lse2, a.R, a.H, HD3, ns);

@@ -351,34 +351,52 @@ def split_plan(R: int, S: int, heads: int) -> Tuple[int, int]:
 
 
 STREAMK_WGS = 512     # persistent workgroups of the stream-K schedule (csrc/attention3.hip ATTN3_SK_WGS = 256 CUs x 2)
-STREAMK_MIN_TILES = 128   # ... used from this many 64-key tiles per unit (mavlm_set_attention_streamk_min_tiles)
+STREAMK_MIN_TILES = 64   # ... used from this many 64-key tiles per unit (mavlm_set_attention_streamk_min_tiles)
+
+
+def streamk_plan(R: int, S: int, heads: int):
+    """Mirrors attn3_plan (csrc/attention3.hip): (G, full, levels) with levels = [(k, first unit, units)] - after `full`
+    whole units per workgroup the remaining units are cut into 2^k equal key ranges, level by level; G = 0: not used."""
+    units = -(-R // 128) * heads
+    G = STREAMK_WGS
+    if units <= G or -(-S // KV_TILE) < STREAMK_MIN_TILES:
+        return 0, 0, []
+    rounds = -(-units // G)
+    if units / (rounds * G) >= 0.95:
+        return 0, 0, []
+    full, rem = divmod(units, G)
+    base, levels = full * G, []
+    for k in range(1, 5):
+        if rem >= (G >> k):
+            levels.append((k, base, G >> k))
+            base += G >> k
+            rem -= G >> k
+    while rem > 0:
+        n = min(rem, G >> 5)
+        levels.append((5, base, n))
+        base += n
+        rem -= n
+    return G, full, levels
 
 
 def streamk_wgs(R: int, S: int, heads: int) -> int:
-    """Mirrors mavlm_attention_streamk_wgs (csrc/attention3.hip): more units (128-query blocks x heads) than workgroup
-    slots and a plain grid's last round < 95 % full -> the key tiles of ALL units are cut into STREAMK_WGS equal ranges."""
-    units = -(-R // 128) * heads
-    if units <= STREAMK_WGS or -(-S // KV_TILE) < STREAMK_MIN_TILES:
-        return 0
-    rounds = -(-units // STREAMK_WGS)
-    return STREAMK_WGS if units / (rounds * STREAMK_WGS) < 0.95 else 0
+    return streamk_plan(R, S, heads)[0]
 
 
-def streamk_split_tiles(R: int, S: int, heads: int) -> Dict[Tuple[int, int], int]:
-    """{(head, query block): tile a} for the units the stream-K schedule cuts (at most once each): their keys are
-    processed as [0, a) and [a, nt) with independent online-softmax states and merged like split-KV partials.  Order of
-    the global tile sequence: head-major, query block, tile (attn_fwd3_kernel)."""
-    G = streamk_wgs(R, S, heads)
-    out: Dict[Tuple[int, int], int] = {}
+def streamk_split_tiles(R: int, S: int, heads: int) -> Dict[Tuple[int, int], List[Tuple[int, int]]]:
+    """{(head, query block): [(tile_lo, tile_hi), ...]} for the units the levelled stream-K schedule cuts: their keys are
+    processed as 2^k ranges with independent online-softmax states and merged in key order like split-KV partials (empty
+    ranges - fewer tiles than pieces - dropped).  Unit order: head-major, then query block (attn_fwd3_kernel)."""
+    G, _, levels = streamk_plan(R, S, heads)
+    out: Dict[Tuple[int, int], List[Tuple[int, int]]] = {}
     if not G:
         return out
     nqb, nt = -(-R // 128), -(-S // KV_TILE)
-    TT = nqb * heads * nt
-    for g in range(1, G):
-        bpos = TT * g // G
-        u, a = divmod(bpos, nt)
-        if a:
-            out[(u // nqb, u % nqb)] = a
+    for k, base, n in levels:
+        for ul in range(n):
+            u = base + ul
+            rng = [((p * nt) >> k, ((p + 1) * nt) >> k) for p in range(1 << k)]
+            out[(u // nqb, u % nqb)] = [(a, b) for a, b in rng if b > a]
     return out
 
 
@@ -515,24 +533,30 @@ def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mo
             else:
                 ns, tps = 1, 0
             if sk_cuts:
-                # stream-K (attention3.hip, more units than workgroup slots): the units a range boundary cuts are computed
-                # as head [0, a) + tail [a, nt) and merged, head first; all other rows see their keys in one sweep
-                cut = np.zeros(R, dtype=np.int64)
-                for qb, a_ in sk_cuts.items():
+                # levelled stream-K (attention3.hip, more units than workgroup slots, long key sequences): a cut unit is
+                # computed as 2^k key ranges with fresh softmax states, merged in key order; all other rows see their keys
+                # in one sweep
+                cut = np.zeros(R, dtype=np.int64)              # 0 = not cut, else 1 + index into `plans`
+                plans = []
+                for qb, rng in sk_cuts.items():
                     lo_, hi_ = qb * 128 - row0, (qb + 1) * 128 - row0
-                    cut[max(lo_, 0):max(min(hi_, R), 0)] = a_
+                    if hi_ <= 0 or lo_ >= R:
+                        continue
+                    if rng not in plans:
+                        plans.append(rng)
+                    cut[max(lo_, 0):min(hi_, R)] = 1 + plans.index(rng)
                 acc = np.empty((R, d), dtype=F32)
                 m = np.empty((R, 1), dtype=F32)
                 l = np.ones((R, 1), dtype=F32)
-                for a_ in np.unique(cut):
-                    rows = np.nonzero(cut == a_)[0]
-                    if a_ == 0:
+                for pi in np.unique(cut):
+                    rows = np.nonzero(cut == pi)[0]
+                    if pi == 0:
                         ac_, m_, l_ = run(0, Lk, rows)
                         acc[rows], m[rows] = (ac_ / l_).astype(F32), (m_ + np.log(l_)).astype(F32)
                     else:
                         parts = []
-                        for k_lo, k_hi in ((0, int(a_) * kv_tile), (int(a_) * kv_tile, Lk)):
-                            ac_, m_, l_ = run(k_lo, k_hi, rows)
+                        for t_lo, t_hi in plans[pi - 1]:
+                            ac_, m_, l_ = run(t_lo * kv_tile, min(t_hi * kv_tile, Lk), rows)
                             parts.append(((ac_ / l_).astype(F32), (m_ + np.log(l_)).astype(F32)))
                         acc[rows], m[rows] = merge(parts)
             elif ns == 1:

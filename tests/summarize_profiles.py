@@ -1,0 +1,90 @@
+"""Turns gpurun_out/prof_<tag>/ (tests/profile_round.sh) into the small summaries committed under profiles/:
+  <tag>_kernel_stats_1video_in_flight.csv / <tag>_kernel_stats.csv   name, calls, total us, average us, % (rocprofv3 --stats)
+  <tag>_bench_under_rocprof*.json                                     the bench line printed by the same command
+  <tag>_mfma_utilisation.csv                                          matrix-pipe busy share per kernel (PMC)
+  <tag>_attn_fwd_hbm_traffic.json                                     FETCH_SIZE x2 (gfx950) + WRITE_SIZE per launch (PMC)
+usage: python tests/summarize_profiles.py <tag>"""
+import collections, csv, glob, json, os, re, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    return re.sub(r"\(.*", "", name).replace("void ", "")
+
+
+def stats(sub, out):
+    files = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+    if not files:
+        print("no kernel_stats for", sub)
+        return
+    rows = list(csv.DictReader(open(files[0])))
+    with open(os.path.join(dst, out), "w") as f:
+        f.write("name,calls,total_us,average_us,percent\n")
+        for r in rows:
+            f.write(f"\"{short(r['Name'])}\",{r['Calls']},{float(r['TotalDurationNs'])/1e3:.1f},{float(r['AverageNs'])/1e3:.2f},{r['Percentage']}\n")
+    js = os.path.join(src, sub + ".json")
+    if os.path.exists(js):
+        line = [l for l in open(js) if l.startswith("{")]
+        if line:
+            open(os.path.join(dst, out.replace("kernel_stats", "bench_under_rocprof").replace(".csv", ".json")), "w").write(line[-1])
+
+
+def counters(sub):
+    files = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for fn in files:
+        for r in csv.DictReader(open(fn)):
+            agg[(short(r["Kernel_Name"]), r.get("Grid_Size", ""))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+stats("stats1", f"{tag}_kernel_stats_1video_in_flight.csv")
+stats("stats2", f"{tag}_kernel_stats.csv")
+
+with open(os.path.join(dst, f"{tag}_mfma_utilisation.csv"), "w") as f:
+    f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES (tests/profile_round.sh), per dispatch averages at the bench shapes\n")
+    f.write("# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs) / (GRBM_GUI_ACTIVE / 8 XCDs); profiled clocks are lower than un-profiled ones\n")
+    f.write("kernel,grid_threads,mfma_busy_cycles_sum,kernel_cycles,mfma_util\n")
+    for op in ("attn", "colsum", "gemm"):
+        for (k, grid), c in sorted(counters(f"mfma_{op}").items()):
+            if "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "GRBM_GUI_ACTIVE" not in c:
+                continue
+            busy = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(c["SQ_VALU_MFMA_BUSY_CYCLES"])
+            cyc = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"]) / 8.0
+            if busy <= 0 or cyc <= 0:
+                continue
+            f.write(f"\"{k}\",{grid},{busy:.0f},{cyc:.0f},{busy / 1024.0 / cyc:.3f}\n")
+
+fetch, write = counters("fetch"), counters("write")
+shapes = {}
+for (k, grid), c in sorted(fetch.items()):
+    if "attn_fwd3_kernel" not in k or "FETCH_SIZE" not in c:
+        continue
+    f_ = c["FETCH_SIZE"]
+    w_ = write.get((k, grid), {}).get("WRITE_SIZE", [0.0])
+    for tag_, vals in (("lo", [v for v in f_ if v <= 1.2 * min(f_)]), ("hi", [v for v in f_ if v > 1.2 * min(f_)])):
+        if vals:
+            shapes[f"{k} grid {grid} ({'fewer' if tag_ == 'lo' else 'more'} keys)" if len(set(round(v / min(f_)) for v in f_)) > 1
+                   else f"{k} grid {grid}"] = {
+                "dispatches": len(vals), "FETCH_SIZE_KB": round(sum(vals) / len(vals), 1), "WRITE_SIZE_KB": round(sum(w_) / len(w_), 1),
+                "read_bytes_corrected": int(2 * 1024 * sum(vals) / len(vals)), "write_bytes": int(1024 * sum(w_) / len(w_))}
+if shapes:
+    out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tests/profile_round.sh) on tests/bench_ops.py attn "
+                   "(R=12544, H=8: S=6272 on the plain grid of 784 workgroups, S=12544 on the stream-K grid of 512), KB per "
+                   "dispatch; read bytes = 2 x FETCH_SIZE x 1024 (gfx950 reports half of a 16-B/lane coalesced stream, "
+                   "MI355X_MICROARCH.md HBM), write bytes = WRITE_SIZE x 1024; FETCH_SIZE counts L2 misses, Infinity-Cache hits "
+                   "included; algorithmic bytes: Q + K + V read once = 51.4 MB (S=6272) / 77.1 MB (S=12544), O written once = 25.7 MB",
+           "kernels": shapes}
+    tot = [(v["read_bytes_corrected"] + v["write_bytes"], v) for v in shapes.values()]
+    if len(tot) >= 2:
+        lo, hi = min(t[0] for t in tot), max(t[0] for t in tot)
+        out["bench_avg_bytes_per_launch"] = int((4 * lo + hi) / 5)      # per video: 4 launches at S=6272, 1 at S=12544
+    elif tot:
+        out["bench_avg_bytes_per_launch"] = tot[0][0]
+    json.dump(out, open(os.path.join(dst, f"{tag}_attn_fwd_hbm_traffic.json"), "w"), indent=1)
+print(sorted(os.listdir(dst)))
