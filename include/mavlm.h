@@ -249,6 +249,9 @@ int mavlm_set_attention_impl(int32_t impl);
  * the global key-tile sequence) when there are more units than workgroup slots AND at least this many 64-key
  * tiles per unit (default 64).  The schedule is part of the result (fp32 summation order): set it before sizing workspaces. */
 int mavlm_set_attention_streamk_min_tiles(int32_t tiles);
+/* tuning hook: waves per workgroup of the stream-K schedule - 8 (256 queries per unit, 256 workgroups: K / V staged once per
+ * eight waves), 4 (128 queries, 512 workgroups), 0 = automatic (8 where its plan applies).  Part of the result, as above. */
+int mavlm_set_attention_streamk_waves(int32_t waves);
 
 /* --- measurement hooks (bench.py only; new - the reference has no profiling) ------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on its own stream.  Kinds: 0 GEMM, 1 attention

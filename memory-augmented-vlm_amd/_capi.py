@@ -91,6 +91,7 @@ SIGNATURES = {
     "mavlm_set_gemm_rows": (C.c_int, [i32]),
     "mavlm_set_attention_impl": (C.c_int, [i32]),
     "mavlm_set_attention_streamk_min_tiles": (C.c_int, [i32]),
+    "mavlm_set_attention_streamk_waves": (C.c_int, [i32]),
     "mavlm_prof_enable": (C.c_int, [i32]),
     "mavlm_prof_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), i32]),

@@ -54,6 +54,7 @@ struct IC { static constexpr int value = V; };
 //     deterministic; attn_combine_sk_kernel merges the 2^k partials of a cut unit in key order; the oracle mirrors the plan.
 struct attn3_sk_plan {
   int wgs;           // G (0 = schedule not used)
+  int qb;            // queries per unit: 128 (4-wave workgroups, G = 512) or 256 (8-wave workgroups, G = 256)
   int full;          // whole units per workgroup
   int nlev;          // levels in use
   int k[6];          // level: units are cut into 2^k key ranges
@@ -62,8 +63,12 @@ struct attn3_sk_plan {
   int slot[6];       // first partial slot of the level (+ virtual workgroup id)
 };
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __restrict__ Q, int ldq,
+// NW = waves per workgroup: 4 (128 queries per unit, two workgroups per CU) or 8 (256 queries per unit, one workgroup per
+// CU, used with the stream-K schedule): the 32 KiB of K / V per tile are then staged once for eight waves instead of
+// twice for four each - half the LDS-DMA pieces per wave and per MFMA (the vector-memory path takes ~16 clocks per 1 KiB
+// piece and every piece cost its issuing wave ~115 clocks in the in-kernel stamps).
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* __restrict__ Q, int ldq,
                                                            const uint16_t* __restrict__ Kall, int ldk,
                                                            const uint16_t* __restrict__ Vall, int ldv,
                                                            uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
@@ -75,7 +80,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
   const int nt_all = (S_all + KT3 - 1) / KT3;
-  const int nqb = (R + 127) / 128;
+  constexpr int QB = 32 * NW;                                 // queries per unit
+  constexpr int NPW = 16 / NW;                                // K (and V) pieces of a tile this wave stages: 4 or 2
+  const int nqb = (R + QB - 1) / QB;
+  const int w4 = wave & 3, wq = wave >> 2;                    // piece j of this wave = rows 16 (wq + (NW/4) j) + 4 w4 + ..
 
   // ---- schedule.  Levelled stream-K: XCD x owns the virtual ids [x G/8, (x+1) G/8), i.e. contiguous units of the
   // head-major order - its L2 holds the K / V of ~H/8 heads, and the 2^k workgroups that share a unit sit on one XCD.
@@ -107,10 +115,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
       out_kind = 2;
       sk_slot = lslot + sk_v;
       if (nt == 0) {                                           // fewer key tiles than pieces: a neutral partial (weight 0)
-        float* pp = Opart + ((size_t)sk_slot * 128 + wave * 32 + r) * HD3 + 64 * hh;
+        float* pp = Opart + ((size_t)sk_slot * QB + wave * 32 + r) * HD3 + 64 * hh;
 #pragma unroll
         for (int g = 0; g < 16; ++g) *(f32x4*)(pp + 4 * g) = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (hh == 0) lse_part[(size_t)sk_slot * 128 + wave * 32 + r] = -INFINITY;
+        if (hh == 0) lse_part[(size_t)sk_slot * QB + wave * 32 + r] = -INFINITY;
         continue;
       }
     }
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
   const uint16_t* K = Kall + (size_t)t_lo * KT3 * ldk;
   const uint16_t* V = Vall + (size_t)t_lo * KT3 * ldv;
   const int S = (S_all - t_lo * KT3 < nt * KT3) ? S_all - t_lo * KT3 : nt * KT3;      // keys of this segment
-  const int q0 = qblk * 128 + wave * 32;
+  const int q0 = qblk * QB + wave * 32;
 
   // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0+r][h*128 + 16ks + 8hh + 0..7]
   typename T::vec8 qf[8];
@@ -149,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
   // form - `global_load_lds` with 64-bit lane addresses rebuilt by VALU for every piece, scalars reloaded from spill
   // lanes - showed 980 of a wave's 3 700 clocks per tile going into ISSUING the eight DMAs.)  The descriptor ends after
   // the last valid row: rows past S of a ragged last tile read as zeros (they are masked to -inf / multiplied by p = 0).
-  const int drow = 4 * wave + (lane >> 4);                    // + 16 i
-  const int dch = (lane & 15) ^ (((lane >> 4) << 2) | wave);
+  const int drow = 4 * w4 + (lane >> 4);                      // + 16 i
+  const int dch = (lane & 15) ^ (((lane >> 4) << 2) | w4);
   auto head_rsrc = [&](const uint16_t* base, int ld) {
     const uintptr_t a = (uintptr_t)(base + h * HD3);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
@@ -162,24 +170,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
   // lane offsets (bytes) of the four pieces of a tile: loop-invariant VGPRs (registers the kernel has to spare - scalar
   // registers it has not: with per-piece scalar offsets and LDS addresses hoisted out of the loop the compiler spilled
   // 64 SGPRs to vector lanes and read 38 of them back per tile)
-  int koff[4], voff[4];
+  int koff[4], voff[4];   // (4, not NPW: hipcc drops the HOST stub of a kernel whose lambdas take value-dependent array refs)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    koff[i] = ((drow + 16 * i) * ldk + dch * 8) * 2;
-    voff[i] = ((drow + 16 * i) * ldv + dch * 8) * 2;
+  for (int j = 0; j < NPW; ++j) {
+    const int i = wq + (NW / 4) * j;
+    koff[j] = ((drow + 16 * i) * ldk + dch * 8) * 2;
+    voff[j] = ((drow + 16 * i) * ldv + dch * 8) * 2;
   }
-  const unsigned lds_wave = (unsigned)(uintptr_t)(MAVLM_LDS char*)smem + wave * 1024;     // + slot + i * 4096
+  const unsigned lds_wave = (unsigned)(uintptr_t)(MAVLM_LDS char*)smem + w4 * 1024 + wq * 4096;   // + slot + j * 4096 * NW/4
   // piece i (0..3) of the tile at scalar byte offset `toff`: rows 16 i .. 16 i + 15.  A tile past the last one lies
   // entirely behind the descriptor's end: issuing it writes zeros into a slot nobody reads again, so the steady-state loop
   // needs no "is there a next tile" branch.
-  auto dma_piece = [&](__amdgpu_buffer_rsrc_t rs, const int (&off)[4], int toff, int slot_off, int i) {
+  auto dma_piece = [&](__amdgpu_buffer_rsrc_t rs, const int (&off)[4], int toff, int slot_off, int j) {
     unsigned base = lds_wave;
     asm volatile("" : "+s"(base));            // keep M0 = base + constant a one-instruction recompute (no hoisting)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (MAVLM_LDS void*)(uintptr_t)(base + slot_off + i * 4096), 16, off[i], toff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (MAVLM_LDS void*)(uintptr_t)(base + slot_off + j * (NW / 4) * 4096), 16, off[j],
+                                             toff, 0, 0);
   };
   auto dma_tile = [&](__amdgpu_buffer_rsrc_t rs, const int (&off)[4], int ld, int t, int slot_off) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_piece(rs, off, t * KT3 * ld * 2, slot_off, i);
+    for (int j = 0; j < NPW; ++j) dma_piece(rs, off, t * KT3 * ld * 2, slot_off, j);
   };
   char* const kbuf = smem;                 // K slots at 0, TILE3
   char* const vbuf = smem + 2 * TILE3;     // V slots at 2*TILE3, 3*TILE3
@@ -327,8 +337,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
         static_assert(KPF <= 6, "extend the wait table");
         __builtin_amdgcn_sched_barrier(0);                    // keep the MFMA below the wait (rule 18)
         st[N][i & 1] = T::mfma32(__builtin_bit_cast(typename T::vec8, kfr[i]), qf[i >> 1], st[N][i & 1]);
-        if constexpr ((i & 1) == 0 && i < 8) dma_piece(krs, koff, ktile, P * TILE3, i >> 1);
-        if constexpr ((i & 1) == 0 && i >= 8) dma_piece(vrs, voff, vtile, (2 + N) * TILE3, (i >> 1) - 4);
+        constexpr int GAP = 8 / NPW;                          // one piece per GAP steps: K in steps 0-7, V in steps 8-15
+        if constexpr (i % GAP == 0 && i < 8) dma_piece(krs, koff, ktile, P * TILE3, i / GAP);
+        if constexpr (i % GAP == 0 && i >= 8) dma_piece(vrs, voff, vtile, (2 + N) * TILE3, (i - 8) / GAP);
         constexpr int e0 = 2 * i, e1 = 2 * i + 1;             // elements (b = e>>4, idx = e&15) of tile t
         // The two empty asm statements are ordered against sched_barrier (both have side effects); the pure
         // fma/exp between them cannot be hoisted in front of the MFMA chain or sunk behind it.
@@ -428,9 +439,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
 
     // reference maximum for tile t+1 (after P.V(t): the rescale touches O)
     if (has_next) {
-      mx = xhalf_max(mx);
-      const float m_new = fmaxf(m_run, mx);
-      if (__any((m_new - m_run) * c > RESCALE3_LOG2)) {
+      // the decision needs no exchange between the two lane halves of a query row: the row maximum exceeds the threshold iff
+      // the maximum of one half does, and `__any` looks at all 64 lanes; the exchange sits in the (rare) rescale branch
+      if (__any((fmaxf(m_run, mx) - m_run) * c > RESCALE3_LOG2)) {
+        mx = xhalf_max(mx);
+        const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
         m_run = m_new;
         l_run *= alpha;
@@ -458,14 +471,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
   const float inv = 1.0f / l_tot;
   const int q = q0 + r;
   if (out_kind == 2) {                                        // stream-K partial: [slot][128 rows][128] + [slot][128]
-    float* pp = Opart + ((size_t)sk_slot * 128 + wave * 32 + r) * HD3 + 4 * hh;
+    float* pp = Opart + ((size_t)sk_slot * QB + wave * 32 + r) * HD3 + 4 * hh;
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *(f32x4*)(pp + 32 * db + 8 * g) = f32x4{ot[db][4 * g] * inv, ot[db][4 * g + 1] * inv, ot[db][4 * g + 2] * inv,
                                                 ot[db][4 * g + 3] * inv};
-    if (hh == 0) lse_part[(size_t)sk_slot * 128 + wave * 32 + r] = m_run * c + log2f(l_tot);
+    if (hh == 0) lse_part[(size_t)sk_slot * QB + wave * 32 + r] = m_run * c + log2f(l_tot);
   } else if (q < R) {
     if (out_kind == 1) {
       float* pp = Opart + ((size_t)split * R + q) * (H * HD3) + h * HD3 + 4 * hh;
@@ -490,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
   }   // segment loop (every tile iteration ends with a barrier: the LDS slots are free for the next segment's prologue)
 }
 
-// Stream-K merge: four workgroups per cut unit (32 query rows each).  Unit `ul` of level j (cut into 2^k key ranges) has its partials in the slots
+// Stream-K merge: one workgroup per 32 query rows of a cut unit (QB = 128 or 256 rows).  Unit `ul` of level j (cut into 2^k key ranges) has its partials in the slots
 // plan.slot[j] + (ul << k) + p, p = 0 .. 2^k - 1 in key order: O = sum_p w_p O_p, w_p = 2^(lse_p - lse), lse = log2 sum_p
 // 2^lse_p (an empty range carries lse = -inf: weight 0).  A 512-byte partial row = 32 lanes x 16 bytes: a wave-instruction
 // covers two whole rows, the workgroup eight.
@@ -500,16 +513,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(const uint16_t* __res
 template <typename T, int NP>
 __device__ __forceinline__ void combine_sk_rows(const float* __restrict__ Opart, const float* __restrict__ lse_part, size_t s0,
                                                 uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2, int R, int h, int qblk,
-                                                int quarter) {
+                                                int quarter, int QB) {
   const int c4 = threadIdx.x & 31, rsub = threadIdx.x >> 5;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {                             // a workgroup merges 32 of the unit's 128 rows
     const int row = quarter * 32 + it * 8 + rsub;
-    const int q = qblk * 128 + row;
+    const int q = qblk * QB + row;
     if (q >= R) continue;
     float l[NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) l[p] = lse_part[(s0 + p) * 128 + row];
+    for (int p = 0; p < NP; ++p) l[p] = lse_part[(s0 + p) * QB + row];
     float mx = l[0];
 #pragma unroll
     for (int p = 1; p < NP; ++p) mx = fmaxf(mx, l[p]);
@@ -523,7 +536,7 @@ __device__ __forceinline__ void combine_sk_rows(const float* __restrict__ Opart,
     for (int p0 = 0; p0 < NP; p0 += CH) {
       f32x4 a[CH];
 #pragma unroll
-      for (int j = 0; j < CH; ++j) a[j] = *(const f32x4*)(Opart + ((s0 + p0 + j) * 128 + row) * HD3 + 4 * c4);
+      for (int j = 0; j < CH; ++j) a[j] = *(const f32x4*)(Opart + ((s0 + p0 + j) * QB + row) * HD3 + 4 * c4);
 #pragma unroll
       for (int j = 0; j < CH; ++j) {                           // key order
         const float w = __builtin_amdgcn_exp2f(l[p0 + j] - lse);
@@ -538,9 +551,10 @@ __device__ __forceinline__ void combine_sk_rows(const float* __restrict__ Opart,
 template <typename T>
 __global__ __launch_bounds__(256) void attn_combine_sk_kernel(const float* __restrict__ Opart, const float* __restrict__ lse_part,
                                                               uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
-                                                              int R, int H, attn3_sk_plan plan) {
-  int b = blockIdx.x >> 2, lk = 0, lbase = 0, lslot = 0;       // four workgroups per cut unit
-  const int quarter = blockIdx.x & 3;
+                                                              int R, int H, attn3_sk_plan plan, int QB) {
+  const int wpu = QB / 32;                                     // workgroups per cut unit (32 query rows each)
+  int b = blockIdx.x / wpu, lk = 0, lbase = 0, lslot = 0;
+  const int quarter = blockIdx.x - b * wpu;
   bool found = false;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -550,16 +564,16 @@ __global__ __launch_bounds__(256) void attn_combine_sk_kernel(const float* __res
     }
   }
   if (!found) return;
-  const int nqb = (R + 127) / 128;
+  const int nqb = (R + QB - 1) / QB;
   const int u = lbase + b;
   const int h = u / nqb, qblk = u - h * nqb;
   const size_t s0 = (size_t)lslot + ((size_t)b << lk);
   switch (lk) {
-    case 1: combine_sk_rows<T, 2>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter); break;
-    case 2: combine_sk_rows<T, 4>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter); break;
-    case 3: combine_sk_rows<T, 8>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter); break;
-    case 4: combine_sk_rows<T, 16>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter); break;
-    default: combine_sk_rows<T, 32>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter); break;
+    case 1: combine_sk_rows<T, 2>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter, QB); break;
+    case 2: combine_sk_rows<T, 4>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter, QB); break;
+    case 3: combine_sk_rows<T, 8>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter, QB); break;
+    case 4: combine_sk_rows<T, 16>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter, QB); break;
+    default: combine_sk_rows<T, 32>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter, QB); break;
   }
 }
 
@@ -643,14 +657,16 @@ int mavlm_attention_splits(int R, int S, int H, int* tiles_per_split) {
 // G/16 units) goes into one or two 32-way levels.  Pure function of the shape (mirrored by oracle/memory_path.py).
 constexpr int ATTN3_SK_WGS = 512;
 int g_mavlm_attn_sk_min_tiles = 64;          // tuning / test hook (mavlm_set_attention_streamk_min_tiles)
-static attn3_sk_plan attn3_plan(int R, int S, int H) {
+int g_mavlm_attn_sk_waves = 0;                // tuning hook: 0 = automatic, 4 / 8 = waves per stream-K workgroup
+static attn3_sk_plan attn3_plan_for(int R, int S, int H, int waves) {
   attn3_sk_plan p = {};
-  const long units = (long)((R + 127) / 128) * H;
-  const int G = ATTN3_SK_WGS;
+  const int QB = 32 * waves, G = ATTN3_SK_WGS * 4 / waves;    // 512 four-wave or 256 eight-wave workgroups fill 256 CUs
+  const long units = (long)((R + QB - 1) / QB) * H;
   if (units <= G || (S + KT3 - 1) / KT3 < g_mavlm_attn_sk_min_tiles) return p;
   const long rounds = (units + G - 1) / G;
   if ((double)units / (double)(rounds * G) >= 0.95) return p;
   p.wgs = G;
+  p.qb = QB;
   p.full = (int)(units / G);
   int rem = (int)(units % G), base = p.full * G, slot = 0;
   for (int k = 1; k <= 4; ++k)
@@ -665,14 +681,49 @@ static attn3_sk_plan attn3_plan(int R, int S, int H) {
   }
   return p;
 }
+static attn3_sk_plan attn3_plan(int R, int S, int H) {
+  if (g_mavlm_attn_sk_waves != 4) {
+    const attn3_sk_plan p8 = attn3_plan_for(R, S, H, 8);
+    if (p8.wgs > 0 || g_mavlm_attn_sk_waves == 8) return p8;
+  }
+  return attn3_plan_for(R, S, H, 4);
+}
 int mavlm_attention_streamk_wgs(int R, int S, int H) { return attn3_plan(R, S, H).wgs; }
 
 size_t mavlm_attention_split_ws_floats(int R, int S, int H) {
   const attn3_sk_plan pl = attn3_plan(R, S, H);
-  if (pl.wgs > 0) return (size_t)pl.wgs * pl.nlev * (128 * HD3 + 128);
+  if (pl.wgs > 0) return (size_t)pl.wgs * pl.nlev * ((size_t)pl.qb * HD3 + pl.qb);
   const int ns = mavlm_attention_splits(R, S, H, nullptr);
   return ns > 1 ? (size_t)ns * R * H * HD3 + (size_t)ns * H * R : 0;
 }
+
+namespace {
+struct attn3_launch_args {
+  dim3 grid;
+  float c;
+  float* opart;
+  float* lpart;
+  int tps, ns, cut_units;
+  attn3_sk_plan plan;
+};
+template <typename T, int NW>
+hipError_t attn3_launch(const mavlm_attn_args& a, const attn3_launch_args& la, hipStream_t s) {
+  auto kern = attn_fwd3_kernel<T, NW>;
+  static mavlm_per_device_once once;
+  hipError_t e = once.dyn_lds((const void*)kern, ATTN3_LDS);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, la.grid, dim3(64 * NW), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K, a.ldk,
+                     (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, la.c, la.opart, la.lpart, la.tps,
+                     la.plan);
+  if (la.plan.wgs > 0 && la.cut_units > 0)
+    hipLaunchKernelGGL(attn_combine_sk_kernel<T>, dim3(la.cut_units * (la.plan.qb / 32)), dim3(256), 0, s, la.opart, la.lpart,
+                       (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.H, la.plan, la.plan.qb);
+  else if (la.ns > 1)
+    hipLaunchKernelGGL(attn_combine_kernel<T>, dim3((a.R + 3) / 4), dim3(256), 0, s, la.opart, la.lpart, (uint16_t*)a.O, a.ldo,
+                       a.lse2, a.R, a.H, HD3, la.ns);
+  return hipGetLastError();
+}
+}  // namespace
 
 hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStream_t s) {
   // K / V are addressed through 32-bit buffer offsets (one descriptor per head): the key block must span < 4 GiB
@@ -691,39 +742,14 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
   if (ns <= 1) { ns = 1; tps = 0; }
   float* opart = a.split_ws;
   float* lpart = nullptr;
-  if (skg > 0) lpart = a.split_ws + (size_t)skg * plan.nlev * 128 * HD3;
+  if (skg > 0) lpart = a.split_ws + (size_t)skg * plan.nlev * plan.qb * HD3;
   else if (ns > 1) lpart = a.split_ws + (size_t)ns * a.R * a.H * HD3;
   const int units = ((a.R + 127) / 128) * a.H;
   const dim3 grid(skg > 0 ? skg : units, skg > 0 ? 1 : ns);
-  static mavlm_per_device_once once[2];
-  if (dtype == MAVLM_F16) {
-    {
-      hipError_t e = once[1].dyn_lds((const void*)attn_fwd3_kernel<F16>, ATTN3_LDS);
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(attn_fwd3_kernel<F16>, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
-                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps, plan);
-    if (skg > 0 && cut_units > 0)
-      hipLaunchKernelGGL(attn_combine_sk_kernel<F16>, dim3(4 * cut_units), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
-                         a.lse2, a.R, a.H, plan);
-    else if (ns > 1)
-      hipLaunchKernelGGL(attn_combine_kernel<F16>, dim3((a.R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
-                         a.lse2, a.R, a.H, HD3, ns);
-  } else {
-    {
-      hipError_t e = once[0].dyn_lds((const void*)attn_fwd3_kernel<BF16>, ATTN3_LDS);
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(attn_fwd3_kernel<BF16>, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
-                       a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, opart, lpart, tps, plan);
-    if (skg > 0 && cut_units > 0)
-      hipLaunchKernelGGL(attn_combine_sk_kernel<BF16>, dim3(4 * cut_units), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
-                         a.lse2, a.R, a.H, plan);
-    else if (ns > 1)
-      hipLaunchKernelGGL(attn_combine_kernel<BF16>, dim3((a.R + 3) / 4), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
-                         a.lse2, a.R, a.H, HD3, ns);
-  }
-  return hipGetLastError();
+  const bool w8 = skg > 0 && plan.qb == 256;
+  const attn3_launch_args la = {grid, c, opart, lpart, tps, ns, cut_units, plan};
+  if (dtype == MAVLM_F16) return w8 ? attn3_launch<F16, 8>(a, la, s) : attn3_launch<F16, 4>(a, la, s);
+  return w8 ? attn3_launch<BF16, 8>(a, la, s) : attn3_launch<BF16, 4>(a, la, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------

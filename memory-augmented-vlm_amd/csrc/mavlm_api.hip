@@ -176,10 +176,15 @@ int mavlm_set_gemm_tile(int32_t tile) {
   return 0;
 }
 
-extern int g_mavlm_attn_sk_min_tiles;
+extern int g_mavlm_attn_sk_min_tiles, g_mavlm_attn_sk_waves;
 int mavlm_set_attention_streamk_min_tiles(int32_t tiles) {
   if (tiles < 1) return MAVLM_E_ARG;
   g_mavlm_attn_sk_min_tiles = tiles;
+  return 0;
+}
+int mavlm_set_attention_streamk_waves(int32_t waves) {
+  if (waves != 0 && waves != 4 && waves != 8) return MAVLM_E_ARG;
+  g_mavlm_attn_sk_waves = waves;
   return 0;
 }
 

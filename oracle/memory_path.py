@@ -354,16 +354,17 @@ STREAMK_WGS = 512     # persistent workgroups of the stream-K schedule (csrc/att
 STREAMK_MIN_TILES = 64   # ... used from this many 64-key tiles per unit (mavlm_set_attention_streamk_min_tiles)
 
 
-def streamk_plan(R: int, S: int, heads: int):
-    """Mirrors attn3_plan (csrc/attention3.hip): (G, full, levels) with levels = [(k, first unit, units)] - after `full`
-    whole units per workgroup the remaining units are cut into 2^k equal key ranges, level by level; G = 0: not used."""
-    units = -(-R // 128) * heads
-    G = STREAMK_WGS
+STREAMK_WAVES = 0         # 0 = automatic (8-wave workgroups where their plan applies, else 4); mavlm_set_attention_streamk_waves
+
+
+def _streamk_plan_for(R: int, S: int, heads: int, waves: int):
+    QB, G = 32 * waves, STREAMK_WGS * 4 // waves
+    units = -(-R // QB) * heads
     if units <= G or -(-S // KV_TILE) < STREAMK_MIN_TILES:
-        return 0, 0, []
+        return 0, QB, 0, []
     rounds = -(-units // G)
     if units / (rounds * G) >= 0.95:
-        return 0, 0, []
+        return 0, QB, 0, []
     full, rem = divmod(units, G)
     base, levels = full * G, []
     for k in range(1, 5):
@@ -376,28 +377,39 @@ def streamk_plan(R: int, S: int, heads: int):
         levels.append((5, base, n))
         base += n
         rem -= n
-    return G, full, levels
+    return G, QB, full, levels
+
+
+def streamk_plan(R: int, S: int, heads: int):
+    """Mirrors attn3_plan (csrc/attention3.hip): (G, queries per unit, full, levels) with levels = [(k, first unit, units)]
+    - after `full` whole units per workgroup the remaining units are cut into 2^k equal key ranges, level by level; G = 0:
+    not used.  Units are 256-query blocks (8-wave workgroups, G = 256) where that plan applies, else 128 (G = 512)."""
+    if STREAMK_WAVES != 4:
+        p8 = _streamk_plan_for(R, S, heads, 8)
+        if p8[0] or STREAMK_WAVES == 8:
+            return p8
+    return _streamk_plan_for(R, S, heads, 4)
 
 
 def streamk_wgs(R: int, S: int, heads: int) -> int:
     return streamk_plan(R, S, heads)[0]
 
 
-def streamk_split_tiles(R: int, S: int, heads: int) -> Dict[Tuple[int, int], List[Tuple[int, int]]]:
-    """{(head, query block): [(tile_lo, tile_hi), ...]} for the units the levelled stream-K schedule cuts: their keys are
-    processed as 2^k ranges with independent online-softmax states and merged in key order like split-KV partials (empty
-    ranges - fewer tiles than pieces - dropped).  Unit order: head-major, then query block (attn_fwd3_kernel)."""
-    G, _, levels = streamk_plan(R, S, heads)
+def streamk_split_tiles(R: int, S: int, heads: int):
+    """(queries per unit, {(head, query block): [(tile_lo, tile_hi), ...]}) for the units the levelled stream-K schedule
+    cuts: their keys are processed as 2^k ranges with independent online-softmax states and merged in key order like
+    split-KV partials (empty ranges - fewer tiles than pieces - dropped).  Unit order: head-major, then query block."""
+    G, QB, _, levels = streamk_plan(R, S, heads)
     out: Dict[Tuple[int, int], List[Tuple[int, int]]] = {}
     if not G:
-        return out
-    nqb, nt = -(-R // 128), -(-S // KV_TILE)
+        return QB, out
+    nqb, nt = -(-R // QB), -(-S // KV_TILE)
     for k, base, n in levels:
         for ul in range(n):
             u = base + ul
             rng = [((p * nt) >> k, ((p + 1) * nt) >> k) for p in range(1 << k)]
             out[(u // nqb, u % nqb)] = [(a, b) for a, b in rng if b > a]
-    return out
+    return QB, out
 
 
 def split_plan_wide(R: int, S: int, heads: int) -> Tuple[int, int]:
@@ -525,7 +537,8 @@ def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mo
             sk_cuts = {}
             if kv_tile == KV_TILE:            # attention3.hip (head_dim <= 128)
                 ns, tps = split_plan(plan_rows or R, Lk, heads)
-                sk_cuts = {qb: a for (hh_, qb), a in streamk_split_tiles(plan_rows or R, Lk, heads).items() if hh_ == h}
+                sk_qb, sk_all = streamk_split_tiles(plan_rows or R, Lk, heads)
+                sk_cuts = {qb: a for (hh_, qb), a in sk_all.items() if hh_ == h}
                 if streamk_wgs(plan_rows or R, Lk, heads):
                     ns, tps = 1, 0
             elif kv_tile == 32:               # attention_hd.hip
@@ -539,7 +552,7 @@ def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mo
                 cut = np.zeros(R, dtype=np.int64)              # 0 = not cut, else 1 + index into `plans`
                 plans = []
                 for qb, rng in sk_cuts.items():
-                    lo_, hi_ = qb * 128 - row0, (qb + 1) * 128 - row0
+                    lo_, hi_ = qb * sk_qb - row0, (qb + 1) * sk_qb - row0
                     if hi_ <= 0 or lo_ >= R:
                         continue
                     if rng not in plans:

@@ -21,10 +21,12 @@ for n in (0.5, 1, 2, 5, 10):
     kv = torch.randn(S, 2 * D, device="cuda").bfloat16()
     res = {}
     for rnd in range(2):
-        for name, mt in (("plain", 1 << 30), ("stream-K", 64)):
+        for name, mt, wv in (("plain", 1 << 30, 0), ("sk4", 64, 4), ("sk8", 64, 8)):
             lib.mavlm_set_attention_streamk_min_tiles(mt)
+            lib.mavlm_set_attention_streamk_waves(wv)
             us = t(lambda: ops.attention(q, kv[:, :D], kv[:, D:], H))
             res.setdefault(name, []).append(us)
     fl = 4.0 * R * S * D
-    print(f"S={S:7d}: " + "  ".join(f"{k} {min(v):9.1f} us {fl / min(v) / 1e6:7.1f} TF" for k, v in res.items()), flush=True)
+    print(f"S={S:7d}: " + "  ".join(f"{k} {min(v):8.1f} us {fl / min(v) / 1e6:6.1f} TF" for k, v in res.items()), flush=True)
 lib.mavlm_set_attention_streamk_min_tiles(64)
+lib.mavlm_set_attention_streamk_waves(0)

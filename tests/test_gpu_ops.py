@@ -195,8 +195,9 @@ def test_attention_split_kv_small_grids(mode, R, S, H):
                                   ops.dtype_code(dq.dtype), ops.stream_ptr()) == capi.E_ARG
 
 
+@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("mode,R,S,H", [("bf16", 8320, 256, 8), ("fp16", 8330, 200, 8), ("bf16", 1100, 64 * 9 + 5, 64)])
-def test_attention_stream_k_more_units_than_slots(mode, R, S, H, monkeypatch, request):
+def test_attention_stream_k_more_units_than_slots(mode, R, S, H, waves, monkeypatch, request):
     """More units (128-query blocks x heads) than the chip's 512 workgroup slots (the bench shape: 784): 512 persistent
     workgroups each own an equal range of the global key-tile sequence, the units a range boundary cuts are computed as
     head + tail partials and merged (attn_combine_sk_kernel).  The oracle mirrors the cuts (streamk_split_tiles): same
@@ -204,10 +205,12 @@ def test_attention_stream_k_more_units_than_slots(mode, R, S, H, monkeypatch, re
     lib = capi.lib()
     assert lib.mavlm_attention_ws_floats(12544, 63 * 64, 8) == 0 and lib.mavlm_attention_ws_floats(12544, 6272, 8) > 0
     capi.check(lib.mavlm_set_attention_streamk_min_tiles(1), "min tiles")     # (the default, 64 tiles, needs S > 4032)
+    capi.check(lib.mavlm_set_attention_streamk_waves(waves), "waves")           # 4: 512 workgroups x 128 queries, 8: 256 x 256
     monkeypatch.setattr(O, "STREAMK_MIN_TILES", 1)
-    request.addfinalizer(lambda: lib.mavlm_set_attention_streamk_min_tiles(64))
+    monkeypatch.setattr(O, "STREAMK_WAVES", waves)
+    request.addfinalizer(lambda: (lib.mavlm_set_attention_streamk_min_tiles(64), lib.mavlm_set_attention_streamk_waves(0)))
     assert lib.mavlm_attention_ws_floats(R, S, H) % (512 * (128 * 128 + 128)) == 0 and lib.mavlm_attention_ws_floats(R, S, H) > 0
-    assert O.streamk_wgs(R, S, H) == 512 and len(O.streamk_split_tiles(R, S, H)) >= 8
+    assert O.streamk_wgs(R, S, H) == 2048 // waves and len(O.streamk_split_tiles(R, S, H)[1]) >= 8
     r = O.rounder(mode)
     q = r(O.hash_normal_like((R, H * 128), 31))
     k = r(O.hash_normal_like((S, H * 128), 32))
