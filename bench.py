@@ -413,6 +413,14 @@ def run_replica(args, rank, world, local, device, dist_info):
         lib.mavlm_prof_enable(0)
     dom = "attention_fwd"
     di = capi.KERNEL_KINDS.index(dom)
+    info = (ctypes.c_int32 * 4)()       # which instantiation the plan picks at the formation shape (S = one chunk's keys)
+    capi.check(lib.mavlm_attention_plan(MEM_TOKENS * PATCHES, 32 * PATCHES, HEADS, info), "mavlm_attention_plan")
+    kname = f"attn_fwd3_kernel<BF16, {info[0]}>"
+    mi = capi.KERNEL_KINDS.index("attention_merge")
+    knote = ("HIP-event bracket around this kernel only (all its launches of a step: formation and evolution shapes); "
+             + (f"schedule: levelled stream-K, {info[1]} workgroups of {info[0]} waves, {info[2]} level(s); its merge kernel "
+                f"attn_combine_sk_kernel<BF16> is bracketed separately: {ms[mi] / max(ln[mi], 1) * 1e3:.1f} us per launch "
+                "(kernels.attention_merge)" if info[1] else "plain grid"))
     achieved = fl[di] / (ms[di] * 1e-3) / 1e12
     traffic, tnote = None, None
     for tp in ("r02_attn_fwd_hbm_traffic.json", "r01_attn_fwd3_hbm_traffic.json"):
@@ -424,7 +432,7 @@ def run_replica(args, rank, world, local, device, dist_info):
             break
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": tnote,
-                "kernel": capi.attention_kernel_name() if hasattr(capi, "attention_kernel_name") else "attn_fwd3_kernel<BF16>",
+                "kernel": kname, "kernel_note": knote,
                 "avg_launch_ms": round(ms[di] / ln[di], 5), "launches_per_step": ln[di] / args.steps,
                 "alg_flops_per_launch": fl[di] / ln[di], "alg_bytes_per_launch": by[di] / ln[di],
                 "hbm_gbs_algorithmic": round(by[di] / (ms[di] * 1e-3) / 1e9, 1)}

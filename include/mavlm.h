@@ -137,11 +137,18 @@ int64_t mavlm_linear_ws_floats(int32_t M, int32_t N, int32_t K, int32_t epilogue
 int mavlm_linear_ws(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const void* res, int32_t ldr,
                     void* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue, float* ws, int64_t ws_floats,
                     int32_t dtype, void* stream);
-/* As mavlm_attention, with the split-KV path for grids too small to fill the chip (ceil(R/128)*H < 320 workgroups,
- * e.g. the reference's default 8 memory tokens): the keys are split over up to 8 workgroup planes that write normalised
- * fp32 partials into `ws` (mavlm_attention_ws_floats(R,S,H) floats; 0 = this shape does not split), a second kernel
- * merges them.  The plan is a pure function of (R,S,H) - mavlm_step uses the same one, so both produce the same bits. */
+/* As mavlm_attention, with the two scheduled forms that need a workspace `ws` of mavlm_attention_ws_floats(R,S,H) floats
+ * (0 = this shape runs the plain grid):
+ *   - split-KV for grids too small to fill the chip (ceil(R/128)*H < 320 workgroups, e.g. the reference's default 8
+ *     memory tokens): the keys are split over up to 8 workgroup planes;
+ *   - the levelled stream-K schedule for grids with more units than resident workgroups and >= 64 key tiles (DESIGN.md
+ *     section 4.2): whole units first, then the remainder in binary levels whose units are cut into 2^k key ranges.
+ * Both write normalised fp32 partials + their log-sum-exp into `ws`, a second kernel merges them.  The plan is a pure
+ * function of (R,S,H) - mavlm_step uses the same one, so both produce the same bits; mavlm_attention_plan reports it:
+ * info[0] = waves per workgroup (4 | 8), info[1] = stream-K workgroups (0 = not scheduled), info[2] = levels,
+ * info[3] = split-KV planes (1 = none). */
 int64_t mavlm_attention_ws_floats(int32_t R, int32_t S, int32_t H);
+int mavlm_attention_plan(int32_t R, int32_t S, int32_t H, int32_t info[4]);
 int mavlm_attention_ws(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                        int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, float* ws,
                        int64_t ws_floats, int32_t dtype, void* stream);
@@ -256,9 +263,9 @@ int mavlm_set_attention_streamk_waves(int32_t waves);
 /* --- measurement hooks (bench.py only; new - the reference has no profiling) ------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on its own stream.  Kinds: 0 GEMM, 1 attention
  * forward, 2 attention column-sum, 3 LayerNorm (forward and backward), 4 row-add, 5 misc, 6 attention backward,
- * 7 split-K GEMM, 8 transpose.  Not re-entrant, not graph-capturable. */
+ * 7 split-K GEMM, 8 transpose, 9 attention merge (split-KV / stream-K partials).  Not re-entrant, not graph-capturable. */
 int mavlm_prof_enable(int32_t on);
-/* host arrays of length nkinds >= 9: total milliseconds, launches, algorithmic flops, algorithmic bytes per kind */
+/* host arrays of length nkinds >= 10: total milliseconds, launches, algorithmic flops, algorithmic bytes per kind */
 int mavlm_prof_read(double* ms, int64_t* launches, double* flops, double* bytes, int32_t nkinds);
 
 #ifdef __cplusplus

@@ -90,6 +90,7 @@ SIGNATURES = {
     "mavlm_set_gemm_tile": (C.c_int, [i32]),
     "mavlm_set_gemm_rows": (C.c_int, [i32]),
     "mavlm_set_attention_impl": (C.c_int, [i32]),
+    "mavlm_attention_plan": (C.c_int, [i32, i32, i32, C.POINTER(i32)]),
     "mavlm_set_attention_streamk_min_tiles": (C.c_int, [i32]),
     "mavlm_set_attention_streamk_waves": (C.c_int, [i32]),
     "mavlm_prof_enable": (C.c_int, [i32]),
@@ -98,7 +99,7 @@ SIGNATURES = {
 }
 
 KERNEL_KINDS = ("gemm", "attention_fwd", "attention_colsum", "layernorm", "row_add", "misc", "attention_bwd",
-                "gemm_splitk", "transpose")
+                "gemm_splitk", "transpose", "attention_merge")
 
 _lib = None
 

@@ -409,9 +409,9 @@ hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream
     return hipErrorInvalidValue;
   const float c = a.scale * 1.44269504088896340736f;
   dim3 grid(((a.R + 127) / 128) * a.H);
+  if (g_mavlm_attn_impl != 2) return mavlm_launch_attention3(a, dtype, s);     // (brackets its kernels itself)
   mavlm_prof_scope prof(MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD,
                         2.0 * HD * a.H * (2.0 * a.R + 2.0 * a.S), s);
-  if (g_mavlm_attn_impl != 2) return mavlm_launch_attention3(a, dtype, s);
   return launch_attention2(a, dtype, s, c, grid);
 }
 

@@ -689,6 +689,14 @@ static attn3_sk_plan attn3_plan(int R, int S, int H) {
   return attn3_plan_for(R, S, H, 4);
 }
 int mavlm_attention_streamk_wgs(int R, int S, int H) { return attn3_plan(R, S, H).wgs; }
+void mavlm_attention_plan_info(int R, int S, int H, int info[4]) {
+  const attn3_sk_plan pl = attn3_plan(R, S, H);
+  info[0] = pl.wgs > 0 && pl.qb == 256 ? 8 : 4;
+  info[1] = pl.wgs;
+  info[2] = pl.nlev;
+  info[3] = pl.wgs > 0 ? 1 : mavlm_attention_splits(R, S, H, nullptr);
+  if (info[3] < 1) info[3] = 1;
+}
 
 size_t mavlm_attention_split_ws_floats(int R, int S, int H) {
   const attn3_sk_plan pl = attn3_plan(R, S, H);
@@ -712,9 +720,20 @@ hipError_t attn3_launch(const mavlm_attn_args& a, const attn3_launch_args& la, h
   static mavlm_per_device_once once;
   hipError_t e = once.dyn_lds((const void*)kern, ATTN3_LDS);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, la.grid, dim3(64 * NW), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K, a.ldk,
-                     (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, la.c, la.opart, la.lpart, la.tps,
-                     la.plan);
+  {  // (bench.py's instrumented pass: the main kernel and the merge are bracketed separately, so the main kernel's average
+     // is directly comparable with its line in a rocprofv3 summary)
+    mavlm_prof_scope prof(MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD3, 2.0 * HD3 * a.H * (2.0 * a.R + 2.0 * a.S), s);
+    hipLaunchKernelGGL(kern, la.grid, dim3(64 * NW), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K, a.ldk,
+                       (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, la.c, la.opart, la.lpart,
+                       la.tps, la.plan);
+  }
+  double parts = la.ns > 1 ? (double)la.ns * a.R * a.H : 0.0;      // fp32 partial rows the merge reads
+  if (la.plan.wgs > 0) {
+    parts = 0.0;
+    for (int j = 0; j < la.plan.nlev; ++j) parts += (double)la.plan.nun[j] * (1 << la.plan.k[j]) * la.plan.qb;
+  }
+  mavlm_prof_scope prof(la.plan.wgs > 0 ? (la.cut_units > 0 ? MAVLM_K_ATTN_MERGE : -1) : (la.ns > 1 ? MAVLM_K_ATTN_MERGE : -1),
+                        0.0, parts * 4.0 * (HD3 + 1), s);
   if (la.plan.wgs > 0 && la.cut_units > 0)
     hipLaunchKernelGGL(attn_combine_sk_kernel<T>, dim3(la.cut_units * (la.plan.qb / 32)), dim3(256), 0, s, la.opart, la.lpart,
                        (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.H, la.plan, la.plan.qb);

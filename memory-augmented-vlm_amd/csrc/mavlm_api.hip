@@ -420,6 +420,14 @@ int64_t mavlm_attention_ws_floats(int32_t R, int32_t S, int32_t H) {
   return (R > 0 && S > 0 && H > 0) ? (int64_t)mavlm_attention_split_ws_floats(R, S, H) : 0;
 }
 
+int mavlm_attention_plan(int32_t R, int32_t S, int32_t H, int32_t info[4]) {
+  if (!info || R <= 0 || S <= 0 || H <= 0) return MAVLM_E_ARG;
+  int v[4];
+  mavlm_attention_plan_info(R, S, H, v);
+  for (int i = 0; i < 4; ++i) info[i] = v[i];
+  return 0;
+}
+
 int mavlm_attention_ws(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                        int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, float* ws,
                        int64_t ws_floats, int32_t dtype, void* stream) {

@@ -50,6 +50,7 @@ hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream
 int mavlm_attention_splits(int R, int S, int H, int* tiles_per_split);
 // stream-K schedule of the head_dim-128 forward (more units than workgroup slots): persistent workgroups, 0 = not used
 int mavlm_attention_streamk_wgs(int R, int S, int H);
+void mavlm_attention_plan_info(int R, int S, int H, int info[4]);
 size_t mavlm_attention_split_ws_floats(int R, int S, int H);
 // the same for the wide-head kernel (attention_hd.hip) and the merge kernel both use (attention3.hip)
 int mavlm_attention_hd_splits(int R, int S, int H, int* tiles_per_split);
@@ -137,7 +138,7 @@ hipError_t mavlm_launch_pool_bilinear(const void* x, void* out, const void* tabl
 
 // ---- optional per-kernel HIP-event profiling (bench.py roofline line); off by default, zero cost when off.
 enum { MAVLM_K_GEMM = 0, MAVLM_K_ATTN = 1, MAVLM_K_COLSUM = 2, MAVLM_K_LN = 3, MAVLM_K_ROWADD = 4, MAVLM_K_MISC = 5,
-       MAVLM_K_ATTN_BWD = 6, MAVLM_K_GEMM_SPLITK = 7, MAVLM_K_TRANSPOSE = 8, MAVLM_K_COUNT = 9 };
+       MAVLM_K_ATTN_BWD = 6, MAVLM_K_GEMM_SPLITK = 7, MAVLM_K_TRANSPOSE = 8, MAVLM_K_ATTN_MERGE = 9, MAVLM_K_COUNT = 10 };
 struct mavlm_prof_scope {
   int slot;
   hipStream_t s;

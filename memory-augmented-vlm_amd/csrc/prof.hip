@@ -13,7 +13,7 @@ size_t g_used = 0;
 }  // namespace
 
 mavlm_prof_scope::mavlm_prof_scope(int kind, double flops, double bytes, hipStream_t stream) : slot(-1), s(stream) {
-  if (!g_on) return;
+  if (!g_on || kind < 0) return;
   if (g_used == g_pool.size()) {
     Rec r;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;

@@ -60,22 +60,35 @@ with open(os.path.join(dst, f"{tag}_mfma_utilisation.csv"), "w") as f:
                 continue
             f.write(f"\"{k}\",{grid},{busy:.0f},{cyc:.0f},{busy / 1024.0 / cyc:.3f}\n")
 
-fetch, write = counters("fetch"), counters("write")
+def ordered(sub, counter):
+    """{(kernel, grid): [values in dispatch order]} - tests/bench_ops.py attn runs all its S=6272 launches, then all its
+    S=12544 ones (the same number of each), and both shapes can share one grid: first half / second half."""
+    files = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
+    agg = collections.defaultdict(list)
+    for fn in files:
+        for r in csv.DictReader(open(fn)):
+            if r["Counter_Name"] == counter:
+                agg[(short(r["Kernel_Name"]), r.get("Grid_Size", ""))].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    return {k: [v for _, v in sorted(vs)] for k, vs in agg.items()}
+
+
+fetch, write = ordered("fetch", "FETCH_SIZE"), ordered("write", "WRITE_SIZE")
 shapes = {}
-for (k, grid), c in sorted(fetch.items()):
-    if "attn_fwd3_kernel" not in k or "FETCH_SIZE" not in c:
+for (k, grid), f_ in sorted(fetch.items()):
+    if "attn_fwd3_kernel" not in k:
         continue
-    f_ = c["FETCH_SIZE"]
-    w_ = write.get((k, grid), {}).get("WRITE_SIZE", [0.0])
-    for tag_, vals in (("lo", [v for v in f_ if v <= 1.2 * min(f_)]), ("hi", [v for v in f_ if v > 1.2 * min(f_)])):
-        if vals:
-            shapes[f"{k} grid {grid} ({'fewer' if tag_ == 'lo' else 'more'} keys)" if len(set(round(v / min(f_)) for v in f_)) > 1
-                   else f"{k} grid {grid}"] = {
-                "dispatches": len(vals), "FETCH_SIZE_KB": round(sum(vals) / len(vals), 1), "WRITE_SIZE_KB": round(sum(w_) / len(w_), 1),
-                "read_bytes_corrected": int(2 * 1024 * sum(vals) / len(vals)), "write_bytes": int(1024 * sum(w_) / len(w_))}
+    w_ = write.get((k, grid), [0.0] * len(f_))
+    two = len(f_) % 2 == 0 and len(f_) >= 2 and abs(sum(f_[len(f_) // 2:]) / max(sum(f_[:len(f_) // 2]), 1.0) - 1.0) > 0.2
+    parts = ((("S=6272", slice(0, len(f_) // 2)), ("S=12544", slice(len(f_) // 2, None))) if two else (("", slice(None)),))
+    for label, sl in parts:
+        fv, wv = f_[sl], (w_[sl] if len(w_) == len(f_) else w_)
+        shapes[f"{k} grid {grid} {label}".strip()] = {
+            "dispatches": len(fv), "FETCH_SIZE_KB": round(sum(fv) / len(fv), 1), "WRITE_SIZE_KB": round(sum(wv) / len(wv), 1),
+            "read_bytes_corrected": int(2 * 1024 * sum(fv) / len(fv)), "write_bytes": int(1024 * sum(wv) / len(wv))}
 if shapes:
     out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tests/profile_round.sh) on tests/bench_ops.py attn "
-                   "(R=12544, H=8: S=6272 on the plain grid of 784 workgroups, S=12544 on the stream-K grid of 512), KB per "
+                   "(R=12544, H=8, S=6272 and S=12544; both run the levelled stream-K schedule: 256 workgroups of 8 waves - the "
+                   "fp32 partials of the cut units are part of the write traffic, the merge kernel is not counted), KB per "
                    "dispatch; read bytes = 2 x FETCH_SIZE x 1024 (gfx950 reports half of a 16-B/lane coalesced stream, "
                    "MI355X_MICROARCH.md HBM), write bytes = WRITE_SIZE x 1024; FETCH_SIZE counts L2 misses, Infinity-Cache hits "
                    "included; algorithmic bytes: Q + K + V read once = 51.4 MB (S=6272) / 77.1 MB (S=12544), O written once = 25.7 MB",
