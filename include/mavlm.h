@@ -167,7 +167,13 @@ int mavlm_attention_hd_ws(const void* Q, int32_t ldq, const void* K, int32_t ldk
                           int64_t ws_floats, int32_t dtype, void* stream);
 int mavlm_attention_colsum_hd(const void* Q, int32_t ldq, const void* K, int32_t ldk, const float* lse2, float* part,
                               int32_t R, int32_t S, int32_t H, int32_t head_dim, float scale, int32_t dtype, void* stream);
-/* part[H,S] fp32 = column sums over queries of the normalised probabilities.  MemoryController.py:135 */
+/* part[H,S] fp32 = column sums over queries of the normalised probabilities.  MemoryController.py:135
+ * `part` is also the pass's scratch: it must hold mavlm_attention_colsum_floats(R,S,H) floats (>= H*S: the balanced
+ * schedule writes one plane of [H,S] per piece of a (key block, head) unit and adds the planes in order - deterministic,
+ * no atomics); the result is its first H*S floats. */
+int64_t mavlm_attention_colsum_floats(int32_t R, int32_t S, int32_t H);
+/* the schedule the pass runs (pure function of the shape): info[0] = workgroups, info[1] = planes it writes */
+int mavlm_attention_colsum_plan(int32_t R, int32_t S, int32_t H, int32_t info[2]);
 int mavlm_attention_colsum(const void* Q, int32_t ldq, const void* K, int32_t ldk, const float* lse2, float* part,
                            int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream);
 /* out = LayerNorm(x fp32 [rows,D] + res) * gamma + beta -> 16-bit; res: 16-bit [rows, ldr] residual or null.
@@ -259,6 +265,9 @@ int mavlm_set_attention_streamk_min_tiles(int32_t tiles);
 /* tuning hook: waves per workgroup of the stream-K schedule - 8 (256 queries per unit, 256 workgroups: K / V staged once per
  * eight waves), 4 (128 queries, 512 workgroups), 0 = automatic (8 where its plan applies).  Part of the result, as above. */
 int mavlm_set_attention_streamk_waves(int32_t waves);
+/* workgroups of the column-sum pass's balanced schedule: 0 = automatic (512), or 64 .. 1024.  Changes the fp32 summation
+ * order of the column sums (pieces per unit), nothing else. */
+int mavlm_set_attention_colsum_wgs(int32_t wgs);
 
 /* --- measurement hooks (bench.py only; new - the reference has no profiling) ------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on its own stream.  Kinds: 0 GEMM, 1 attention

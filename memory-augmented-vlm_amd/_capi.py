@@ -93,6 +93,9 @@ SIGNATURES = {
     "mavlm_attention_plan": (C.c_int, [i32, i32, i32, C.POINTER(i32)]),
     "mavlm_set_attention_streamk_min_tiles": (C.c_int, [i32]),
     "mavlm_set_attention_streamk_waves": (C.c_int, [i32]),
+    "mavlm_set_attention_colsum_wgs": (C.c_int, [i32]),
+    "mavlm_attention_colsum_floats": (C.c_int64, [i32, i32, i32]),
+    "mavlm_attention_colsum_plan": (C.c_int, [i32, i32, i32, C.POINTER(i32)]),
     "mavlm_prof_enable": (C.c_int, [i32]),
     "mavlm_prof_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), i32]),

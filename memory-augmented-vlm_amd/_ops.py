@@ -107,13 +107,16 @@ def attention_colsum(q, k, lse2, heads, head_dim=128, wide_kernel=False, scale=N
     _need_gpu(q, k, lse2)
     R, _, ldq = _rows(q)
     S, _, ldk = _rows(k)
-    part = torch.empty((heads, S), device=q.device, dtype=torch.float32)
     if head_dim == 128 and not wide_kernel:
+        # `part` doubles as the pass's scratch (one [H,S] plane per piece of the balanced schedule); result = first plane
+        buf = torch.empty((int(capi.lib().mavlm_attention_colsum_floats(R, S, heads)),), device=q.device, dtype=torch.float32)
+        part = buf[:heads * S].view(heads, S)
         capi.check(capi.lib().mavlm_attention_colsum(q.data_ptr(), ldq, k.data_ptr(), ldk, lse2.data_ptr(), part.data_ptr(),
                                                      R, S, heads, 1.0 / math.sqrt(128.0) if scale is None else float(scale),
                                                      dtype_code(q.dtype), stream_ptr()),
                    "mavlm_attention_colsum")
     else:
+        part = torch.empty((heads, S), device=q.device, dtype=torch.float32)
         capi.check(capi.lib().mavlm_attention_colsum_hd(q.data_ptr(), ldq, k.data_ptr(), ldk, lse2.data_ptr(),
                                                         part.data_ptr(), R, S, heads, head_dim,
                                                         1.0 / math.sqrt(head_dim) if scale is None else float(scale),

@@ -375,15 +375,26 @@ __global__ __launch_bounds__(256, 2) void attn_colsum_kernel(const uint16_t* __r
 }
 
 template <typename T>
-__global__ void frame_scores_kernel(const float* __restrict__ part, int H, int S, int P, void* __restrict__ out,
-                                    int out_f32) {
-  // one wave per frame
-  const int f = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void frame_scores_kernel(const float* __restrict__ part, int planes, int H, int S, int P,
+                                                           void* __restrict__ out, int out_f32) {
+  // one workgroup per frame; the planes of the column-sum pass are added first, in plane order (as
+  // colsum_planes_reduce_kernel); fixed summation order: per thread, per wave (butterfly), then the four waves in order
+  __shared__ float wsum[4];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const size_t plane_stride = (size_t)H * S;
   float s = 0.f;
-  for (int hh = 0; hh < H; ++hh)
-    for (int p = lane; p < P; p += 64) s += part[(size_t)hh * S + (size_t)f * P + p];
-  s = wave_sum(s) / (float)P;
-  if (lane == 0) {
+  for (int e = tid; e < H * P; e += 256) {
+    const int hh = e / P, p = e - hh * P;
+    const size_t i = (size_t)hh * S + (size_t)f * P + p;
+    float v = part[i];
+    for (int pl = 1; pl < planes; ++pl) v += part[(size_t)pl * plane_stride + i];
+    s += v;
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) wsum[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    s = (((wsum[0] + wsum[1]) + wsum[2]) + wsum[3]) / (float)P;
     if (out_f32) ((float*)out)[f] = s;
     else ((uint16_t*)out)[f] = T::from_f32(s);
   }
@@ -433,8 +444,8 @@ hipError_t mavlm_launch_colsum(const mavlm_colsum_args& a, int dtype, hipStream_
   if (!attn_args_ok(a.Q, a.ldq, a.K, a.ldk, a.R, a.S, a.H) || !a.lse2 || !a.part) return hipErrorInvalidValue;
   const float c = a.scale * 1.44269504088896340736f;
   dim3 grid(((a.S + 127) / 128) * a.H);
+  if (g_mavlm_attn_impl != 2) return mavlm_launch_colsum3(a, dtype, s);     // (brackets its kernels itself)
   mavlm_prof_scope prof(MAVLM_K_COLSUM, 2.0 * a.R * (double)a.S * a.H * HD, 2.0 * HD * a.H * ((double)a.R + a.S), s);
-  if (g_mavlm_attn_impl != 2) return mavlm_launch_colsum3(a, dtype, s);
   if (dtype == MAVLM_F16)
     hipLaunchKernelGGL(attn_colsum_kernel<F16>, grid, dim3(256), CS_LDS, s, (const uint16_t*)a.Q, a.ldq,
                        (const uint16_t*)a.K, a.ldk, a.lse2, a.part, a.R, a.S, a.H, c);
@@ -444,14 +455,14 @@ hipError_t mavlm_launch_colsum(const mavlm_colsum_args& a, int dtype, hipStream_
   return hipGetLastError();
 }
 
-hipError_t mavlm_launch_frame_scores(const float* part, int H, int S, int F, int P, void* out, int out_f32, int dtype,
-                                     hipStream_t s) {
-  if (!part || !out || F <= 0 || F * P > S) return hipErrorInvalidValue;
-  mavlm_prof_scope prof(MAVLM_K_MISC, 0.0, 4.0 * H * (double)S, s);
+hipError_t mavlm_launch_frame_scores(const float* part, int planes, int H, int S, int F, int P, void* out, int out_f32,
+                                     int dtype, hipStream_t s) {
+  if (!part || !out || F <= 0 || F * P > S || planes < 1) return hipErrorInvalidValue;
+  mavlm_prof_scope prof(MAVLM_K_MISC, 0.0, 4.0 * planes * H * (double)S, s);
   if (dtype == MAVLM_F16)
-    hipLaunchKernelGGL(frame_scores_kernel<F16>, dim3(F), dim3(64), 0, s, part, H, S, P, out, out_f32);
+    hipLaunchKernelGGL(frame_scores_kernel<F16>, dim3(F), dim3(256), 0, s, part, planes, H, S, P, out, out_f32);
   else
-    hipLaunchKernelGGL(frame_scores_kernel<BF16>, dim3(F), dim3(64), 0, s, part, H, S, P, out, out_f32);
+    hipLaunchKernelGGL(frame_scores_kernel<BF16>, dim3(F), dim3(256), 0, s, part, planes, H, S, P, out, out_f32);
   return hipGetLastError();
 }
 

@@ -780,9 +780,14 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
 //     the plain-C++ form waited `lgkmcnt(0)` for every fragment right after issuing its read).
 //   * The DMAs are buffer loads (descriptor + 32-bit lane offset + scalar tile offset) issued between MFMA steps, not as
 //     a burst (see attn_fwd3_kernel).
-//   * The QUERY range is split over blockIdx (2 halves) when (key blocks x heads) alone would leave most of the chip's
-//     workgroup slots empty (392 workgroups at S = 6272 against 1024 slots): both halves add into `part`, zeroed by the
-//     launcher.  Two addends per element: the float sum does not depend on their order, so the result is deterministic.
+//   * Balanced schedule.  A unit = (128-key block, head) x all query tiles; (key blocks x heads) rarely matches the chip's
+//     workgroup slots (392 units at S = 6272: whole units leave the CUs with 1 or 2 workgroups, two halves with 3 or 4 -
+//     measured 820 TFLOP/s there against 904 at S = 6144 and 975 at S = 8192 where the slots fill evenly).  The grid is
+//     therefore G workgroups over the FLATTENED (unit, query tile) space: workgroup g owns tiles [g*T/G, (g+1)*T/G) - every
+//     workgroup the same count (+-1) - and walks the at most few units its range touches (segment loop).
+//   * Deterministic output without atomics or a memset: the pieces of a unit are consecutive workgroups, piece j of a unit
+//     stores its column sums into plane j of `part` ([planes, H, S]); piece 0 also zeroes the planes its unit does not use.
+//     The consumer adds the planes in order (frame_scores_kernel / colsum_planes_reduce_kernel).
 namespace {
 
 constexpr int CS3_LSE = 2 * TILE3;             // 2 x 256 B of lse2 behind the two Q slots
@@ -794,19 +799,35 @@ template <typename T>
 __global__ __launch_bounds__(256, 4) void attn_colsum3_kernel(const uint16_t* __restrict__ Q, int ldq,
                                                               const uint16_t* __restrict__ K, int ldk,
                                                               const float* __restrict__ lse2, float* __restrict__ part,
-                                                              int R, int S, int H, float c, int nkb, int tps, int nsplit) {
+                                                              int R, int S, int H, float c, int nkb, int nplanes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = blockIdx.x % H;
-  const int kb = (blockIdx.x / H) % nkb;
-  const int qsp = blockIdx.x / (H * nkb);                       // query split
-  const int k0 = kb * 128 + wave * 32;
   const int r = lane & 31, hh = lane >> 5;
   const int ntq = (R + KT3 - 1) / KT3;
-  const int tq0 = qsp * tps;                                    // first query tile of this workgroup
-  const int nt = (ntq - tq0 < tps) ? ntq - tq0 : tps;           // >= 1 (launcher)
+  // workgroup g owns tiles [b(g), b(g+1)) of the flattened (unit, query tile) space, b(g) = g*q + min(g, rem): the first
+  // `rem` workgroups take q+1 tiles, the others q  (32-bit arithmetic; the launcher checks units * tiles < 2^31)
+  const int ttot = nkb * H * ntq, G = (int)gridDim.x, gq = ttot / G, grem = ttot - gq * G;
+  const int g = (int)blockIdx.x;
+  int b0 = g * gq + (g < grem ? g : grem);
+  const int b1 = b0 + gq + (g < grem ? 1 : 0);
+  const size_t plane_stride = (size_t)H * S;
+  auto owner = [&](int x) { return x < grem * (gq + 1) ? x / (gq + 1) : (x - grem) / gq; };   // largest g with b(g) <= x
+
+  for (bool first_seg = true; b0 < b1; first_seg = false) {
+  const int u = b0 / ntq;                                       // unit = (key block, head)
+  const int tq0 = b0 - u * ntq;                                 // first query tile of this segment
+  const int nt = (ntq - tq0 < b1 - b0) ? ntq - tq0 : b1 - b0;   // >= 1
+  const int h = u % H, kb = u / H;
+  const int g_first = owner(u * ntq), g_last = owner((u + 1) * ntq - 1);   // the workgroups that touch this unit
+  const int plane = g - g_first;
+  const int k0 = kb * 128 + wave * 32;
+  if (!first_seg) {             // every wave is done with the LDS slots of the previous segment (and has no DMA in flight)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
 
   typename T::vec8 kf[8];
   {
@@ -975,39 +996,86 @@ __global__ __launch_bounds__(256, 4) void attn_colsum3_kernel(const uint16_t* __
     for (int i = 0; i < 16; ++i) {
       const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
       if (key < S) {
-        if (nsplit > 1) atomicAdd(part + (size_t)h * S + key, acc[i]);
-        else part[(size_t)h * S + key] = acc[i];
+        float* o = part + (size_t)h * S + key;
+        o[(size_t)plane * plane_stride] = acc[i];
+        if (plane == 0)
+          for (int pz = g_last - g_first + 1; pz < nplanes; ++pz) o[(size_t)pz * plane_stride] = 0.f;
       }
     }
   }
+  b0 += nt;
+  }  // segment loop
+}
+
+// part[0] += part[1] + ... in plane order (stand-alone operator: the result is the first H*S floats)
+__global__ void colsum_planes_reduce_kernel(float* __restrict__ part, size_t n, int nplanes) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = part[i];
+  for (int p = 1; p < nplanes; ++p) v += part[(size_t)p * n + i];
+  part[i] = v;
 }
 
 }  // namespace
 
-// Query-split plan of the column-sum pass (pure function of the shape): 2 halves when key blocks x heads would fill less
-// than ~60 % of the 1024 workgroup slots (4 per CU), else 1.  At most two addends per output element -> deterministic.
-int mavlm_colsum_splits(int R, int S, int H) {
-  const int nkb = (S + 127) / 128, ntq = (R + KT3 - 1) / KT3;
-  return (nkb * H < 600 && ntq >= 8) ? 2 : 1;
+// Plan of the column-sum pass (pure function of the shape): G workgroups over the flattened (unit, query tile) space and
+// the number of planes of `part` = the most pieces a unit can have.  G = 2 workgroups per CU measured best (longer query
+// streams per workgroup, one prologue per ~150 tiles); never more workgroups than tiles.
+int g_mavlm_colsum_wgs = 0;       // diagnostics: 0 = automatic
+int mavlm_colsum_plan(int R, int S, int H, int* planes) {
+  const long nkb = (S + 127) / 128, ntq = (R + KT3 - 1) / KT3;
+  const long ttot = nkb * H * ntq;
+  long G = g_mavlm_colsum_wgs > 0 ? g_mavlm_colsum_wgs : 512;       // (the setter admits 64 .. 1024)
+  {   // short ranges only pay prologues: at least ~8 query tiles per workgroup, but never fewer workgroups than units
+    const long units = nkb * H, floor_ = units < G ? units : G, by_len = ttot / 8;
+    const long cap = by_len > floor_ ? by_len : floor_;
+    if (G > cap) G = cap;
+  }
+  if (G > ttot) G = ttot;
+  if (planes) {                                          // the most workgroups any unit's tiles are spread over (exact)
+    const long q = ttot / G, rem = ttot - q * G;
+    auto owner = [&](long x) { return x < rem * (q + 1) ? x / (q + 1) : (x - rem) / q; };     // as in the kernel
+    long most = 1;
+    for (long u = 0; u < nkb * H; ++u) {
+      const long n = owner((u + 1) * ntq - 1) - owner(u * ntq) + 1;
+      if (n > most) most = n;
+    }
+    *planes = (int)most;
+  }
+  return (int)G;
+}
+size_t mavlm_colsum_part_floats(int R, int S, int H) {      // buffer size: covers every setting of the diagnostics hooks
+  const long nkb = (S + 127) / 128, ntq = (R + KT3 - 1) / KT3;
+  const long ttot = nkb * H * ntq;
+  const long minlen = ttot / (ttot < 1024 ? ttot : 1024);
+  return (size_t)((ntq - 1 + minlen - 1) / minlen + 1) * H * S;
+}
+int mavlm_colsum_planes(int R, int S, int H) {
+  int planes = 1;
+  if (g_mavlm_attn_impl != 2) mavlm_colsum_plan(R, S, H, &planes);
+  return planes;
 }
 
 hipError_t mavlm_launch_colsum3(const mavlm_colsum_args& a, int dtype, hipStream_t s) {
   if ((double)a.R * a.ldq * 2.0 >= 2147483648.0) return hipErrorInvalidValue;      // 32-bit buffer offsets
   const float c = a.scale * 1.44269504088896340736f;
-  const int nkb = (a.S + 127) / 128, ntq = (a.R + KT3 - 1) / KT3;
-  const int ns = mavlm_colsum_splits(a.R, a.S, a.H);
-  const int tps = (ntq + ns - 1) / ns;
-  const int nsplit = (ntq + tps - 1) / tps;
-  if (nsplit > 1) {
-    hipError_t e = hipMemsetAsync(a.part, 0, (size_t)a.H * a.S * sizeof(float), s);
-    if (e != hipSuccess) return e;
+  const int nkb = (a.S + 127) / 128;
+  if ((double)nkb * a.H * ((a.R + KT3 - 1) / KT3) >= 2.0e9) return hipErrorInvalidValue;   // 32-bit schedule arithmetic
+  int planes = 1;
+  const int G = mavlm_colsum_plan(a.R, a.S, a.H, &planes);
+  {
+    mavlm_prof_scope prof(MAVLM_K_COLSUM, 2.0 * a.R * (double)a.S * a.H * HD3, 2.0 * HD3 * a.H * ((double)a.R + a.S), s);
+    if (dtype == MAVLM_F16)
+      hipLaunchKernelGGL(attn_colsum3_kernel<F16>, dim3(G), dim3(256), CS3_LDS, s, (const uint16_t*)a.Q, a.ldq,
+                         (const uint16_t*)a.K, a.ldk, a.lse2, a.part, a.R, a.S, a.H, c, nkb, planes);
+    else
+      hipLaunchKernelGGL(attn_colsum3_kernel<BF16>, dim3(G), dim3(256), CS3_LDS, s, (const uint16_t*)a.Q, a.ldq,
+                         (const uint16_t*)a.K, a.ldk, a.lse2, a.part, a.R, a.S, a.H, c, nkb, planes);
   }
-  dim3 grid(nkb * a.H * nsplit);
-  if (dtype == MAVLM_F16)
-    hipLaunchKernelGGL(attn_colsum3_kernel<F16>, grid, dim3(256), CS3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
-                       a.ldk, a.lse2, a.part, a.R, a.S, a.H, c, nkb, tps, nsplit);
-  else
-    hipLaunchKernelGGL(attn_colsum3_kernel<BF16>, grid, dim3(256), CS3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K,
-                       a.ldk, a.lse2, a.part, a.R, a.S, a.H, c, nkb, tps, nsplit);
+  if (!a.keep_planes && planes > 1) {
+    const size_t n = (size_t)a.H * a.S;
+    mavlm_prof_scope prof(MAVLM_K_MISC, 0.0, 4.0 * (planes + 1) * (double)n, s);
+    hipLaunchKernelGGL(colsum_planes_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.part, n, planes);
+  }
   return hipGetLastError();
 }

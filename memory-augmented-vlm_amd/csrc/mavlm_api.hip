@@ -69,7 +69,15 @@ void carve(mavlm_ctx* x) {
   x->o_mA = o;   o += al(R * D * 2);
   x->o_mB = o;   o += al(R * D * 2);
   x->o_lse = o;  o += al(H * R * 4);
-  x->o_part = o; o += al(H * S * 4);
+  {   // column-sum planes (attention3.hip: balanced schedule): the plane count depends on the chunk's key count
+    size_t fl = H * S;
+    if (!wide_heads(c))
+      for (int f = 1; f <= c.max_chunk_frames; ++f) {
+        const size_t v = mavlm_colsum_part_floats((int)R, f * c.patches, (int)H);
+        if (v > fl) fl = v;
+      }
+    x->o_part = o; o += al(fl * 4);
+  }
   // split-KV partials of the attention (small grids only: mavlm_attention_splits): worst case over the key count
   x->o_split = o;
   {
@@ -185,6 +193,12 @@ int mavlm_set_attention_streamk_min_tiles(int32_t tiles) {
 int mavlm_set_attention_streamk_waves(int32_t waves) {
   if (waves != 0 && waves != 4 && waves != 8) return MAVLM_E_ARG;
   g_mavlm_attn_sk_waves = waves;
+  return 0;
+}
+
+int mavlm_set_attention_colsum_wgs(int32_t wgs) {
+  if (wgs != 0 && (wgs < 64 || wgs > 1024)) return MAVLM_E_ARG;
+  g_mavlm_colsum_wgs = wgs;
   return 0;
 }
 
@@ -310,12 +324,15 @@ int mavlm_step(mavlm_ctx* x, const void* seg, int32_t F, void* frame_scores, int
       mavlm_colsum_args ca;
       ca.Q = ws(x, x->o_q); ca.ldq = Dp; ca.K = Kl; ca.ldk = ldkv; ca.lse2 = lse; ca.part = (float*)ws(x, x->o_part);
       ca.R = R; ca.S = S; ca.H = H; ca.scale = attn_scale(c);
+      int planes = 1;
       if (wide_heads(c)) {
         MAVLM_TRY(mavlm_launch_colsum_hd(ca, c.hidden / c.heads, dt, s));
       } else {
+        ca.keep_planes = 1;                   // frame_scores_kernel adds the planes (same order as the reduce kernel)
+        planes = mavlm_colsum_planes(R, S, H);
         MAVLM_TRY(mavlm_launch_colsum(ca, dt, s));
       }
-      MAVLM_TRY(mavlm_launch_frame_scores(ca.part, H, S, F, c.patches, frame_scores, scores_f32, dt, s));
+      MAVLM_TRY(mavlm_launch_frame_scores(ca.part, planes, H, S, F, c.patches, frame_scores, scores_f32, dt, s));
     }
     // MLP: Linear(D,I)+ReLU -> Residual(I->D)  (MemoryController.py:63-67,71)
     MAVLM_TRY(gemm_x(x, s, ws(x, x->o_a), D, x->w.w_up[l], D, x->w.b_up[l], ws(x, x->o_h), I, R, I, D, MAVLM_EPI_RELU));
@@ -483,6 +500,18 @@ int mavlm_attention_colsum_hd(const void* Q, int32_t ldq, const void* K, int32_t
   mavlm_colsum_args a;
   a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.lse2 = lse2; a.part = part; a.R = R; a.S = S; a.H = H; a.scale = scale;
   return (int)mavlm_launch_colsum_hd(a, head_dim, dtype, (hipStream_t)stream);
+}
+
+int64_t mavlm_attention_colsum_floats(int32_t R, int32_t S, int32_t H) {
+  return (R > 0 && S > 0 && H > 0) ? (int64_t)mavlm_colsum_part_floats(R, S, H) : 0;
+}
+
+int mavlm_attention_colsum_plan(int32_t R, int32_t S, int32_t H, int32_t info[2]) {
+  if (!info || R <= 0 || S <= 0 || H <= 0) return MAVLM_E_ARG;
+  int planes = 1;
+  info[0] = mavlm_colsum_plan(R, S, H, &planes);
+  info[1] = mavlm_colsum_planes(R, S, H);
+  return 0;
 }
 
 int mavlm_attention_colsum(const void* Q, int32_t ldq, const void* K, int32_t ldk, const float* lse2, float* part,

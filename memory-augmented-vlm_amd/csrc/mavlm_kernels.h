@@ -109,10 +109,17 @@ struct mavlm_colsum_args {
   const void* Q; int ldq;
   const void* K; int ldk;
   const float* lse2;             // [H, R]
-  float* part;                   // [H, S]
+  float* part;                   // mavlm_colsum_part_floats(R,S,H) floats; the result is [H, S] at its start, or - with
+                                 // keep_planes - mavlm_colsum_planes(R,S,H) planes of [H, S] the consumer adds in order
   int R, S, H;
   float scale;
+  int keep_planes = 0;
 };
+// column-sum pass of the head_dim-128 kernels: workgroups of the balanced schedule / planes of `part` (attention3.hip)
+int mavlm_colsum_plan(int R, int S, int H, int* planes);
+int mavlm_colsum_planes(int R, int S, int H);         // planes the selected kernel writes (1 for the register-staged one)
+size_t mavlm_colsum_part_floats(int R, int S, int H);
+extern int g_mavlm_colsum_wgs;
 hipError_t mavlm_launch_colsum(const mavlm_colsum_args& a, int dtype, hipStream_t s);
 hipError_t mavlm_launch_colsum3(const mavlm_colsum_args& a, int dtype, hipStream_t s);   // pipelined (attention3.hip)
 // wide heads (attention_hd.hip): head_dim 448 (OV-7B), also 128 for cross-checks; columns of head h start at h*head_dim
@@ -120,8 +127,8 @@ hipError_t mavlm_launch_attention_hd(const mavlm_attn_args& a, int head_dim, int
 hipError_t mavlm_launch_colsum_hd(const mavlm_colsum_args& a, int head_dim, int dtype, hipStream_t s);
 
 // frame_scores[f] = (1/P) * sum_{p<P} sum_h part[h][f*P+p]     (MemoryController.py:135-139)
-hipError_t mavlm_launch_frame_scores(const float* part, int H, int S, int F, int P, void* out, int out_f32, int dtype,
-                                     hipStream_t s);
+hipError_t mavlm_launch_frame_scores(const float* part, int planes, int H, int S, int F, int P, void* out, int out_f32,
+                                     int dtype, hipStream_t s);
 
 // out[r,:] = LayerNorm(x[r,:] + res[r,:]) * gamma + beta   (x fp32 [rows, D]; res 16-bit [rows, ldr] or null;
 // biased variance; rsqrt(var+eps))

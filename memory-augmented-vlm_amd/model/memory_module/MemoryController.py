@@ -281,6 +281,26 @@ class _Engine:
             out[n_] = self.workspace[b0:b0 + nbytes].view(dt).view(shp)
         return out
 
+    def colsum_part(self, F):
+        """[H, F*P] fp32 per-head column sums the last step with F frames left in the workspace: the column-sum pass writes
+        one [H, S] plane per piece of its schedule (mavlm_attention_colsum_plan), added here in plane order."""
+        import ctypes
+        offs = (ctypes.c_size_t * 10)()
+        capi.check(capi.lib().mavlm_workspace_layout(self.c, offs, 10), "mavlm_workspace_layout")
+        c = self.c
+        R, S, H = c.mem_tokens * c.patches, F * c.patches, c.heads
+        planes = 1
+        if self.Dp // H == 128:
+            info = (ctypes.c_int32 * 2)()
+            capi.check(capi.lib().mavlm_attention_colsum_plan(R, S, H, info), "mavlm_attention_colsum_plan")
+            planes = info[1]
+        b0 = self.workspace_base_offset + offs[9]
+        flat = self.workspace[b0:b0 + planes * H * S * 4].view(torch.float32).view(planes, H, S)
+        acc = flat[0].clone()
+        for p_ in range(1, planes):
+            acc += flat[p_]
+        return acc
+
 
 class TransformerProjector(nn.Module):
     """The recurrent memory transformer (:74-158)."""

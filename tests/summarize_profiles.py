@@ -46,19 +46,33 @@ def counters(sub):
 stats("stats1", f"{tag}_kernel_stats_1video_in_flight.csv")
 stats("stats2", f"{tag}_kernel_stats.csv")
 
+def per_dispatch(sub):
+    """[{kernel, grid, counter: value...}] one record per dispatch"""
+    files = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
+    rec = collections.defaultdict(dict)
+    for fn in files:
+        for r in csv.DictReader(open(fn)):
+            d = rec[(fn, r["Dispatch_Id"])]
+            d["kernel"], d["grid"] = short(r["Kernel_Name"]), r.get("Grid_Size", "")
+            d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    return list(rec.values())
+
+
 with open(os.path.join(dst, f"{tag}_mfma_utilisation.csv"), "w") as f:
     f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES (tests/profile_round.sh), per dispatch averages at the bench shapes\n")
     f.write("# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs) / (GRBM_GUI_ACTIVE / 8 XCDs); profiled clocks are lower than un-profiled ones\n")
-    f.write("kernel,grid_threads,mfma_busy_cycles_sum,kernel_cycles,mfma_util\n")
+    f.write("# dispatches of one kernel are grouped by their MFMA-busy count (it is a function of the shape), first dispatch of a group dropped (cold)\n")
+    f.write("kernel,grid_threads,dispatches,mfma_busy_cycles_sum,kernel_cycles,mfma_util\n")
     for op in ("attn", "colsum", "gemm"):
-        for (k, grid), c in sorted(counters(f"mfma_{op}").items()):
-            if "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "GRBM_GUI_ACTIVE" not in c:
-                continue
-            busy = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(c["SQ_VALU_MFMA_BUSY_CYCLES"])
-            cyc = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"]) / 8.0
-            if busy <= 0 or cyc <= 0:
-                continue
-            f.write(f"\"{k}\",{grid},{busy:.0f},{cyc:.0f},{busy / 1024.0 / cyc:.3f}\n")
+        groups = collections.defaultdict(list)
+        for d in per_dispatch(f"mfma_{op}"):
+            if d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0 and d.get("GRBM_GUI_ACTIVE", 0) > 0:
+                groups[(d["kernel"], d["grid"], round(d["SQ_VALU_MFMA_BUSY_CYCLES"], -5))].append(d)
+        for (k, grid, _), ds in sorted(groups.items()):
+            ds = ds[1:] if len(ds) > 2 else ds
+            busy = sum(d["SQ_VALU_MFMA_BUSY_CYCLES"] for d in ds) / len(ds)
+            cyc = sum(d["GRBM_GUI_ACTIVE"] for d in ds) / len(ds) / 8.0
+            f.write(f"\"{k}\",{grid},{len(ds)},{busy:.0f},{cyc:.0f},{busy / 1024.0 / cyc:.3f}\n")
 
 def ordered(sub, counter):
     """{(kernel, grid): [values in dispatch order]} - tests/bench_ops.py attn runs all its S=6272 launches, then all its

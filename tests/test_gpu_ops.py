@@ -195,12 +195,38 @@ def test_attention_split_kv_small_grids(mode, R, S, H):
                                   ops.dtype_code(dq.dtype), ops.stream_ptr()) == capi.E_ARG
 
 
+@pytest.mark.parametrize("wgs", [0, 64, 200, 1024])
+@pytest.mark.parametrize("mode,R,S,H", [("bf16", 1568, 1000, 3), ("fp16", 4100, 64 * 9 + 5, 8), ("bf16", 130, 6272, 8)])
+def test_colsum_balanced_schedule(mode, R, S, H, wgs, request):
+    """The column-sum pass runs G workgroups over the flattened (128-key block x head, 64-query tile) space: a workgroup's
+    range may start and end in the middle of a unit and span several units; the pieces of a unit land in separate planes
+    that are added in a fixed order.  Same gate against the oracle for every G (the hook changes the summation order only),
+    ragged tiles / key blocks included, H not a power of two; bit-reproducible (no atomics)."""
+    lib = capi.lib()
+    capi.check(lib.mavlm_set_attention_colsum_wgs(wgs), "colsum wgs")
+    request.addfinalizer(lambda: lib.mavlm_set_attention_colsum_wgs(0))
+    assert lib.mavlm_set_attention_colsum_wgs(63) == capi.E_ARG and lib.mavlm_set_attention_colsum_wgs(wgs) == 0
+    assert lib.mavlm_attention_colsum_floats(R, S, H) >= H * S
+    r = O.rounder(mode)
+    q = r(O.hash_normal_like((R, H * 128), 41))
+    k = r(O.hash_normal_like((S, H * 128), 42))
+    v = r(O.hash_normal_like((S, H * 128), 43))
+    _, lse2, col = _attn_oracle(q, k, v, H, mode)
+    dq, dk, dv = to_dev(q, mode), to_dev(k, mode), to_dev(v, mode)
+    _, lse = ops.attention(dq, dk, dv, H, want_lse=True)
+    part = ops.attention_colsum(dq, dk, lse, H)
+    assert part.shape == (H, S) and O.rel_l2(to_np(part), col) < TOL and abs(float(part.sum()) - H * R) < 1e-3 * H * R
+    for _ in range(3):
+        assert torch.equal(ops.attention_colsum(dq, dk, lse, H), part)
+
+
 @pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("mode,R,S,H", [("bf16", 8320, 256, 8), ("fp16", 8330, 200, 8), ("bf16", 1100, 64 * 9 + 5, 64)])
 def test_attention_stream_k_more_units_than_slots(mode, R, S, H, waves, monkeypatch, request):
-    """More units (128-query blocks x heads) than the chip's 512 workgroup slots (the bench shape: 784): 512 persistent
-    workgroups each own an equal range of the global key-tile sequence, the units a range boundary cuts are computed as
-    head + tail partials and merged (attn_combine_sk_kernel).  The oracle mirrors the cuts (streamk_split_tiles): same
+    """More units (query blocks x heads) than resident workgroups (the bench shape: 784 four-wave units on 512 slots): the
+    levelled stream-K schedule - every workgroup takes floor(U/G) whole units, the remainder is served in binary levels whose
+    units are cut into 2^k key ranges (normalised fp32 partials, merged by attn_combine_sk_kernel); 4-wave (G = 512, 128
+    queries per unit) and 8-wave (G = 256, 256 queries) workgroups.  The oracle mirrors the cuts (streamk_split_tiles): same
     gates as the plain kernel; ragged query blocks / key tiles included; the plain entry point agrees within rounding."""
     lib = capi.lib()
     assert lib.mavlm_attention_ws_floats(12544, 63 * 64, 8) == 0 and lib.mavlm_attention_ws_floats(12544, 6272, 8) > 0

@@ -156,7 +156,7 @@ def test_step_stagewise_teacher_forced():
     errs["m_out(LN)"] = O.rel_l2(to_np(cache[-1]).reshape(R, D),                              # + residual in the LN kernel
                                  r(O.layernorm(ws["pre"] + ws["a"], w[f"{T}.layers.1.residual.layernorm.weight"],
                                                w[f"{T}.layers.1.residual.layernorm.bias"], cfg.eps)))
-    part = eng.workspace_views()["part"].reshape(-1)[:H * S].view(H, S).cpu().numpy()
+    part = eng.colsum_part(S // 196).cpu().numpy()
     errs["colsum"] = O.rel_l2(part, col)
     errs["scores"] = O.rel_l2(to_np(scores[-1]), r(col.sum(0).reshape(2, 196).mean(1)))
     print({k: f"{v:.1e}" for k, v in errs.items()})
