@@ -43,12 +43,16 @@ constexpr int STAGE2 = 4 * HALF;             // A0 A1 B0 B1
 constexpr int GEMM256_LDS = 2 * STAGE2;      // 128 KiB
 
 // raw workgroup barrier fenced against compiler motion of memory operations (s_barrier itself is IntrNoMem)
+#ifdef MAVLM_GEMM_ABLATE_BAR
+#define MAVLM_BAR() do { asm volatile("" ::: "memory"); } while (0)
+#else
 #define MAVLM_BAR()                          \
   do {                                       \
     asm volatile("" ::: "memory");           \
     __builtin_amdgcn_s_barrier();            \
     asm volatile("" ::: "memory");           \
   } while (0)
+#endif
 // all LDS reads of this phase retired before its MFMAs (WAR rule above); sched_barrier: hipcc may hoist a
 // register-only MFMA above an inline-asm wait (cdna_hip_programming.md rule 18)
 #define MAVLM_LGKM0()                                          \
@@ -114,6 +118,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   const unsigned lds_wave = (unsigned)(uintptr_t)(MAVLM_LDS char*)smem + wave * 2048;
   // half-tile ids: 0 = A0, 1 = A1, 2 = B0, 3 = B1
   auto dma = [&](int stage, int half_id, int kt) {
+#ifdef MAVLM_GEMM_ABLATE_DMA
+    if (kt > 1) return;                       // (diagnostic build: results are wrong, timing only)
+#endif
     unsigned base = lds_wave;
     asm volatile("" : "+s"(base));            // M0 = base + constant stays a one-instruction recompute (no SGPR hoisting)
     const unsigned dst = base + stage * STAGE2 + half_id * HALF;
@@ -137,6 +144,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifdef MAVLM_GEMM_ABLATE_READS
+  int ablate_kt = 0;
+#endif
   typename T::vec8 af[4][2];      // [m-tile of the current 64-row slice][k-step]
   typename T::vec8 bf[4][2];      // [n-tile of the wave's 64 columns][k-step]
 
@@ -154,6 +164,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   MAVLM_BAR();
 
   auto read_a = [&](const char* st, int mh) {
+#ifdef MAVLM_GEMM_ABLATE_READS
+    if (ablate_kt > 0) return;
+#endif
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       if (mh == 1 && mt >= MT1) continue;     // (mh is a literal at every call site)
@@ -162,12 +175,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
     }
   };
   auto read_b = [&](const char* st) {
+#ifdef MAVLM_GEMM_ABLATE_READS
+    if (ablate_kt > 0) return;
+#endif
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       bf[nt][0] = *(const typename T::vec8*)(st + offB + nt * 2048 + ck0);
       bf[nt][1] = *(const typename T::vec8*)(st + offB + nt * 2048 + ck1);
     }
   };
+#ifdef MAVLM_GEMM_ABLATE_MFMA
+#define MAVLM_QUADRANT(MH, NH) { asm volatile("" : "+v"(af[0][0]), "+v"(bf[0][0])); }
+#else
 #define MAVLM_QUADRANT(MH, NH)                                                              \
   {                                                                                         \
     __builtin_amdgcn_s_setprio(1);                                                          \
@@ -177,12 +196,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
       acc[MH * 4 + mt][NH * 2 + nt] = T::mfma16(bf[NH * 2 + nt][ks], af[mt][ks], acc[MH * 4 + mt][NH * 2 + nt]); \
     __builtin_amdgcn_s_setprio(0);                                                          \
   }
+#endif
 
   if (trailing) MAVLM_BAR();           // ping-pong skew: pairs with the leading group's first in-loop barrier
 
   for (int kt = 0; kt < nk; ++kt) {
     const int s = kt & 1;
     const char* st = smem + s * STAGE2;
+#ifdef MAVLM_GEMM_ABLATE_READS
+    ablate_kt = kt;
+#endif
     // -------- phase 1
     read_a(st, 0);
     read_b(st);

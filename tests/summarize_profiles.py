@@ -17,8 +17,13 @@ def short(name):
     return re.sub(r"\(.*", "", name).replace("void ", "")
 
 
+def newest(files):
+    """gpurun merges every call's files into gpurun_out/: keep the most recent run of a sub-directory only"""
+    return sorted(files, key=os.path.getmtime)[-1:]
+
+
 def stats(sub, out):
-    files = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+    files = newest(glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True))
     if not files:
         print("no kernel_stats for", sub)
         return
@@ -35,7 +40,7 @@ def stats(sub, out):
 
 
 def counters(sub):
-    files = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
+    files = newest(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for fn in files:
         for r in csv.DictReader(open(fn)):
@@ -48,7 +53,7 @@ stats("stats2", f"{tag}_kernel_stats.csv")
 
 def per_dispatch(sub):
     """[{kernel, grid, counter: value...}] one record per dispatch"""
-    files = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
+    files = newest(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True))
     rec = collections.defaultdict(dict)
     for fn in files:
         for r in csv.DictReader(open(fn)):
@@ -77,7 +82,7 @@ with open(os.path.join(dst, f"{tag}_mfma_utilisation.csv"), "w") as f:
 def ordered(sub, counter):
     """{(kernel, grid): [values in dispatch order]} - tests/bench_ops.py attn runs all its S=6272 launches, then all its
     S=12544 ones (the same number of each), and both shapes can share one grid: first half / second half."""
-    files = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
+    files = newest(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True))
     agg = collections.defaultdict(list)
     for fn in files:
         for r in csv.DictReader(open(fn)):
