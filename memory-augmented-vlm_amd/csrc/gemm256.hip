@@ -187,6 +187,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
 #ifdef MAVLM_GEMM_ABLATE_MFMA
 #define MAVLM_QUADRANT(MH, NH) { asm volatile("" : "+v"(af[0][0]), "+v"(bf[0][0])); }
 #else
+  auto read_b_half = [&](const char* st, int nh) {
+#pragma unroll
+    for (int nt = 2 * nh; nt < 2 * nh + 2; ++nt) {
+      bf[nt][0] = *(const typename T::vec8*)(st + offB + nt * 2048 + ck0);
+      bf[nt][1] = *(const typename T::vec8*)(st + offB + nt * 2048 + ck1);
+    }
+  };
 #define MAVLM_QUADRANT(MH, NH)                                                              \
   {                                                                                         \
     __builtin_amdgcn_s_setprio(1);                                                          \
@@ -206,6 +213,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
 #ifdef MAVLM_GEMM_ABLATE_READS
     ablate_kt = kt;
 #endif
+#ifndef MAVLM_GEMM_SCHED2
     // -------- phase 1
     read_a(st, 0);
     read_b(st);
@@ -236,6 +244,41 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
     MAVLM_BAR();
     MAVLM_QUADRANT(1, 0)
     MAVLM_BAR();
+#else
+    // (experiment) reads 12 / 4 / 8 / 0 and DMAs 0 / 1 / 1 / 2 per L segment instead of 16 / 0 / 8 / 0 and 1 / 1 / 1 / 1
+    // -------- phase 1
+    read_a(st, 0);
+    read_b_half(st, 0);
+    MAVLM_BAR();
+    MAVLM_LGKM0();
+    MAVLM_QUADRANT(0, 0)
+    MAVLM_BAR();
+    // -------- phase 2
+    read_b_half(st, 1);
+    if (kt + 1 < nk) dma(s ^ 1, 1, kt + 1);              // A1 of the next K-tile (needed at its L1)
+    MAVLM_BAR();
+    MAVLM_LGKM0();
+    MAVLM_QUADRANT(0, 1)
+    MAVLM_BAR();
+    // -------- phase 3   (B half-tiles of this stage are dead)
+    read_a(st, 1);
+    if (kt + 2 < nk) dma(s, 2, kt + 2);
+    MAVLM_BAR();
+    MAVLM_LGKM0();
+    MAVLM_QUADRANT(1, 1)
+    MAVLM_BAR();
+    // -------- phase 4   (A half-tiles dead)
+    if (kt + 2 < nk) {
+      dma(s, 3, kt + 2);
+      dma(s, 0, kt + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // K-tile kt+1 landed; 3 half-tiles of kt+2 stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    MAVLM_BAR();
+    MAVLM_QUADRANT(1, 0)
+    MAVLM_BAR();
+#endif
   }
   if (!trailing) MAVLM_BAR();          // matches the trailing group's last barrier
 #undef MAVLM_QUADRANT

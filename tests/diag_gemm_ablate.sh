@@ -7,12 +7,14 @@ cd "$(dirname "$0")/.."
 SRC=memory-augmented-vlm_amd/csrc
 OUT=memory-augmented-vlm_amd/lib/exp
 mkdir -p $OUT /tmp/gab
-for v in base READS DMA MFMA BAR; do
+VARIANTS=${VARIANTS:-"base READS DMA MFMA BAR"}
+for v in $VARIANTS; do
   D=""; [ $v != base ] && D="-DMAVLM_GEMM_ABLATE_$v"
+  [ $v = SCHED2 ] && D="-DMAVLM_GEMM_SCHED2"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $D -c -o /tmp/gab/gemm256_$v.o $SRC/gemm256.hip &
 done
 wait
-for v in base READS DMA MFMA BAR; do
+for v in $VARIANTS; do
   objs=$(ls memory-augmented-vlm_amd/lib/obj/*.o | grep -v "/gemm256.o")
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/gemm_$v.so $objs /tmp/gab/gemm256_$v.o
 done
