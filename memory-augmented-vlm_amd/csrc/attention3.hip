@@ -292,9 +292,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
     // in issue for ~1 000 clocks per tile (in-kernel stamps) before their first MFMA.
 
     const float mc = m_run * c;
-#ifdef MAVLM_ATTN3_PK
-    const f32x2 cmc = {c, -mc};
-#endif
     // [A] S'(t+1) = K(t+1).Q^T  ||  p = exp2(s*c - mc) for tile t (2 elements per MFMA).  The order is pinned with
     // sched_barrier(0): left alone hipcc hoists all 32 v_exp in front of the MFMA chain (no overlap at all) and sinks
     // the fragment reads to their use; K fragments are read KPF steps ahead (MAVLM_ATTN3_KPF).
@@ -346,20 +343,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
         constexpr int e0 = 2 * i, e1 = 2 * i + 1;             // elements (b = e>>4, idx = e&15) of tile t
         // The two empty asm statements are ordered against sched_barrier (both have side effects); the pure
         // fma/exp between them cannot be hoisted in front of the MFMA chain or sunk behind it.
-#ifdef MAVLM_ATTN3_PK
-        // the pair (e0, e1) sits in an even-aligned register pair of the accumulator: ONE v_pk_fma_f32 for both
-        // (both lanes take c from the low half and -mc from the high half of ONE register pair: op_sel)
-        f32x2 x = {st[P][e0 >> 4][e0 & 15], st[P][e1 >> 4][e1 & 15]};
-        asm volatile("v_pk_fma_f32 %0, %0, %1, %1 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "+v"(x) : "v"(cmc));
-        float x0 = __builtin_amdgcn_exp2f(x[0]), x1 = __builtin_amdgcn_exp2f(x[1]);
-        asm volatile("" : "+v"(x0), "+v"(x1));
-#else
         float x0 = st[P][e0 >> 4][e0 & 15], x1 = st[P][e1 >> 4][e1 & 15];
         asm volatile("" : "+v"(x0), "+v"(x1));
         x0 = __builtin_amdgcn_exp2f(x0 * c - mc);
         x1 = __builtin_amdgcn_exp2f(x1 * c - mc);
         asm volatile("" : "+v"(x0), "+v"(x1));
-#endif
         st[P][e0 >> 4][e0 & 15] = x0;
         st[P][e1 >> 4][e1 & 15] = x1;
         __builtin_amdgcn_sched_barrier(0);
@@ -377,9 +365,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
     // [B] O^T += V(t)^T.P(t)^T  ||  16-bit converts + row sums of tile t, row maximum of tile t+1
     if (has_next && t + 1 == nt - 1 && (S & (KT3 - 1))) mask_tail(IC<N>{}, t + 1);
     float psum = 0.f;
-#ifdef MAVLM_ATTN3_PK
-    f32x2 psum2 = {0.f, 0.f};
-#endif
     float mx = has_next ? st[N][0][0] : 0.f;
     {
       // The transposed V reads go through inline asm with hand-counted lgkmcnt waits: through the builtin, hipcc puts
@@ -441,15 +426,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
         ot[db] = T::mfma32(vf, pf[bs], ot[db]);
         if (db == 1 && bs < 3) cvt(bs + 1);                   // next group's converts, 2 MFMAs ahead of their use
         const int e0 = 8 * bs + 2 * db, e1 = e0 + 1;          // 2 of the 32 p values / 2 of the next 32 scores per MFMA
-#ifdef MAVLM_ATTN3_PK
-        {
-          const f32x2 pp = {st[P][e0 >> 4][e0 & 15], st[P][e1 >> 4][e1 & 15]};
-          asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(psum2) : "v"(pp));
-        }
-#else
         psum += st[P][e0 >> 4][e0 & 15];
         psum += st[P][e1 >> 4][e1 & 15];
-#endif
         if (has_next) mx = max3_asm(mx, st[N][e0 >> 4][e0 & 15], st[N][e1 >> 4][e1 & 15]);
         __builtin_amdgcn_sched_barrier(0);
       };
@@ -457,9 +435,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
       step(IC<7>{}); step(IC<8>{}); step(IC<9>{}); step(IC<10>{}); step(IC<11>{}); step(IC<12>{}); step(IC<13>{});
       step(IC<14>{}); step(IC<15>{});
     }
-#ifdef MAVLM_ATTN3_PK
-    psum = psum2[0] + psum2[1];
-#endif
     l_run += psum;
 
     // reference maximum for tile t+1 (after P.V(t): the rescale touches O)

@@ -6,14 +6,18 @@
 //     workgroup per CU, 128 KiB LDS = 2 stages x {A0,A1,B0,B1} half-tiles of 128 rows x 64 k (16 KiB each).
 //   * Operands arrive by LDS-DMA (16-byte global_load_lds), XOR-swizzled through the per-lane SOURCE address;
 //     a half-tile is 2 DMA instructions per wave.
-//   * A K-tile is consumed in 4 phases of 16 MFMAs (one 64x32 quadrant of the wave tile x K=64):
-//        phase 1: read A(rows 0-63) + all of B into registers (16 ds_read_b128), quadrant (0,0)
-//        phase 2: quadrant (0,1)            phase 3: read A(rows 64-127) (8 reads), quadrant (1,1)
-//        phase 4: quadrant (1,0)
-//     so the B half-tiles of the stage are dead after phase 1 and the A half-tiles after phase 3, and every phase
-//     re-stages ONE half-tile: phase 1 -> A1 of K-tile kt+1 (other stage), phases 2,3,4 -> B0,B1,A0 of K-tile kt+2
-//     (this stage).  Loads therefore stay in flight across barriers; the only vmcnt wait is a COUNTED one per K-tile
-//     (vmcnt(6): the three youngest half-tiles stay in flight), never 0 inside the loop.
+//   * A K-tile is consumed in 4 phases of 16 MFMAs (one 64x32 quadrant of the wave tile x K=64), every phase an L
+//     segment (fragment reads + DMA issue) and an M segment (the MFMAs):
+//        phase 1: read A(rows 0-63) + B(columns 0-31)   (12 ds_read_b128), quadrant (0,0)
+//        phase 2: read B(columns 32-63) (4),  DMA A1 of K-tile kt+1 (other stage),  quadrant (0,1)
+//        phase 3: read A(rows 64-127) (8),    DMA B0 of K-tile kt+2 (this stage),   quadrant (1,1)
+//        phase 4: no reads,                   DMA B1 + A0 of K-tile kt+2, the counted wait,  quadrant (1,0)
+//     so the B half-tiles of the stage are dead after phase 2 and the A half-tiles after phase 3.  (Round 1 read all of
+//     B in phase 1 and issued one half-tile per phase: L segments of 16 / 0 / 8 / 0 reads + 1 DMA each, the first far
+//     longer than the 256-clock M segment of the other wave group it should hide behind; 12 / 4 / 8 / 0 reads with
+//     0 / 1 / 1 / 2 DMAs measured 2-4 % faster on every shape, tests/diag_gemm_ablate.sh.)  Loads stay in flight across
+//     barriers; the only vmcnt wait is a COUNTED one per K-tile (vmcnt(6): the three youngest half-tiles stay in
+//     flight), never 0 inside the loop.
 //   * Raw s_barrier (a __syncthreads() would drain the DMA queue), MFMA clusters bracketed by s_setprio.
 //   * Ping-pong: every phase is two barrier segments, L (fragment reads + DMA issue + the counted wait) and M (16
 //     MFMAs).  Waves 4-7 run ONE SEGMENT BEHIND waves 0-3 (they execute one extra s_barrier before their first
@@ -26,12 +30,16 @@
 // Hazards (LDS-DMA is ordered by nothing but the issuing wave's vmcnt + a barrier), with g = global barrier index,
 // the leading group executing segment g and the trailing group segment g-1, K-tile kt = segments 8kt+1 .. 8kt+8
 // (L1 M1 L2 M2 L3 M3 L4 M4), stage s = kt & 1:
-//   reads of stage s: L1 (A rows 0-63 + B) and L3 (A rows 64-127): g = 8kt+1, 8kt+5 (leading), 8kt+2, 8kt+6 (trailing);
-//        every read is retired by the lgkmcnt(0) at the top of the following M segment.
-//   WAR  B half-tiles of s are dead from g = 8kt+3, A half-tiles from g = 8kt+7.  Re-staging (K-tile kt+2) is issued
-//        by the leading group in L2 (g = 8kt+3: B0), L3 (8kt+5: B1), L4 (8kt+7: A0) and the next L1 (8kt+9: A1).
-//   RAW  K-tile kt+1 is first read at g = 8kt+9.  Its last half-tile (A1) is issued in L1 of kt; both groups wait
-//        vmcnt(6) in L4 (g = 8kt+7 / 8kt+8) and pass a barrier before g = 8kt+9.
+//   reads of stage s: L1 (A rows 0-63, B columns 0-31), L2 (B columns 32-63), L3 (A rows 64-127): g = 8kt+1, +3, +5
+//        (leading), 8kt+2, +4, +6 (trailing); every read is retired by the lgkmcnt(0) at the top of the following M
+//        segment.
+//   WAR  B half-tiles of s are dead from g = 8kt+5, A0 (read by the leading group only) from g = 8kt+7, A1 (trailing
+//        group only) from g = 8kt+8.  Re-staging (K-tile kt+2) is issued by the leading group in L3 (g = 8kt+5: B0), L4
+//        (8kt+7: B1, A0) and the next K-tile's L2 (8kt+11: A1).  (A DMA issued at barrier index g lands hundreds of
+//        clocks later; the trailing group's last reads of a half-tile retire at the top of the same index.)
+//   RAW  K-tile kt+1 is first read at g = 8kt+9.  Its last half-tile (A1) is issued in L2 of kt; both groups wait
+//        vmcnt(6) in L4 (g = 8kt+7 / 8kt+8) - the six youngest DMAs are B0, B1, A0 of kt+2 - and pass a barrier before
+//        g = 8kt+9.
 #include "mavlm_common.h"
 #include "mavlm_kernels.h"
 
@@ -174,20 +182,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
       af[mt][1] = *(const typename T::vec8*)(st + offA + mh * 8192 + mt * 2048 + ck1);
     }
   };
-  auto read_b = [&](const char* st) {
-#ifdef MAVLM_GEMM_ABLATE_READS
-    if (ablate_kt > 0) return;
-#endif
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      bf[nt][0] = *(const typename T::vec8*)(st + offB + nt * 2048 + ck0);
-      bf[nt][1] = *(const typename T::vec8*)(st + offB + nt * 2048 + ck1);
-    }
-  };
 #ifdef MAVLM_GEMM_ABLATE_MFMA
 #define MAVLM_QUADRANT(MH, NH) { asm volatile("" : "+v"(af[0][0]), "+v"(bf[0][0])); }
 #else
   auto read_b_half = [&](const char* st, int nh) {
+#ifdef MAVLM_GEMM_ABLATE_READS
+    if (ablate_kt > 0) return;
+#endif
 #pragma unroll
     for (int nt = 2 * nh; nt < 2 * nh + 2; ++nt) {
       bf[nt][0] = *(const typename T::vec8*)(st + offB + nt * 2048 + ck0);
@@ -213,39 +214,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
 #ifdef MAVLM_GEMM_ABLATE_READS
     ablate_kt = kt;
 #endif
-#ifndef MAVLM_GEMM_SCHED2
-    // -------- phase 1
-    read_a(st, 0);
-    read_b(st);
-    if (kt + 1 < nk) dma(s ^ 1, 1, kt + 1);              // A1 of the next K-tile
-    MAVLM_BAR();
-    MAVLM_LGKM0();
-    MAVLM_QUADRANT(0, 0)
-    MAVLM_BAR();
-    // -------- phase 2   (B half-tiles of this stage are dead: everything is in registers)
-    if (kt + 2 < nk) dma(s, 2, kt + 2);
-    MAVLM_BAR();
-    MAVLM_QUADRANT(0, 1)
-    MAVLM_BAR();
-    // -------- phase 3
-    read_a(st, 1);
-    if (kt + 2 < nk) dma(s, 3, kt + 2);
-    MAVLM_BAR();
-    MAVLM_LGKM0();
-    MAVLM_QUADRANT(1, 1)
-    MAVLM_BAR();
-    // -------- phase 4   (A half-tiles dead)
-    if (kt + 2 < nk) {
-      dma(s, 0, kt + 2);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // K-tile kt+1 landed; 3 half-tiles of kt+2 stay in flight
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    MAVLM_BAR();
-    MAVLM_QUADRANT(1, 0)
-    MAVLM_BAR();
-#else
-    // (experiment) reads 12 / 4 / 8 / 0 and DMAs 0 / 1 / 1 / 2 per L segment instead of 16 / 0 / 8 / 0 and 1 / 1 / 1 / 1
     // -------- phase 1
     read_a(st, 0);
     read_b_half(st, 0);
@@ -278,7 +246,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
     MAVLM_BAR();
     MAVLM_QUADRANT(1, 0)
     MAVLM_BAR();
-#endif
   }
   if (!trailing) MAVLM_BAR();          // matches the trailing group's last barrier
 #undef MAVLM_QUADRANT

@@ -17,14 +17,8 @@
 //     workgroup per CU, 128 KiB LDS = 2 stages x {A0,A1,B0,B1} half-tiles of 128 rows x 64 k (16 KiB each).
 //   * Operands arrive by LDS-DMA (16-byte global_load_lds), XOR-swizzled through the per-lane SOURCE address;
 //     a half-tile is 2 DMA instructions per wave.
-//   * A K-tile is consumed in 4 phases of 16 MFMAs (one 64x32 quadrant of the wave tile x K=64):
-//        phase 1: read A(rows 0-63) + all of B into registers (16 ds_read_b128), quadrant (0,0)
-//        phase 2: quadrant (0,1)            phase 3: read A(rows 64-127) (8 reads), quadrant (1,1)
-//        phase 4: quadrant (1,0)
-//     so the B half-tiles of the stage are dead after phase 1 and the A half-tiles after phase 3, and every phase
-//     re-stages ONE half-tile: phase 1 -> A1 of K-tile kt+1 (other stage), phases 2,3,4 -> B0,B1,A0 of K-tile kt+2
-//     (this stage).  Loads therefore stay in flight across barriers; the only vmcnt wait is a COUNTED one per K-tile
-//     (vmcnt(6): the three youngest half-tiles stay in flight), never 0 inside the loop.
+//   * A K-tile is consumed in 4 phases of 16 MFMAs (one 64x32 quadrant of the wave tile x K=64); reads 12 / 4 / 8 / 0 and
+//     DMAs 0 / 1 / 1 / 2 half-tiles per phase, one counted vmcnt(6) per K-tile: the table in gemm256.hip.
 //   * Raw s_barrier (a __syncthreads() would drain the DMA queue), MFMA clusters bracketed by s_setprio.
 //   * Ping-pong: every phase is two barrier segments, L (fragment reads + DMA issue + the counted wait) and M (16
 //     MFMAs).  Waves 4-7 run ONE SEGMENT BEHIND waves 0-3 (they execute one extra s_barrier before their first
@@ -37,12 +31,8 @@
 // Hazards (LDS-DMA is ordered by nothing but the issuing wave's vmcnt + a barrier), with g = global barrier index,
 // the leading group executing segment g and the trailing group segment g-1, K-tile kt = segments 8kt+1 .. 8kt+8
 // (L1 M1 L2 M2 L3 M3 L4 M4), stage s = kt & 1:
-//   reads of stage s: L1 (A rows 0-63 + B) and L3 (A rows 64-127): g = 8kt+1, 8kt+5 (leading), 8kt+2, 8kt+6 (trailing);
-//        every read is retired by the lgkmcnt(0) at the top of the following M segment.
-//   WAR  B half-tiles of s are dead from g = 8kt+3, A half-tiles from g = 8kt+7.  Re-staging (K-tile kt+2) is issued
-//        by the leading group in L2 (g = 8kt+3: B0), L3 (8kt+5: B1), L4 (8kt+7: A0) and the next L1 (8kt+9: A1).
-//   RAW  K-tile kt+1 is first read at g = 8kt+9.  Its last half-tile (A1) is issued in L1 of kt; both groups wait
-//        vmcnt(6) in L4 (g = 8kt+7 / 8kt+8) and pass a barrier before g = 8kt+9.
+//   (reads / WAR / RAW per barrier index: as listed in gemm256.hip; the bias DMA of a tile is the oldest VMEM operation of
+//   its first K-tile's phase 2, older than the six DMAs the counted wait leaves in flight.)
 #include "mavlm_common.h"
 #include "mavlm_kernels.h"
 
@@ -189,9 +179,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
       af[mt][1] = *(const typename T::vec8*)(st + offA_f + mh * 8192 + mt * 2048 + ck1);
     }
   };
-  auto read_b = [&](const char* st) {
+  auto read_b_half = [&](const char* st, int nh) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 2 * nh; nt < 2 * nh + 2; ++nt) {
       bf[nt][0] = *(const typename T::vec8*)(st + offB_f + nt * 2048 + ck0);
       bf[nt][1] = *(const typename T::vec8*)(st + offB_f + nt * 2048 + ck1);
     }
@@ -214,27 +204,29 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
       const char* st = smem + (v & 1) * STAGE2;
       // -------- phase 1
       read_a(st, 0);
-      read_b(st);
-      if (kt == 0 && it > 0) dma_bias(it, n0c);              // oldest VMEM operation of this K-tile
-      if (v + 1 < VT) dma(1, v + 1, it);                     // A1 of the next virtual K-tile
+      read_b_half(st, 0);
       MAVLM_BAR();
       MAVLM_LGKM0();
       MAVLM_QUADRANT(0, 0)
       MAVLM_BAR();
-      // -------- phase 2   (B half-tiles of this stage are dead: everything is in registers)
-      if (v + 2 < VT) dma(2, v + 2, it);
+      // -------- phase 2
+      read_b_half(st, 1);
+      if (kt == 0 && it > 0) dma_bias(it, n0c);              // oldest VMEM operation of this K-tile
+      if (v + 1 < VT) dma(1, v + 1, it);                     // A1 of the next virtual K-tile
       MAVLM_BAR();
+      MAVLM_LGKM0();
       MAVLM_QUADRANT(0, 1)
       MAVLM_BAR();
-      // -------- phase 3
+      // -------- phase 3   (B half-tiles of this stage are dead: everything is in registers)
       read_a(st, 1);
-      if (v + 2 < VT) dma(3, v + 2, it);
+      if (v + 2 < VT) dma(2, v + 2, it);
       MAVLM_BAR();
       MAVLM_LGKM0();
       MAVLM_QUADRANT(1, 1)
       MAVLM_BAR();
       // -------- phase 4   (A half-tiles dead)
       if (v + 2 < VT) {
+        dma(3, v + 2, it);
         dma(0, v + 2, it);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // K-tile v+1 landed; 3 half-tiles of v+2 stay in flight
       } else {

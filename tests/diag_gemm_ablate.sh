@@ -10,7 +10,6 @@ mkdir -p $OUT /tmp/gab
 VARIANTS=${VARIANTS:-"base READS DMA MFMA BAR"}
 for v in $VARIANTS; do
   D=""; [ $v != base ] && D="-DMAVLM_GEMM_ABLATE_$v"
-  [ $v = SCHED2 ] && D="-DMAVLM_GEMM_SCHED2"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $D -c -o /tmp/gab/gemm256_$v.o $SRC/gemm256.hip &
 done
 wait
