@@ -69,6 +69,7 @@ constexpr int GEMM256_LDS = 2 * STAGE2;      // 128 KiB
     __builtin_amdgcn_sched_barrier(0);                         \
   } while (0)
 
+
 __device__ __forceinline__ float gelu_erf2(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // MT1 = 16-row MFMA tiles in the SECOND 64-row slice of a wave's rows: 4 -> 256-row workgroup tile (wave tile 128x64),
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
     __builtin_amdgcn_s_setprio(0);                                                          \
   }
 #endif
+
 
   if (trailing) MAVLM_BAR();           // ping-pong skew: pairs with the leading group's first in-loop barrier
 
