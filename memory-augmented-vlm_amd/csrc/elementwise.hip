@@ -63,6 +63,80 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// D % 8 == 0: a lane owns chunks of 8 consecutive elements (two float4 in, ONE 16-byte residual load and ONE 16-byte
+// store per chunk - the 4-element form above moves the 16-bit data 8 bytes per lane)
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void layernorm8_kernel(const float* __restrict__ x, const uint16_t* __restrict__ res,
+                                                         int ldr, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, uint16_t* __restrict__ out,
+                                                         int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = D >> 3;
+  const f32x4* xr = (const f32x4*)(x + (size_t)row * D);
+  f32x4 v[NC][2];
+  u32x4 rv[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int j = i * 64 + lane;
+    if (j < nch) {
+      v[i][0] = xr[2 * j];
+      v[i][1] = xr[2 * j + 1];
+      if (res != nullptr) rv[i] = *(const u32x4*)(res + (size_t)row * ldr + 8 * j);
+    } else {
+      v[i][0] = v[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int j = i * 64 + lane;
+    if (j < nch) {
+      if (res != nullptr) {      // residual add of the Residual block, in fp32 (MemoryController.py:28)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[i][e >> 1][2 * (e & 1)] += T::to_f32((uint16_t)(rv[i][e] & 0xffffu));
+          v[i][e >> 1][2 * (e & 1) + 1] += T::to_f32((uint16_t)(rv[i][e] >> 16));
+        }
+      }
+      s += ((v[i][0][0] + v[i][0][1]) + (v[i][0][2] + v[i][0][3])) + ((v[i][1][0] + v[i][1][1]) + (v[i][1][2] + v[i][1][3]));
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int j = i * 64 + lane;
+    if (j < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[i][e >> 2][e & 3] - mean;
+        ss += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+  uint16_t* orow = out + (size_t)row * D;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int j = i * 64 + lane;
+    if (j < nch) {
+      u32x4 o;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const f32x4 g = ((const f32x4*)gamma)[2 * j + hf];
+        const f32x4 b = ((const f32x4*)beta)[2 * j + hf];
+        const u32x2 w = pack4<T>((v[i][hf][0] - mean) * rstd * g[0] + b[0], (v[i][hf][1] - mean) * rstd * g[1] + b[1],
+                                 (v[i][hf][2] - mean) * rstd * g[2] + b[2], (v[i][hf][3] - mean) * rstd * g[3] + b[3]);
+        o[2 * hf] = w[0];
+        o[2 * hf + 1] = w[1];
+      }
+      *(u32x4*)(orow + 8 * j) = o;
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void row_add_kernel(const uint16_t* __restrict__ x, const int64_t* __restrict__ src,
                                                       const uint16_t* __restrict__ table,
@@ -136,9 +210,24 @@ void ln_launch(const float* x, const void* res, int ldr, const float* g, const f
                      (uint16_t*)out, rows, D, eps);
 }
 
+template <typename T, int NC>
+void ln8_launch(const float* x, const void* res, int ldr, const float* g, const float* b, void* out, int rows, int D,
+                float eps, hipStream_t s) {
+  hipLaunchKernelGGL((layernorm8_kernel<T, NC>), dim3((rows + 3) / 4), dim3(256), 0, s, x, (const uint16_t*)res, ldr, g, b,
+                     (uint16_t*)out, rows, D, eps);
+}
+
 template <typename T>
 hipError_t ln_dispatch(const float* x, const void* res, int ldr, const float* g, const float* b, void* out, int rows, int D,
                        float eps, hipStream_t s) {
+  if ((D & 7) == 0 && (ldr & 7) == 0 && D <= 4096) {       // 16-byte accesses to the 16-bit data
+    const int nc = (D / 8 + 63) / 64;
+    if (nc <= 1) ln8_launch<T, 1>(x, res, ldr, g, b, out, rows, D, eps, s);
+    else if (nc <= 2) ln8_launch<T, 2>(x, res, ldr, g, b, out, rows, D, eps, s);
+    else if (nc <= 4) ln8_launch<T, 4>(x, res, ldr, g, b, out, rows, D, eps, s);
+    else ln8_launch<T, 8>(x, res, ldr, g, b, out, rows, D, eps, s);
+    return hipGetLastError();
+  }
   const int nv = (D / 4 + 63) / 64;
   if (nv <= 1) ln_launch<T, 1>(x, res, ldr, g, b, out, rows, D, eps, s);
   else if (nv <= 2) ln_launch<T, 2>(x, res, ldr, g, b, out, rows, D, eps, s);
