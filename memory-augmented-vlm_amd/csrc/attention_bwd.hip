@@ -31,6 +31,9 @@ constexpr int BTILE = BKT * BHD * 2;             // 16 KiB
 constexpr int BSTAT = 4 * BTILE;                 // 2 stages x {lse2[64], delta[64]} floats
 constexpr int BWD_LDS = 4 * BTILE + 2 * 512;
 
+template <int V>
+struct BIC { static constexpr int value = V; };
+
 __device__ __forceinline__ int bimg_x(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 template <typename T, int MODE>
@@ -71,35 +74,50 @@ __global__ __launch_bounds__(256, (MODE == 3 ? 1 : 2)) void attn_bwd_kernel(cons
     del_l = delta[(size_t)h * R + xrow];
   }
 
-  // ---- staging through registers: thread handles chunks row = (tid>>4) + 16 i, ch = tid & 15 of both images
-  const int srow = tid >> 4, sch = tid & 15;
-  const int st_off = 256 * srow + 16 * (sch ^ bimg_x(srow));   // + 4096 i
-  const uint16_t* yg = Y + h * BHD + sch * 8;
-  const uint16_t* y2g = Y2 + h * BHD + sch * 8;
-  u32x4 yreg[4], y2reg[4];
-  float sreg = 0.f;
-  auto load_tile = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int row = t * BKT + srow + 16 * i;
-      row = row < NY ? row : NY - 1;
-      yreg[i] = *(const u32x4*)(yg + (size_t)row * ldy);
-      y2reg[i] = *(const u32x4*)(y2g + (size_t)row * ldy2);
-    }
-    if (MODE != 0 && tid < 128) {                 // per-row statistics of the streamed queries (MODE 1-3)
-      const int q = t * BKT + (tid & 63);
-      if (tid < 64) sreg = q < NY ? lse2[(size_t)h * R + q] : INFINITY;    // masked query: exp2(-inf) = 0
-      else sreg = q < NY ? delta[(size_t)h * R + q] : 0.f;
-    }
+  // ---- staging by LDS-DMA (buffer loads, as attn_fwd3_kernel): instruction i (0..3) of wave w writes the 1 KiB block of
+  // rows 16 i + 4 w + (lane>>4) of an image; physical chunk lane&15 of a row holds logical chunk (lane&15) ^ x(row),
+  // x(row) = ((lane>>4)<<2) | w for every i.  One descriptor per streamed operand over this head's columns, ending after
+  // row NY-1: rows of a ragged last tile read as ZEROS, and so do their statistics (lse2 = 0, delta = 0) - a zero row
+  // contributes nothing to any product (dO / Q / K rows of zeros; MODE 0 masks the keys past the end explicitly).
+  // (Round 1 staged through registers: 32 VGPRs of transit data and 8 ds_write_b128 per thread and tile.)
+  const int drow = 4 * wave + (lane >> 4);
+  const int dch = (lane & 15) ^ (((lane >> 4) << 2) | wave);
+  auto rsrc_of = [&](const void* base, uint32_t bytes) {
+    const uintptr_t a = (uintptr_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes),
+                                             0x00020000);
   };
-  auto store_tile = [&](int buf) {
-    char* yb = smem + buf * 2 * BTILE;
+  const __amdgpu_buffer_rsrc_t yrs = rsrc_of(Y + h * BHD, (uint32_t)(NY - 1) * (uint32_t)ldy * 2u + (uint32_t)BHD * 2u);
+  const __amdgpu_buffer_rsrc_t y2rs = rsrc_of(Y2 + h * BHD, (uint32_t)(NY - 1) * (uint32_t)ldy2 * 2u + (uint32_t)BHD * 2u);
+  const __amdgpu_buffer_rsrc_t lrs = rsrc_of(lse2 + (size_t)h * R, (uint32_t)NY * 4u);     // MODE 1-3: NY == R (queries)
+  const __amdgpu_buffer_rsrc_t drs = rsrc_of(delta + (size_t)h * R, (uint32_t)NY * 4u);
+  int yoff[4], y2off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    yoff[i] = ((drow + 16 * i) * ldy + dch * 8) * 2;
+    y2off[i] = ((drow + 16 * i) * ldy2 + dch * 8) * 2;
+  }
+  const unsigned lds_wave = (unsigned)(uintptr_t)(MAVLM_LDS char*)smem + wave * 1024;
+  auto dma_tile = [&](int t, int buf) {
+    unsigned base = lds_wave;
+    asm volatile("" : "+s"(base));            // M0 = base + constant stays a one-instruction recompute
+    const unsigned dst = base + buf * 2 * BTILE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *(u32x4*)(yb + st_off + 4096 * i) = yreg[i];
-      *(u32x4*)(yb + BTILE + st_off + 4096 * i) = y2reg[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrs, (MAVLM_LDS void*)(uintptr_t)(dst + 4096 * i), 16, yoff[i],
+                                               t * BKT * ldy * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(y2rs, (MAVLM_LDS void*)(uintptr_t)(dst + BTILE + 4096 * i), 16, y2off[i],
+                                               t * BKT * ldy2 * 2, 0, 0);
     }
-    if (MODE != 0 && tid < 128) *(float*)(smem + BSTAT + buf * 512 + 4 * tid) = sreg;
+    if (MODE != 0 && wave < 2) {              // per-row statistics of the streamed queries: wave 0 lse2, wave 1 delta
+      unsigned sb = (unsigned)(uintptr_t)(MAVLM_LDS char*)smem;
+      asm volatile("" : "+s"(sb));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wave == 0 ? lrs : drs,
+                                               (MAVLM_LDS void*)(uintptr_t)(sb + BSTAT + buf * 512 + wave * 256), 4, lane * 4,
+                                               t * BKT * 4, 0, 0);
+    }
   };
 
   // ---- fragment read geometry
@@ -121,18 +139,20 @@ __global__ __launch_bounds__(256, (MODE == 3 ? 1 : 2)) void attn_bwd_kernel(cons
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[d][i] = 0.f; acc2[d][i] = 0.f; }
 
-  load_tile(0);
-  store_tile(0);
+  dma_tile(0, 0);
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
     asm volatile("" : "+v"(xf[ks]));
     if (MODE != 2) asm volatile("" : "+v"(x2f[ks]));
   }
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
-    if (t + 1 < nt) load_tile(t + 1);
+    if (t + 1 < nt) dma_tile(t + 1, cur ^ 1);     // the other stage is dead since the barrier that ended tile t-1
     const char* yb = smem + cur * 2 * BTILE;                   // Y image; Y2 image at + BTILE
     const char* zb = (MODE == 2) ? yb + BTILE : yb;            // image read transposed
     const unsigned zbase = (unsigned)(uintptr_t)(MAVLM_LDS const char*)zb;
@@ -169,6 +189,7 @@ __global__ __launch_bounds__(256, (MODE == 3 ? 1 : 2)) void attn_bwd_kernel(cons
           const float l = (MODE == 0) ? lse_l : l4[j];
           float p = __builtin_amdgcn_exp2f(tt[i] * c - l);
           if (MODE == 0 && ragged && t * BKT + 32 * b + j + 8 * g + 4 * hh >= NY) p = 0.f;   // key past the end
+          // (MODE 1-3: a query past the end has zero Y / Y2 rows and zero statistics - p = 1, every product 0)
           if (MODE == 2) tt[i] = p;
           else tt[i] = p * (dp[i] - ((MODE == 0) ? del_l : d4[j]));
           if (MODE == 3) dp[i] = p;                                   // dP is consumed: its registers carry P
@@ -187,26 +208,64 @@ __global__ __launch_bounds__(256, (MODE == 3 ? 1 : 2)) void attn_bwd_kernel(cons
           pf[s] = __builtin_bit_cast(typename T::vec8, w);
         }
       }
-      // ---- A^T += Z^T . E^T
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const typename T::vec4 lo = T::ds_read_tr(zbase + zaddr[db][0] + 256 * (32 * b + 16 * s));
-          const typename T::vec4 hi = T::ds_read_tr(zbase + zaddr[db][1] + 256 * (32 * b + 16 * s));
-          const typename T::vec8 zf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          acc[db] = T::mfma32(zf, ef[s], acc[db]);
-          if (MODE == 3) {
-            const typename T::vec4 lo2 = T::ds_read_tr(z2base + zaddr[db][0] + 256 * (32 * b + 16 * s));
-            const typename T::vec4 hi2 = T::ds_read_tr(z2base + zaddr[db][1] + 256 * (32 * b + 16 * s));
-            const typename T::vec8 z2f = __builtin_shufflevector(lo2, hi2, 0, 1, 2, 3, 4, 5, 6, 7);
-            acc2[db] = T::mfma32(z2f, pf[s], acc2[db]);
+      // ---- A^T += Z^T . E^T.  The transposed reads are inline asm with hand-counted lgkmcnt waits (as attn_fwd3_kernel):
+      // through the builtin hipcc puts an s_waitcnt vmcnt(0) in front of the first one (it cannot prove that the read
+      // does not alias the LDS-DMA in flight) - that drained the next tile's DMAs in the middle of this one.  Step
+      // i = 2 db + s issues the reads of step i + 2, then waits until only the younger ones are outstanding (in-order
+      // completion: LDS operations hipcc may have placed in between only make the wait more conservative).
+      {
+        const unsigned zbase_b = zbase + 256 * 32 * b, z2base_b = z2base + 256 * 32 * b;
+        constexpr int NRD = (MODE == 3) ? 4 : 2;               // reads per step
+        u32x2 zlo[8], zhi[8], z2lo[8], z2hi[8];
+        auto zrd = [&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          constexpr int db = i >> 1, sx = i & 1;
+          const unsigned a0 = zbase_b + zaddr[db][0], a1 = zbase_b + zaddr[db][1];
+          u32x2 lo, hi;
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "i"(256 * 16 * sx + 0));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "i"(256 * 16 * sx + 0));
+          zlo[i] = lo; zhi[i] = hi;
+          if constexpr (MODE == 3) {
+            const unsigned c0 = z2base_b + zaddr[db][0], c1 = z2base_b + zaddr[db][1];
+            u32x2 lo2, hi2;
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo2) : "v"(c0), "i"(256 * 16 * sx + 0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi2) : "v"(c1), "i"(256 * 16 * sx + 0));
+            z2lo[i] = lo2; z2hi[i] = hi2;
           }
-        }
+        };
+        auto zstep = [&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          constexpr int db = i >> 1, sx = i & 1;
+          if constexpr (i + 2 < 8) zrd(BIC<(i + 2 < 8 ? i + 2 : 7)>{});
+          constexpr int ahead = (7 - i) < 2 ? (7 - i) : 2;
+          if constexpr (ahead * NRD == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          else if constexpr (ahead * NRD == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+          else if constexpr (ahead * NRD == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);                    // keep the MFMA below the wait
+          u32x4 both;
+          both[0] = zlo[i][0]; both[1] = zlo[i][1]; both[2] = zhi[i][0]; both[3] = zhi[i][1];
+          acc[db] = T::mfma32(__builtin_bit_cast(typename T::vec8, both), ef[sx], acc[db]);
+          if constexpr (MODE == 3) {
+            u32x4 b2;
+            b2[0] = z2lo[i][0]; b2[1] = z2lo[i][1]; b2[2] = z2hi[i][0]; b2[3] = z2hi[i][1];
+            acc2[db] = T::mfma32(__builtin_bit_cast(typename T::vec8, b2), pf[sx], acc2[db]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // nothing older than the reads below is outstanding
+        zrd(BIC<0>{});
+        zrd(BIC<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        zstep(BIC<0>{}); zstep(BIC<1>{}); zstep(BIC<2>{}); zstep(BIC<3>{});
+        zstep(BIC<4>{}); zstep(BIC<5>{}); zstep(BIC<6>{}); zstep(BIC<7>{});
+      }
     }
 
-    if (t + 1 < nt) store_tile(cur ^ 1);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMAs of tile t+1 have landed
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   }
 
   // ---- epilogue: Out[x][h*128 + 32db + 8g + 4hh + 0..3] = A^T * out_scale
