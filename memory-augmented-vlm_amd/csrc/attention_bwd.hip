@@ -100,6 +100,27 @@ __global__ __launch_bounds__(256, (MODE == 3 ? 1 : 2)) void attn_bwd_kernel(cons
     y2off[i] = ((drow + 16 * i) * ldy2 + dch * 8) * 2;
   }
   const unsigned lds_wave = (unsigned)(uintptr_t)(MAVLM_LDS char*)smem + wave * 1024;
+  auto dma_piece = [&](int t, int buf, auto jc) {   // piece j: 0-3 = rows 16 j.. of Y, 4-7 = of Y2
+    constexpr int j = decltype(jc)::value;
+    unsigned base = lds_wave;
+    asm volatile("" : "+s"(base));
+    const unsigned dst = base + buf * 2 * BTILE;
+    if constexpr (j < 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrs, (MAVLM_LDS void*)(uintptr_t)(dst + 4096 * j), 16, yoff[j],
+                                               t * BKT * ldy * 2, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(y2rs, (MAVLM_LDS void*)(uintptr_t)(dst + BTILE + 4096 * (j - 4)), 16,
+                                               y2off[j - 4], t * BKT * ldy2 * 2, 0, 0);
+  };
+  auto dma_stat = [&](int t, int buf) {
+    if (MODE != 0 && wave < 2) {              // per-row statistics of the streamed queries: wave 0 lse2, wave 1 delta
+      unsigned sb = (unsigned)(uintptr_t)(MAVLM_LDS char*)smem;
+      asm volatile("" : "+s"(sb));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wave == 0 ? lrs : drs,
+                                               (MAVLM_LDS void*)(uintptr_t)(sb + BSTAT + buf * 512 + wave * 256), 4, lane * 4,
+                                               t * BKT * 4, 0, 0);
+    }
+  };
   auto dma_tile = [&](int t, int buf) {
     unsigned base = lds_wave;
     asm volatile("" : "+s"(base));            // M0 = base + constant stays a one-instruction recompute
@@ -152,7 +173,8 @@ __global__ __launch_bounds__(256, (MODE == 3 ? 1 : 2)) void attn_bwd_kernel(cons
 
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
-    if (t + 1 < nt) dma_tile(t + 1, cur ^ 1);     // the other stage is dead since the barrier that ended tile t-1
+    // (tile t+1 goes into the other stage - dead since the barrier that ended tile t-1 - piece by piece inside half 0;
+    // a tile past the last one lies behind the descriptors' end: zeros into a stage nobody reads again, no branch)
     const char* yb = smem + cur * 2 * BTILE;                   // Y image; Y2 image at + BTILE
     const char* zb = (MODE == 2) ? yb + BTILE : yb;            // image read transposed
     const unsigned zbase = (unsigned)(uintptr_t)(MAVLM_LDS const char*)zb;
@@ -160,20 +182,52 @@ __global__ __launch_bounds__(256, (MODE == 3 ? 1 : 2)) void attn_bwd_kernel(cons
     const float* stat = (const float*)(smem + BSTAT + cur * 512);
     const bool ragged = (t == nt - 1) && (NY & (BKT - 1));
 
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      // ---- T^T = Y . X^T and (dQ, dK) dP^T = Y2 . X2^T for the 32 streamed rows of half b
+    const unsigned ybase = (unsigned)(uintptr_t)(MAVLM_LDS const char*)yb;
+    auto half = [&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      // ---- T^T = Y . X^T and (dQ, dK) dP^T = Y2 . X2^T for the 32 streamed rows of half b.  Row reads two k-steps ahead
+      // with hand-counted waits (inline asm, as the transposed reads below); during half 0 the eight DMA pieces of the
+      // NEXT tile are issued one per k-step between the MFMAs instead of as a burst behind the barrier (a 1 KiB piece
+      // holds a wave's issue for ~100 clocks: attn_fwd3_kernel's stamps), the statistics DMA at the first step of half 1.
       f32x16 tt, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { tt[i] = 0.f; dp[i] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const typename T::vec8 yf = *(const typename T::vec8*)(yb + yaddr[ks] + 8192 * b);
-        tt = T::mfma32(yf, xf[ks], tt);
-        if (MODE != 2) {
-          const typename T::vec8 y2f = *(const typename T::vec8*)(yb + BTILE + yaddr[ks] + 8192 * b);
-          dp = T::mfma32(y2f, x2f[ks], dp);
-        }
+      {
+        constexpr int NS = (MODE != 2) ? 2 : 1;                 // reads per step
+        u32x4 yfr[8], y2fr[8];
+        auto yrd = [&](auto ic) {
+          constexpr int ks = decltype(ic)::value;
+          const unsigned a = ybase + (unsigned)yaddr[ks];
+          u32x4 v;
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "i"(8192 * b));
+          yfr[ks] = v;
+          if constexpr (MODE != 2) {
+            u32x4 v2;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v2) : "v"(a), "i"(BTILE + 8192 * b));
+            y2fr[ks] = v2;
+          }
+        };
+        auto sstep = [&](auto ic) {
+          constexpr int ks = decltype(ic)::value;
+          if constexpr (ks + 2 < 8) yrd(BIC<(ks + 2 < 8 ? ks + 2 : 7)>{});
+          constexpr int ahead = (7 - ks) < 2 ? (7 - ks) : 2;
+          if constexpr (ahead * NS == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          else if constexpr (ahead * NS == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+          else if constexpr (ahead * NS == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          tt = T::mfma32(__builtin_bit_cast(typename T::vec8, yfr[ks]), xf[ks], tt);
+          if constexpr (MODE != 2) dp = T::mfma32(__builtin_bit_cast(typename T::vec8, y2fr[ks]), x2f[ks], dp);
+          if constexpr (b == 0) dma_piece(t + 1, cur ^ 1, BIC<ks>{});
+          if constexpr (b == 1 && ks == 0) dma_stat(t + 1, cur ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        yrd(BIC<0>{});
+        yrd(BIC<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        sstep(BIC<0>{}); sstep(BIC<1>{}); sstep(BIC<2>{}); sstep(BIC<3>{});
+        sstep(BIC<4>{}); sstep(BIC<5>{}); sstep(BIC<6>{}); sstep(BIC<7>{});
       }
       // ---- E = P (dV) or dS = P o (dP - delta) (dQ, dK); streamed row of element i: 32b + (i&3) + 8(i>>2) + 4hh
 #pragma unroll
@@ -260,7 +314,9 @@ __global__ __launch_bounds__(256, (MODE == 3 ? 1 : 2)) void attn_bwd_kernel(cons
         zstep(BIC<0>{}); zstep(BIC<1>{}); zstep(BIC<2>{}); zstep(BIC<3>{});
         zstep(BIC<4>{}); zstep(BIC<5>{}); zstep(BIC<6>{}); zstep(BIC<7>{});
       }
-    }
+    };
+    half(BIC<0>{});
+    half(BIC<1>{});
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMAs of tile t+1 have landed
     asm volatile("" ::: "memory");
@@ -328,6 +384,11 @@ void launch_mode(dim3 grid, hipStream_t s, const void* X, int ldx, const void* X
 
 template <typename T>
 hipError_t launch_all(const mavlm_attn_bwd_args& a, hipStream_t s) {
+  // streamed operands are addressed through 32-bit buffer offsets (one tile past the end included)
+  const double lim = 2147483648.0;
+  if (((double)a.S + 64) * a.ldk * 2.0 >= lim || ((double)a.S + 64) * a.ldv * 2.0 >= lim ||
+      ((double)a.R + 64) * a.ldq * 2.0 >= lim || ((double)a.R + 64) * a.lddo * 2.0 >= lim)
+    return hipErrorInvalidValue;
   const float c = a.scale * 1.44269504088896340736f;
   static mavlm_per_device_once once[4];
   {
