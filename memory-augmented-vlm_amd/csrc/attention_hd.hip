@@ -16,8 +16,14 @@
 #include "mavlm_common.h"
 #include "mavlm_kernels.h"
 #include <type_traits>
+#include <utility>
 
 namespace {
+
+template <int V>
+struct HIC { static constexpr int value = V; };
+template <int... I, typename F>
+__device__ __forceinline__ void hd_for_each(std::integer_sequence<int, I...>, F&& f) { (f(HIC<I>{}), ...); }
 
 constexpr int KTH = 32;                                   // keys per tile
 constexpr float RESCALE_H_LOG2 = 8.0f;
@@ -183,16 +189,41 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd_kernel(const uint16_t* __r
     pw[2] = pack2<T>(st[1][0], st[1][1]); pw[3] = pack2<T>(st[1][2], st[1][3]);
     const typename T::vec8 pf = __builtin_bit_cast(typename T::vec8, pw);
 
-    // ---- O^T += V^T.P^T : DB blocks of 16 columns, one 32-key k-step
+    // ---- O^T += V^T.P^T : DB blocks of 16 columns, one 32-key k-step.  The transposed reads are inline asm with
+    // hand-counted lgkmcnt waits (as attn_fwd3_kernel): through the builtin hipcc puts an s_waitcnt vmcnt(0) in front of
+    // the first one (it cannot prove that the read does not alias the LDS-DMA in flight), which drained the next tile's
+    // DMAs in the middle of this one.  Step db issues the two reads of step db + 2, then waits until only the younger
+    // reads are outstanding.
     const unsigned vbl = (unsigned)(uintptr_t)(MAVLM_LDS const char*)vb;
-#pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      const int gch = 2 * db;                             // + (tp>>1); sub-image = gch>>4 compile-time
-      const unsigned a0 = vbl + (gch >> 4) * SUB + vbase_off + 16 * (((gch & 15) + (tp >> 1)) ^ vx);
-      const typename T::vec4 lo = T::ds_read_tr(a0);
-      const typename T::vec4 hi = T::ds_read_tr(a0 + 4096);            // rows + 16
-      const typename T::vec8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      ot[db] = T::mfma16(vf, pf, ot[db]);
+    {
+      u32x2 vlo[DB], vhi[DB];
+      auto vrd = [&](auto ic) {
+        constexpr int db = decltype(ic)::value;
+        constexpr int gch = 2 * db;                           // + (tp>>1); sub-image = gch>>4 compile-time
+        const unsigned a0 = vbl + vbase_off + 16 * (((gch & 15) + (tp >> 1)) ^ vx);
+        u32x2 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "i"((gch >> 4) * SUB));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a0), "i"((gch >> 4) * SUB + 4096));   // rows + 16
+        vlo[db] = lo; vhi[db] = hi;
+      };
+      auto vstep = [&](auto ic) {
+        constexpr int db = decltype(ic)::value;
+        if constexpr (db + 2 < DB) vrd(HIC<(db + 2 < DB ? db + 2 : DB - 1)>{});
+        constexpr int ahead = (DB - 1 - db) < 2 ? (DB - 1 - db) : 2;
+        if constexpr (ahead == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if constexpr (ahead == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);                    // keep the MFMA below the wait
+        u32x4 both;
+        both[0] = vlo[db][0]; both[1] = vlo[db][1]; both[2] = vhi[db][0]; both[3] = vhi[db][1];
+        ot[db] = T::mfma16(__builtin_bit_cast(typename T::vec8, both), pf, ot[db]);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // nothing older than the reads below is outstanding
+      vrd(HIC<0>{});
+      if constexpr (DB > 1) vrd(HIC<1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      hd_for_each(std::make_integer_sequence<int, DB>{}, vstep);
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
