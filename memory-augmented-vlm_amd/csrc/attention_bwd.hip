@@ -183,140 +183,154 @@ __global__ __launch_bounds__(256, (MODE == 3 ? 1 : 2)) void attn_bwd_kernel(cons
     const bool ragged = (t == nt - 1) && (NY & (BKT - 1));
 
     const unsigned ybase = (unsigned)(uintptr_t)(MAVLM_LDS const char*)yb;
-    auto half = [&](auto bc) {
-      constexpr int b = decltype(bc)::value;
-      // ---- T^T = Y . X^T and (dQ, dK) dP^T = Y2 . X2^T for the 32 streamed rows of half b.  Row reads two k-steps ahead
-      // with hand-counted waits (inline asm, as the transposed reads below); during half 0 the eight DMA pieces of the
-      // NEXT tile are issued one per k-step between the MFMAs instead of as a burst behind the barrier (a 1 KiB piece
-      // holds a wave's issue for ~100 clocks: attn_fwd3_kernel's stamps), the statistics DMA at the first step of half 1.
-      f32x16 tt, dp;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { tt[i] = 0.f; dp[i] = 0.f; }
-      {
-        constexpr int NS = (MODE != 2) ? 2 : 1;                 // reads per step
-        u32x4 yfr[8], y2fr[8];
-        auto yrd = [&](auto ic) {
-          constexpr int ks = decltype(ic)::value;
-          const unsigned a = ybase + (unsigned)yaddr[ks];
-          u32x4 v;
-          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "i"(8192 * b));
-          yfr[ks] = v;
-          if constexpr (MODE != 2) {
-            u32x4 v2;
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v2) : "v"(a), "i"(BTILE + 8192 * b));
-            y2fr[ks] = v2;
-          }
-        };
-        auto sstep = [&](auto ic) {
-          constexpr int ks = decltype(ic)::value;
-          if constexpr (ks + 2 < 8) yrd(BIC<(ks + 2 < 8 ? ks + 2 : 7)>{});
-          constexpr int ahead = (7 - ks) < 2 ? (7 - ks) : 2;
-          if constexpr (ahead * NS == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          else if constexpr (ahead * NS == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
-          else if constexpr (ahead * NS == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-          else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-          tt = T::mfma32(__builtin_bit_cast(typename T::vec8, yfr[ks]), xf[ks], tt);
-          if constexpr (MODE != 2) dp = T::mfma32(__builtin_bit_cast(typename T::vec8, y2fr[ks]), x2f[ks], dp);
-          if constexpr (b == 0) dma_piece(t + 1, cur ^ 1, BIC<ks>{});
-          if constexpr (b == 1 && ks == 0) dma_stat(t + 1, cur ^ 1);
-          __builtin_amdgcn_sched_barrier(0);
-        };
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        yrd(BIC<0>{});
-        yrd(BIC<1>{});
-        __builtin_amdgcn_sched_barrier(0);
-        sstep(BIC<0>{}); sstep(BIC<1>{}); sstep(BIC<2>{}); sstep(BIC<3>{});
-        sstep(BIC<4>{}); sstep(BIC<5>{}); sstep(BIC<6>{}); sstep(BIC<7>{});
+    // Per tile, with the two 32-row halves b = 0, 1 of the streamed rows:
+    //     S(0)   |   S(1) || V(0)   |   A(0) || V(1)   |   A(1)
+    //   S(b): T^T = Y . X^T and (dQ, dK) dP^T = Y2 . X2^T  (8 k-steps of 1-2 MFMAs)
+    //   V(b): E = P (dV) or dS = P o (dP - delta): exp2 / fma of the 16 values per lane, two per MFMA step of the phase it
+    //         hides behind (round 1 ran S, V, A of a half in sequence: the matrix pipe idled through every V)
+    //   A(b): A^T += Z^T . E^T  (8 steps)
+    // Fragment reads are inline asm, two steps ahead, with hand-counted lgkmcnt waits (in-order completion: LDS operations
+    // hipcc places in between - the statistics of V - only make a wait more conservative); through the builtin hipcc put
+    // an s_waitcnt vmcnt(0) in front of the first transposed read, draining the next tile's DMAs mid-tile.  Those DMAs
+    // are issued one piece per k-step of S(0), the statistics at the first step of S(1).
+    f32x16 tt[2], dp[2];
+    typename T::vec8 ef[2][2], pf[2][2];
+    f32x4 l4, d4;
+    auto vpair = [&](auto vbc, auto jc) {                      // values 2j, 2j+1 of half vb
+      constexpr int vb = decltype(vbc)::value, j = decltype(jc)::value;
+      constexpr int g = j >> 1, jj = 2 * (j & 1);              // streamed row of value i: 32 vb + (i&3) + 8(i>>2) + 4hh
+      if constexpr (MODE != 0 && (j & 1) == 0) {
+        l4 = *(const f32x4*)(stat + 32 * vb + 8 * g + 4 * hh);
+        if constexpr (MODE == 1 || MODE == 3) d4 = *(const f32x4*)(stat + 64 + 32 * vb + 8 * g + 4 * hh);
       }
-      // ---- E = P (dV) or dS = P o (dP - delta) (dQ, dK); streamed row of element i: 32b + (i&3) + 8(i>>2) + 4hh
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 l4, d4;
-        if (MODE != 0) {
-          l4 = *(const f32x4*)(stat + 32 * b + 8 * g + 4 * hh);
-          if (MODE == 1 || MODE == 3) d4 = *(const f32x4*)(stat + 64 + 32 * b + 8 * g + 4 * hh);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int i = 4 * g + j;
-          const float l = (MODE == 0) ? lse_l : l4[j];
-          float p = __builtin_amdgcn_exp2f(tt[i] * c - l);
-          if (MODE == 0 && ragged && t * BKT + 32 * b + j + 8 * g + 4 * hh >= NY) p = 0.f;   // key past the end
-          // (MODE 1-3: a query past the end has zero Y / Y2 rows and zero statistics - p = 1, every product 0)
-          if (MODE == 2) tt[i] = p;
-          else tt[i] = p * (dp[i] - ((MODE == 0) ? del_l : d4[j]));
-          if (MODE == 3) dp[i] = p;                                   // dP is consumed: its registers carry P
-        }
-      }
-      typename T::vec8 ef[2], pf[2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        u32x4 w;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = pack2<T>(tt[8 * s + 2 * j], tt[8 * s + 2 * j + 1]);
-        ef[s] = __builtin_bit_cast(typename T::vec8, w);
-        if (MODE == 3) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) w[j] = pack2<T>(dp[8 * s + 2 * j], dp[8 * s + 2 * j + 1]);
-          pf[s] = __builtin_bit_cast(typename T::vec8, w);
-        }
-      }
-      // ---- A^T += Z^T . E^T.  The transposed reads are inline asm with hand-counted lgkmcnt waits (as attn_fwd3_kernel):
-      // through the builtin hipcc puts an s_waitcnt vmcnt(0) in front of the first one (it cannot prove that the read
-      // does not alias the LDS-DMA in flight) - that drained the next tile's DMAs in the middle of this one.  Step
-      // i = 2 db + s issues the reads of step i + 2, then waits until only the younger ones are outstanding (in-order
-      // completion: LDS operations hipcc may have placed in between only make the wait more conservative).
-      {
-        const unsigned zbase_b = zbase + 256 * 32 * b, z2base_b = z2base + 256 * 32 * b;
-        constexpr int NRD = (MODE == 3) ? 4 : 2;               // reads per step
-        u32x2 zlo[8], zhi[8], z2lo[8], z2hi[8];
-        auto zrd = [&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          constexpr int db = i >> 1, sx = i & 1;
-          const unsigned a0 = zbase_b + zaddr[db][0], a1 = zbase_b + zaddr[db][1];
-          u32x2 lo, hi;
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "i"(256 * 16 * sx + 0));
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "i"(256 * 16 * sx + 0));
-          zlo[i] = lo; zhi[i] = hi;
-          if constexpr (MODE == 3) {
-            const unsigned c0 = z2base_b + zaddr[db][0], c1 = z2base_b + zaddr[db][1];
-            u32x2 lo2, hi2;
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo2) : "v"(c0), "i"(256 * 16 * sx + 0));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi2) : "v"(c1), "i"(256 * 16 * sx + 0));
-            z2lo[i] = lo2; z2hi[i] = hi2;
-          }
-        };
-        auto zstep = [&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          constexpr int db = i >> 1, sx = i & 1;
-          if constexpr (i + 2 < 8) zrd(BIC<(i + 2 < 8 ? i + 2 : 7)>{});
-          constexpr int ahead = (7 - i) < 2 ? (7 - i) : 2;
-          if constexpr (ahead * NRD == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          else if constexpr (ahead * NRD == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-          else if constexpr (ahead * NRD == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-          else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);                    // keep the MFMA below the wait
-          u32x4 both;
-          both[0] = zlo[i][0]; both[1] = zlo[i][1]; both[2] = zhi[i][0]; both[3] = zhi[i][1];
-          acc[db] = T::mfma32(__builtin_bit_cast(typename T::vec8, both), ef[sx], acc[db]);
-          if constexpr (MODE == 3) {
-            u32x4 b2;
-            b2[0] = z2lo[i][0]; b2[1] = z2lo[i][1]; b2[2] = z2hi[i][0]; b2[3] = z2hi[i][1];
-            acc2[db] = T::mfma32(__builtin_bit_cast(typename T::vec8, b2), pf[sx], acc2[db]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        };
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // nothing older than the reads below is outstanding
-        zrd(BIC<0>{});
-        zrd(BIC<1>{});
-        __builtin_amdgcn_sched_barrier(0);
-        zstep(BIC<0>{}); zstep(BIC<1>{}); zstep(BIC<2>{}); zstep(BIC<3>{});
-        zstep(BIC<4>{}); zstep(BIC<5>{}); zstep(BIC<6>{}); zstep(BIC<7>{});
+      for (int e = 0; e < 2; ++e) {
+        const int i = 2 * j + e;
+        const float l = (MODE == 0) ? lse_l : l4[jj + e];
+        float x = tt[vb][i];
+        asm volatile("" : "+v"(x));
+        float p = __builtin_amdgcn_exp2f(x * c - l);
+        if (MODE == 0 && ragged && t * BKT + 32 * vb + (jj + e) + 8 * g + 4 * hh >= NY) p = 0.f;   // key past the end
+        // (MODE 1-3: a query past the end has zero Y / Y2 rows and zero statistics - p = 1, every product 0)
+        float y;
+        if (MODE == 2) y = p;
+        else y = p * (dp[vb][i] - ((MODE == 0) ? del_l : d4[jj + e]));
+        asm volatile("" : "+v"(y));
+        tt[vb][i] = y;
+        if (MODE == 3) dp[vb][i] = p;                           // dP is consumed: its registers carry P
       }
     };
-    half(BIC<0>{});
-    half(BIC<1>{});
+    auto pack = [&](auto vbc) {
+      constexpr int vb = decltype(vbc)::value;
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) {
+        u32x4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = pack2<T>(tt[vb][8 * sx + 2 * j], tt[vb][8 * sx + 2 * j + 1]);
+        ef[vb][sx] = __builtin_bit_cast(typename T::vec8, w);
+        if (MODE == 3) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = pack2<T>(dp[vb][8 * sx + 2 * j], dp[vb][8 * sx + 2 * j + 1]);
+          pf[vb][sx] = __builtin_bit_cast(typename T::vec8, w);
+        }
+      }
+    };
+    auto sphase = [&](auto bc, auto vc) {                      // S(b) [|| V(vb) when vb >= 0]
+      constexpr int b = decltype(bc)::value, vb = decltype(vc)::value;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { tt[b][i] = 0.f; dp[b][i] = 0.f; }
+      constexpr int NS = (MODE != 2) ? 2 : 1;                   // reads per step
+      u32x4 yfr[8], y2fr[8];
+      auto yrd = [&](auto ic) {
+        constexpr int ks = decltype(ic)::value;
+        const unsigned a = ybase + (unsigned)yaddr[ks];
+        u32x4 v;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "i"(8192 * b));
+        yfr[ks] = v;
+        if constexpr (MODE != 2) {
+          u32x4 v2;
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v2) : "v"(a), "i"(BTILE + 8192 * b));
+          y2fr[ks] = v2;
+        }
+      };
+      auto sstep = [&](auto ic) {
+        constexpr int ks = decltype(ic)::value;
+        if constexpr (ks + 2 < 8) yrd(BIC<(ks + 2 < 8 ? ks + 2 : 7)>{});
+        constexpr int ahead = (7 - ks) < 2 ? (7 - ks) : 2;
+        if constexpr (ahead * NS == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if constexpr (ahead * NS == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        else if constexpr (ahead * NS == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        tt[b] = T::mfma32(__builtin_bit_cast(typename T::vec8, yfr[ks]), xf[ks], tt[b]);
+        if constexpr (MODE != 2) dp[b] = T::mfma32(__builtin_bit_cast(typename T::vec8, y2fr[ks]), x2f[ks], dp[b]);
+        if constexpr (b == 0) dma_piece(t + 1, cur ^ 1, BIC<ks>{});
+        if constexpr (b == 1 && ks == 0) dma_stat(t + 1, cur ^ 1);
+        if constexpr (vb >= 0) vpair(BIC<(vb >= 0 ? vb : 0)>{}, BIC<ks>{});
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      yrd(BIC<0>{});
+      yrd(BIC<1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      sstep(BIC<0>{}); sstep(BIC<1>{}); sstep(BIC<2>{}); sstep(BIC<3>{});
+      sstep(BIC<4>{}); sstep(BIC<5>{}); sstep(BIC<6>{}); sstep(BIC<7>{});
+    };
+    auto aphase = [&](auto bc, auto vc) {                      // A(b) [|| V(vb) when vb >= 0]
+      constexpr int b = decltype(bc)::value, vb = decltype(vc)::value;
+      const unsigned zbase_b = zbase + 256 * 32 * b, z2base_b = z2base + 256 * 32 * b;
+      constexpr int NRD = (MODE == 3) ? 4 : 2;                  // reads per step
+      u32x2 zlo[8], zhi[8], z2lo[8], z2hi[8];
+      auto zrd = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int db = i >> 1, sx = i & 1;
+        const unsigned a0 = zbase_b + zaddr[db][0], a1 = zbase_b + zaddr[db][1];
+        u32x2 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "i"(256 * 16 * sx + 0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "i"(256 * 16 * sx + 0));
+        zlo[i] = lo; zhi[i] = hi;
+        if constexpr (MODE == 3) {
+          const unsigned c0 = z2base_b + zaddr[db][0], c1 = z2base_b + zaddr[db][1];
+          u32x2 lo2, hi2;
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo2) : "v"(c0), "i"(256 * 16 * sx + 0));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi2) : "v"(c1), "i"(256 * 16 * sx + 0));
+          z2lo[i] = lo2; z2hi[i] = hi2;
+        }
+      };
+      auto zstep = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int db = i >> 1, sx = i & 1;
+        if constexpr (i + 2 < 8) zrd(BIC<(i + 2 < 8 ? i + 2 : 7)>{});
+        constexpr int ahead = (7 - i) < 2 ? (7 - i) : 2;
+        if constexpr (ahead * NRD == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if constexpr (ahead * NRD == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else if constexpr (ahead * NRD == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);                      // keep the MFMA below the wait
+        u32x4 both;
+        both[0] = zlo[i][0]; both[1] = zlo[i][1]; both[2] = zhi[i][0]; both[3] = zhi[i][1];
+        acc[db] = T::mfma32(__builtin_bit_cast(typename T::vec8, both), ef[b][sx], acc[db]);
+        if constexpr (MODE == 3) {
+          u32x4 b2;
+          b2[0] = z2lo[i][0]; b2[1] = z2lo[i][1]; b2[2] = z2hi[i][0]; b2[3] = z2hi[i][1];
+          acc2[db] = T::mfma32(__builtin_bit_cast(typename T::vec8, b2), pf[b][sx], acc2[db]);
+        }
+        if constexpr (vb >= 0) vpair(BIC<(vb >= 0 ? vb : 0)>{}, BIC<i>{});
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // nothing older than the reads below is outstanding
+      zrd(BIC<0>{});
+      zrd(BIC<1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      zstep(BIC<0>{}); zstep(BIC<1>{}); zstep(BIC<2>{}); zstep(BIC<3>{});
+      zstep(BIC<4>{}); zstep(BIC<5>{}); zstep(BIC<6>{}); zstep(BIC<7>{});
+    };
+    sphase(BIC<0>{}, BIC<-1>{});
+    sphase(BIC<1>{}, BIC<0>{});
+    pack(BIC<0>{});
+    aphase(BIC<0>{}, BIC<1>{});
+    pack(BIC<1>{});
+    aphase(BIC<1>{}, BIC<-1>{});
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMAs of tile t+1 have landed
     asm volatile("" ::: "memory");
