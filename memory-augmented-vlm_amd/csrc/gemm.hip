@@ -119,32 +119,60 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const uint16_t* __restr
     __syncthreads();   // next tile landed (vmcnt(0)) and everyone is done reading buf[cur]
   }
 
-  // ---- epilogue: lane holds C[m][n..n+3], m = m0+wm*64+16i+fr, n = n0+wn*64+16j+4fq
+  // ---- epilogue: lane holds C[m][n..n+3], m = m0+wm*64+16i+fr, n = n0+wn*64+16j+4fq.  Every load (4 bias vectors, the
+  // 16 residual vectors of the RES epilogue) is issued BEFORE the first store: with the bias load inside the store loop
+  // hipcc emitted load / s_waitcnt vmcnt(0) / store sixteen times over - and vmcnt(0) also waits for the previous store,
+  // i.e. sixteen serial round trips to memory per tile (~10 us on a 15-30 us small-grid GEMM).
+  f32x4 bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    bv[j] = ksplit > 0 ? f32x4{0.f, 0.f, 0.f, 0.f}                     // split-K planes: bias in the reduce
+                       : *(const f32x4*)(bias + n0 + wn * 64 + j * 16 + fq * 4);
+  u16x4 rv[4][4];
+  if (EPI == MAVLM_EPI_RES_F32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m = m0 + wm * 64 + i * 16 + fr;
+      m = m < M ? m : M - 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rv[i][j] = *(const u16x4*)(res + (size_t)m * ldr + n0 + wn * 64 + j * 16 + fq * 4);
+    }
+  }
+  // Stores are BUFFER stores through a descriptor that ends after row M-1: the rows of a ragged last tile are dropped
+  // by the hardware, so the store loop has no divergent branch (at every branch join hipcc waited vmcnt(0) for the stores
+  // before it).  (32-bit offsets: the launcher checks M * ldc * element size < 4 GiB.)
+  constexpr int ESZ = (EPI == MAVLM_EPI_RES_F32 || EPI == MAVLM_EPI_F32) ? 4 : 2;
+  __amdgpu_buffer_rsrc_t crs;
+  {
+    const uintptr_t a = (uintptr_t)Cout;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const uint32_t bytes = __builtin_amdgcn_readfirstlane(((uint32_t)(M - 1) * (uint32_t)ldc + (uint32_t)N) * (uint32_t)ESZ);
+    crs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, bytes, 0x00020000);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + fr;
-    if (m >= M) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + fq * 4;
-      const f32x4 bv = ksplit > 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(bias + n);   // split-K planes: bias in the reduce
-      float v0 = acc[i][j][0] + bv[0], v1 = acc[i][j][1] + bv[1], v2 = acc[i][j][2] + bv[2],
-            v3 = acc[i][j][3] + bv[3];
+      const int off = (m * ldc + n) * ESZ;
+      float v0 = acc[i][j][0] + bv[j][0], v1 = acc[i][j][1] + bv[j][1], v2 = acc[i][j][2] + bv[j][2],
+            v3 = acc[i][j][3] + bv[j][3];
       if (EPI == MAVLM_EPI_RELU) {
         v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
       } else if (EPI == MAVLM_EPI_GELU) {
         v0 = gelu_erf_fast(v0); v1 = gelu_erf_fast(v1); v2 = gelu_erf_fast(v2); v3 = gelu_erf_fast(v3);
       }
       if (EPI == MAVLM_EPI_RES_F32) {
-        const u16x4 rv = *(const u16x4*)(res + (size_t)m * ldr + n);
         f32x4 o;
-        o[0] = v0 + T::to_f32(rv[0]); o[1] = v1 + T::to_f32(rv[1]);
-        o[2] = v2 + T::to_f32(rv[2]); o[3] = v3 + T::to_f32(rv[3]);
-        *(f32x4*)((float*)Cout + (size_t)m * ldc + n) = o;
+        o[0] = v0 + T::to_f32(rv[i][j][0]); o[1] = v1 + T::to_f32(rv[i][j][1]);
+        o[2] = v2 + T::to_f32(rv[i][j][2]); o[3] = v3 + T::to_f32(rv[i][j][3]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), crs, off, 0, 0);
       } else if (EPI == MAVLM_EPI_F32) {
-        *(f32x4*)((float*)Cout + (size_t)m * ldc + n) = f32x4{v0, v1, v2, v3};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4{v0, v1, v2, v3})), crs, off, 0, 0);
       } else {
-        *(u32x2*)((uint16_t*)Cout + (size_t)m * ldc + n) = pack4<T>(v0, v1, v2, v3);
+        __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(v0, v1, v2, v3), crs, off, 0, 0);
       }
     }
   }
@@ -152,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const uint16_t* __restr
 
 template <typename T, int EPI>
 hipError_t launch(const mavlm_gemm_args& g, hipStream_t s) {
+  if ((double)g.M * g.ldc * 4.0 >= 4294967296.0) return hipErrorInvalidValue;     // 32-bit offsets of the buffer stores
   auto kern = gemm_tn_kernel<T, EPI>;
   static mavlm_per_device_once once;   // per instantiation
   {
@@ -166,6 +195,7 @@ hipError_t launch(const mavlm_gemm_args& g, hipStream_t s) {
 
 template <typename T>
 hipError_t launch_splitk(const mavlm_gemm_args& g, int splits, int ksplit, hipStream_t s) {
+  if ((double)g.M * g.ldc * 4.0 >= 4294967296.0) return hipErrorInvalidValue;     // (per plane)
   auto kern = gemm_tn_kernel<T, MAVLM_EPI_F32>;
   static mavlm_per_device_once once;
   {
