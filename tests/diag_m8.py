@@ -9,7 +9,7 @@ if os.environ.get("HIDDEN"):
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 bench.MEM_TOKENS = M
 dev = torch.device("cuda", 0)
-model, arch = bench.build_model(dev)
+model, arch = bench.build_model(dev, mem_tokens=M)
 if os.environ.get("MAVLM_GEMM_TILE"):
     from memory_augmented_vlm_amd import _capi as _c
     _c.check(_c.lib().mavlm_set_gemm_tile(int(os.environ["MAVLM_GEMM_TILE"])), "tile")
