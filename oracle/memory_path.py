@@ -28,6 +28,9 @@ Each function cites the reference file:line it restates (paths relative to
 from __future__ import annotations
 
 import math
+import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -431,6 +434,28 @@ ROW_BLOCK_ELEMS = 1 << 28   # score elements per (head, query block) above which
 LAZY_SCORE_ELEMS = 1 << 27  # ... and above which a block's scores are produced per 4096-key chunk (emulation modes)
 
 
+# Heads and query blocks are independent: large problems spread them over a few threads (numpy releases the GIL inside
+# its kernels).  Same operations on the same data in the same order per head / block - results do not depend on it.
+PAR_THREADS = max(1, min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+PAR_MIN_ELEMS = 1 << 22          # below this much work per call the threads cost more than they bring
+_par_tls = threading.local()
+
+
+def _par_map(fn, items):
+    """[fn(x) for x in items], on a thread pool when there are several items and we are not already inside one"""
+    if len(items) < 2 or PAR_THREADS < 2 or getattr(_par_tls, "busy", False):
+        return [fn(x) for x in items]
+
+    def guarded(x):
+        _par_tls.busy = True
+        try:
+            return fn(x)
+        finally:
+            _par_tls.busy = False
+    with ThreadPoolExecutor(max_workers=min(PAR_THREADS, len(items))) as ex:
+        return list(ex.map(guarded, items))
+
+
 def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mode: str = "fp32",
                     want_colsum: bool = False, want_probs: bool = False, kv_tile: Optional[int] = None,
                     wave_rows: Optional[int] = None):
@@ -443,8 +468,10 @@ def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mod
     if want_probs or R * Lk <= ROW_BLOCK_ELEMS or R <= blk:
         return _attention_heads(Q, K, V, heads, mode, want_colsum, want_probs, kv_tile, wave_rows, R)
     ctxs, lses, cs = [], [], None
-    for r0 in range(0, R, blk):
-        c_, l_, s_, _ = _attention_heads(Q[r0:r0 + blk], K, V, heads, mode, want_colsum, False, kv_tile, wave_rows, R, r0)
+
+    def one_block(r0):
+        return _attention_heads(Q[r0:r0 + blk], K, V, heads, mode, want_colsum, False, kv_tile, wave_rows, R, r0)
+    for c_, l_, s_, _ in _par_map(one_block, list(range(0, R, blk))):      # (results in block order: sums stay deterministic)
         ctxs.append(c_)
         lses.append(l_)
         if want_colsum:
@@ -476,7 +503,8 @@ def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mo
     colsum = np.zeros((heads, Lk), dtype=np.float64) if want_colsum else None
     probs = np.empty((heads, R, Lk), dtype=F32) if want_probs else None
     lazy = mode != "fp32" and not want_probs and R * Lk > LAZY_SCORE_ELEMS   # (eager is faster while [R, Lk] fits)
-    for h in range(heads):
+
+    def one_head(h):              # writes ctx[:, head], lse2[h], colsum[h], probs[h]: disjoint per head
         sl = slice(h * d, (h + 1) * d)
         if lazy:
             # large problems (emulation modes): scores are produced tile by tile instead of as one [R, Lk] matrix whose
@@ -596,6 +624,11 @@ def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mo
                 colsum[h] = pn.sum(axis=0, dtype=np.float64)
             if want_probs:
                 probs[h] = pn
+    if heads > 1 and R * Lk >= PAR_MIN_ELEMS:
+        _par_map(one_head, list(range(heads)))
+    else:
+        for h in range(heads):
+            one_head(h)
     return ctx, lse2, (colsum.astype(F32) if want_colsum else None), probs
 
 
