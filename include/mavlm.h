@@ -268,6 +268,15 @@ int mavlm_set_attention_streamk_waves(int32_t waves);
 /* workgroups of the column-sum pass's balanced schedule: 0 = automatic (512), or 64 .. 1024.  Changes the fp32 summation
  * order of the column sums (pieces per unit), nothing else. */
 int mavlm_set_attention_colsum_wgs(int32_t wgs);
+/* how mavlm_step obtains the frame scores of the last formation layer (head_dim <= 128, patches % 4 == 0, <= 64 frames per
+ * chunk): 1 (default) = fused into that layer's attention forward - every query row carries the probability mass of the
+ * current frame next to its row sum; 0 = the separate column-sum pass over Q, K and lse2.  Same
+ * values up to fp32 summation order. */
+int mavlm_set_frame_score_mode(int32_t mode);
+/* 1 if mavlm_step takes the fused form for a last-layer attention of R memory rows over S = F * patches keys with heads of
+ * <= 128 columns (then that attention runs the plain, never-split grid - what mavlm_attention computes - so a host that
+ * mirrors the step operator by operator, e.g. the training path, calls mavlm_attention there to stay bit-identical) */
+int mavlm_frame_scores_fused(int32_t R, int32_t S, int32_t H, int32_t patches);
 
 /* --- measurement hooks (bench.py only; new - the reference has no profiling) ------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on its own stream.  Kinds: 0 GEMM, 1 attention

@@ -101,9 +101,9 @@ class AttentionFn(torch.autograd.Function):
     zero-padded by the caller).  Saves O and the log-sum-exp; the backward recomputes the probabilities per tile."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, scale, head_dim=128):
+    def forward(ctx, q, k, v, heads, scale, head_dim=128, plain=False):
         q, k, v = q.detach(), k.detach(), v.detach()
-        o, lse = ops.attention(q, k, v, heads, want_lse=True, scale=scale, head_dim=head_dim)
+        o, lse = ops.attention(q, k, v, heads, want_lse=True, scale=scale, head_dim=head_dim, plain=plain)
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.heads, ctx.scale, ctx.head_dim = heads, scale, head_dim
         ctx.mark_non_differentiable(lse)
@@ -117,7 +117,7 @@ class AttentionFn(torch.autograd.Function):
             dq, dk, dv = ops.attention_bwd(q, k, v, o, _c(do), lse, ctx.heads, n[0], n[1], n[2], scale=ctx.scale)
         else:       # wide heads (448): one head's scores at a time, every product a GEMM (ops.attention_bwd_wide)
             dq, dk, dv = ops.attention_bwd_wide(q, k, v, o, _c(do), lse, ctx.heads, ctx.head_dim, ctx.scale, n[0], n[1], n[2])
-        return dq, dk, dv, None, None, None
+        return dq, dk, dv, None, None, None, None
 
 
 def head_width(hd):
@@ -163,7 +163,7 @@ def project_kv(attns, x):
     return [(kv[:, (2 * i) * Dp:(2 * i + 1) * Dp], kv[:, (2 * i + 1) * Dp:(2 * i + 2) * Dp]) for i in range(len(attns))]
 
 
-def attention_block(attn, q_in, k, v, want_stats=False):
+def attention_block(attn, q_in, k, v, want_stats=False, patches_per_frame=196):
     """`Attention.forward` (MemoryController.py:47-56) on a 2-D [rows, D] query input and already projected K/V
     (padded-head layout; may be column views); returns (out, (q, k, lse) | None)."""
     H = attn.num_attention_heads
@@ -174,7 +174,10 @@ def attention_block(attn, q_in, k, v, want_stats=False):
     dt = q_in.dtype      # parameters kept in fp32 (master weights) are cast per use; the cast is autograd-transparent
     q = LinearFn.apply(q_in, pad_heads_out(attn.q_proj.weight, H, hd).to(dt), pad_heads_out(attn.q_proj.bias, H, hd),
                        ACT_NONE)
-    ctxv, lse = AttentionFn.apply(q, k, v, H, scale, head_width(hd))
+    # the fused step runs the last formation layer's attention on the plain grid when it carries the frame scores
+    plain = bool(want_stats and hd <= 128 and
+                 capi.lib().mavlm_frame_scores_fused(q.shape[0], k.shape[0], H, patches_per_frame))
+    ctxv, lse = AttentionFn.apply(q, k, v, H, scale, head_width(hd), plain)
     d = attn.residual
     out = DenseResidualNormFn.apply(ctxv, pad_heads_in(d.dense.weight, H, hd).to(dt), d.dense.bias, q_in,
                                     d.layernorm.weight, d.layernorm.bias, d.layernorm.eps)

@@ -94,6 +94,8 @@ SIGNATURES = {
     "mavlm_set_attention_streamk_min_tiles": (C.c_int, [i32]),
     "mavlm_set_attention_streamk_waves": (C.c_int, [i32]),
     "mavlm_set_attention_colsum_wgs": (C.c_int, [i32]),
+    "mavlm_set_frame_score_mode": (C.c_int, [i32]),
+    "mavlm_frame_scores_fused": (C.c_int, [i32, i32, i32, i32]),
     "mavlm_attention_colsum_floats": (C.c_int64, [i32, i32, i32]),
     "mavlm_attention_colsum_plan": (C.c_int, [i32, i32, i32, C.POINTER(i32)]),
     "mavlm_prof_enable": (C.c_int, [i32]),

@@ -66,10 +66,12 @@ def linear(x, weight, bias_f32, epilogue=capi.EPI_BIAS, residual=None, out=None)
     return out
 
 
-def attention(q, k, v, heads, want_lse=False, out=None, head_dim=128, wide_kernel=False, scale=None):
+def attention(q, k, v, heads, want_lse=False, out=None, head_dim=128, wide_kernel=False, scale=None, plain=False):
     """ctx = softmax(q k^T / sqrt(head_dim)) v per head.  q [R,>=H*hd], k/v [S,...] may be column slices of wider
     buffers.  head_dim 128 (default kernels) or 448 (wide-head kernel; `wide_kernel=True` forces that kernel at 128
-    for cross-checks).  Returns (ctx [R,H*hd], lse2 [H,R] fp32 | None)."""
+    for cross-checks).  `plain` (head_dim 128): the never-split grid of `mavlm_attention` - what the fused step runs for the
+    last formation layer when it carries the frame scores (`mavlm_frame_scores_fused`).
+    Returns (ctx [R,H*hd], lse2 [H,R] fp32 | None)."""
     _need_gpu(q, k, v)
     R, _, ldq = _rows(q)
     S, _, ldk = _rows(k)
@@ -81,7 +83,12 @@ def attention(q, k, v, heads, want_lse=False, out=None, head_dim=128, wide_kerne
         out = torch.empty((R, W), device=q.device, dtype=q.dtype)
     lse = torch.empty((heads, R), device=q.device, dtype=torch.float32) if want_lse else None
     lp = lse.data_ptr() if want_lse else 0
-    if head_dim == 128 and not wide_kernel:
+    if head_dim == 128 and not wide_kernel and plain:
+        capi.check(capi.lib().mavlm_attention(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(),
+                                              out.stride(0), lp, R, S, heads,
+                                              1.0 / math.sqrt(128.0) if scale is None else float(scale),
+                                              dtype_code(q.dtype), stream_ptr()), "mavlm_attention")
+    elif head_dim == 128 and not wide_kernel:
         lib = capi.lib()
         nws = lib.mavlm_attention_ws_floats(R, S, heads)     # > 0: small grid, the keys are split (same plan as mavlm_step)
         ws = torch.empty((nws,), device=q.device, dtype=torch.float32) if nws else None

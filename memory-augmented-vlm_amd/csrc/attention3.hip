@@ -67,13 +67,23 @@ struct attn3_sk_plan {
 // CU, used with the stream-K schedule): the 32 KiB of K / V per tile are then staged once for eight waves instead of
 // twice for four each - half the LDS-DMA pieces per wave and per MFMA (the vector-memory path takes ~16 clocks per 1 KiB
 // piece and every piece cost its issuing wave ~115 clocks in the in-kernel stamps).
-template <typename T, int NW>
+// FR = 1: the frame-score variant (last formation layer, MemoryController.py:135-139).  The keys of a chunk are F frames
+// of FP consecutive patches; the score of a frame is the mean over its patches of the column sums of the normalised
+// probabilities.  Instead of a second pass that recomputes Q.K^T (attn_colsum3_kernel, 10 % of a video), every query row
+// keeps the running mass a = sum_{keys of the current frame} exp2(s c - m c) next to its row sum, and writes (a, m) to a
+// scratch entry [h][q][frame] when the key loop crosses a frame boundary (FP % 4 == 0: a boundary never cuts one of the
+// 4-key groups a lane holds).  With the final log-sum-exp of the row known, the wave turns its 32 x F entries into F
+// partial frame sums, sum_q a 2^(m c - lse2); frame_finish_kernel adds the partial sums of all waves in a fixed order.
+// Whole units only (plain grid, no key splits): an entry has one writer.
+template <typename T, int NW, int FR = 0>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* __restrict__ Q, int ldq,
                                                            const uint16_t* __restrict__ Kall, int ldk,
                                                            const uint16_t* __restrict__ Vall, int ldv,
                                                            uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
                                                            int R, int S_all, int H, float c, float* __restrict__ Opart,
-                                                           float* __restrict__ lse_part, int tps, attn3_sk_plan plan) {
+                                                           float* __restrict__ lse_part, int tps, attn3_sk_plan plan,
+                                                           float* __restrict__ fscr = nullptr,
+                                                           float* __restrict__ fout = nullptr, int FP = 0, int FN = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -220,6 +230,21 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
     for (int i = 0; i < 16; ++i) ot[d][i] = 0.f;
   f32x16 st[2][2];                                            // [parity][key block]
   float m_run = -1e30f, l_run = 0.f;
+  // frame-score state (FR): mass of the current frame (this lane's half of the keys), the frame and its end key
+  float a_cur = 0.f;
+  int f_cur = 0, f_end = FP;
+  __amdgpu_buffer_rsrc_t frs;
+  int f_voff = 0;
+  if constexpr (FR != 0) {
+    const uintptr_t fa = (uintptr_t)fscr;
+    const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)fa);          // (uint32_t: readfirstlane returns int - no
+    const uint32_t fhi = __builtin_amdgcn_readfirstlane((uint32_t)(fa >> 32));  //  sign extension into the high word)
+    const uint32_t fbytes = __builtin_amdgcn_readfirstlane((uint32_t)H * (uint32_t)R * (uint32_t)FN * 8u);
+    frs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)fhi << 32) | flo), 0, fbytes, 0x00020000);
+    int qrow = q0 + r;
+    qrow = qrow < R ? qrow : R - 1;                           // (rows past R: duplicates of the last row, never read back)
+    f_voff = (h * R + qrow) * FN * 8;                         // entry [h][q][f] = (a, m): 8 bytes
+  }
 
   // S(t) = K(t).Q^T into st[P] (no overlap; used for tile 0 only)
   auto qk_plain = [&](auto par, int slot) {
@@ -436,6 +461,32 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
       step(IC<14>{}); step(IC<15>{});
     }
     l_run += psum;
+    if constexpr (FR != 0) {
+      const int k_end = (t + 1) * KT3;
+      if (f_end <= k_end) {                                   // the current frame ends inside (or at the end of) this tile
+        const int kofs = f_end - t * KT3;                     // keys [0, kofs) of the tile belong to it: 4 <= kofs <= 64
+        float plo = 0.f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {                    // a lane's 4-key group: keys 32 b + 8 g4 + 4 hh + 0..3
+            const float s4 = (st[P][b][4 * g4] + st[P][b][4 * g4 + 1]) + (st[P][b][4 * g4 + 2] + st[P][b][4 * g4 + 3]);
+            plo += (32 * b + 8 * g4 + 4 * hh < kofs) ? s4 : 0.f;
+          }
+        const float a_done = xhalf_sum(a_cur + plo);          // both key halves of the row
+        if (hh == 0) {
+          u32x2 e;
+          e[0] = __builtin_bit_cast(unsigned, a_done);
+          e[1] = __builtin_bit_cast(unsigned, m_run);
+          __builtin_amdgcn_raw_buffer_store_b64(e, frs, f_voff, f_cur * 8, 0);
+        }
+        a_cur = psum - plo;
+        f_cur += 1;
+        f_end += FP;
+      } else {
+        a_cur += psum;
+      }
+    }
 
     // reference maximum for tile t+1 (after P.V(t): the rescale touches O)
     if (has_next) {
@@ -447,6 +498,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
         m_run = m_new;
         l_run *= alpha;
+        if constexpr (FR != 0) a_cur *= alpha;
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -499,6 +551,27 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
                                                      ot[db][4 * g + 2] * inv, ot[db][4 * g + 3] * inv);
       if (lse2 != nullptr && hh == 0) lse2[(size_t)h * R + q] = m_run * c + log2f(l_tot);
     }
+  }
+  if constexpr (FR != 0) {
+    // Lane j takes frame j (FN <= 64): for each of the wave's 32 queries it reads the (a, m) entry [h][q][j] - one 8-byte
+    // load per lane, a query's F entries are contiguous - and adds a 2^(m c - lse2[q]).  The entries were written by this
+    // wave (all stores retired by the vmcnt(0) that ended the last tile); nobody else has touched these lines.
+    const float my_lse = m_run * c + log2f(l_tot);            // lane (r, hh): query q0 + r
+    float fsum = 0.f;
+    const int fj = lane < FN ? lane : FN - 1;
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) {
+      const float lse_i = __shfl(my_lse, i);                  // lanes i and i + 32 hold the same row
+      int qi = q0 + i;
+      const bool ok = qi < R && lane < FN;
+      qi = qi < R ? qi : R - 1;
+      // (two dword loads: with the b64 form of the builtin hipcc emitted ONE buffer_load_dword and used it for both halves)
+      const int eoff = ((h * R + qi) * FN + fj) * 8;
+      const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frs, eoff, 0, 1 /* glc: not from L1 */));
+      const float mm = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frs, eoff + 4, 0, 1));
+      fsum += ok ? a * __builtin_amdgcn_exp2f(mm * c - lse_i) : 0.f;
+    }
+    if (lane < FN) fout[((size_t)(h * nqb + qblk) * NW + wave) * FN + lane] = fsum;
   }
   }   // segment loop (every tile iteration ends with a barrier: the LDS slots are free for the next segment's prologue)
 }
@@ -725,7 +798,7 @@ hipError_t attn3_launch(const mavlm_attn_args& a, const attn3_launch_args& la, h
     mavlm_prof_scope prof(MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD3, 2.0 * HD3 * a.H * (2.0 * a.R + 2.0 * a.S), s);
     hipLaunchKernelGGL(kern, la.grid, dim3(64 * NW), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K, a.ldk,
                        (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, la.c, la.opart, la.lpart,
-                       la.tps, la.plan);
+                       la.tps, la.plan, (float*)nullptr, (float*)nullptr, 0, 0);
   }
   double parts = la.ns > 1 ? (double)la.ns * a.R * a.H : 0.0;      // fp32 partial rows the merge reads
   if (la.plan.wgs > 0) {
@@ -743,6 +816,74 @@ hipError_t attn3_launch(const mavlm_attn_args& a, const attn3_launch_args& la, h
   return hipGetLastError();
 }
 }  // namespace
+
+int g_mavlm_frame_score_mode = 1;   // mavlm_step: 1 = frame scores fused into the last layer's forward, 0 = column-sum pass
+
+// scores[f] = (1 / P) * sum of the per-wave partial frame sums, rows added in a fixed order (one workgroup per frame)
+template <typename T>
+__global__ __launch_bounds__(256) void frame_finish_kernel(const float* __restrict__ fout, int rows, int F, int P,
+                                                           void* __restrict__ out, int out_f32) {
+  __shared__ float wsum[4];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f;
+  for (int i = tid; i < rows; i += 256) s += fout[(size_t)i * F + f];
+  s = wave_sum(s);
+  if ((tid & 63) == 0) wsum[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    s = (((wsum[0] + wsum[1]) + wsum[2]) + wsum[3]) / (float)P;
+    if (out_f32) ((float*)out)[f] = s;
+    else ((uint16_t*)out)[f] = T::from_f32(s);
+  }
+}
+
+// Frame-score variant of the forward (fused step, last formation layer): plain grid of 4-wave workgroups, whole units.
+bool mavlm_attention_frames_supported(int R, int S, int H, int frame_keys) {
+  // (the size bound is taken at the largest frame count, 64: the answer depends on S only through S % frame_keys and S / frame_keys <= 64)
+  return frame_keys >= 4 && (frame_keys & 3) == 0 && S > 0 && S % frame_keys == 0 && S / frame_keys <= 64 &&
+         (double)H * R * 64.0 * 8.0 < 4294967296.0;
+}
+size_t mavlm_attention_frames_scr_floats(int R, int S, int H, int frame_keys) { return (size_t)H * R * (S / frame_keys) * 2; }
+size_t mavlm_attention_frames_out_floats(int R, int S, int H, int frame_keys) {
+  return (size_t)H * ((R + 127) / 128) * 4 * (S / frame_keys);
+}
+
+hipError_t mavlm_launch_attention3_frames(const mavlm_attn_args& a, int dtype, hipStream_t s) {
+  if (!a.frame_scr || !a.frame_out || !mavlm_attention_frames_supported(a.R, a.S, a.H, a.frame_keys)) return hipErrorInvalidValue;
+  if ((double)a.S * a.ldk * 2.0 >= 2147483648.0 || (double)a.S * a.ldv * 2.0 >= 2147483648.0) return hipErrorInvalidValue;
+  const float c = a.scale * 1.44269504088896340736f;
+  const int FN = a.S / a.frame_keys;
+  const dim3 grid(((a.R + 127) / 128) * a.H);
+  const attn3_sk_plan plan = {};
+  mavlm_prof_scope prof(MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD3, 2.0 * HD3 * a.H * (2.0 * a.R + 2.0 * a.S), s);
+  if (dtype == MAVLM_F16) {
+    auto kern = attn_fwd3_kernel<F16, 4, 1>;
+    static mavlm_per_device_once once;
+    hipError_t e = once.dyn_lds((const void*)kern, ATTN3_LDS);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K, a.ldk,
+                       (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, (float*)nullptr,
+                       (float*)nullptr, 0, plan, a.frame_scr, a.frame_out, a.frame_keys, FN);
+  } else {
+    auto kern = attn_fwd3_kernel<BF16, 4, 1>;
+    static mavlm_per_device_once once;
+    hipError_t e = once.dyn_lds((const void*)kern, ATTN3_LDS);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K, a.ldk,
+                       (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, (float*)nullptr,
+                       (float*)nullptr, 0, plan, a.frame_scr, a.frame_out, a.frame_keys, FN);
+  }
+  return hipGetLastError();
+}
+
+hipError_t mavlm_launch_frame_finish(const float* fout, int rows, int F, int P, void* out, int out_f32, int dtype,
+                                     hipStream_t s) {
+  if (!fout || !out || rows <= 0 || F <= 0 || P <= 0) return hipErrorInvalidValue;
+  mavlm_prof_scope prof(MAVLM_K_MISC, 0.0, 4.0 * rows * (double)F, s);
+  if (dtype == MAVLM_F16) hipLaunchKernelGGL(frame_finish_kernel<F16>, dim3(F), dim3(256), 0, s, fout, rows, F, P, out, out_f32);
+  else hipLaunchKernelGGL(frame_finish_kernel<BF16>, dim3(F), dim3(256), 0, s, fout, rows, F, P, out, out_f32);
+  return hipGetLastError();
+}
 
 hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStream_t s) {
   // K / V are addressed through 32-bit buffer offsets (one descriptor per head): the key block must span < 4 GiB

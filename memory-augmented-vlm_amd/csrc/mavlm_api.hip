@@ -16,6 +16,7 @@ struct mavlm_ctx {
   int steps = 0;
   // workspace carve (byte offsets)
   size_t o_kv, o_q, o_ctx, o_a, o_h, o_pre, o_mA, o_mB, o_lse, o_part, o_split, o_gsplit, gsplit_floats, total;
+  size_t o_fscr = 0, o_fout = 0;   // frame-score variant of the last layer's forward (0 = not available for this config)
   int fuse_mems = 1;   // cached memories the Memory-Fuser MLP takes per GEMM launch (mavlm_fuse_emit)
 };
 
@@ -109,6 +110,16 @@ void carve(mavlm_ctx* x) {
     for (size_t n : need) x->gsplit_floats = n > x->gsplit_floats ? n : x->gsplit_floats;
   }
   o += al(x->gsplit_floats * 4);
+  // scratch of the frame-score variant of the last formation layer's forward (attention3.hip): (a, m) per (head, memory
+  // row, frame) and the per-wave partial frame sums
+  x->o_fscr = x->o_fout = 0;
+  {
+    const int fc = c.max_chunk_frames < 64 ? c.max_chunk_frames : 64;      // chunks of more frames take the column-sum pass
+    if (!wide_heads(c) && mavlm_attention_frames_supported((int)R, fc * c.patches, (int)H, c.patches)) {
+      x->o_fscr = o; o += al(mavlm_attention_frames_scr_floats((int)R, fc * c.patches, (int)H, c.patches) * 4);
+      x->o_fout = o; o += al(mavlm_attention_frames_out_floats((int)R, fc * c.patches, (int)H, c.patches) * 4);
+    }
+  }
   x->total = o;
 }
 
@@ -141,7 +152,7 @@ inline hipError_t gemm_x(mavlm_ctx* x, hipStream_t s, const void* A, int lda, co
 
 // One `Attention` block given projected K/V:  out = LN(dense(attn(q_proj(xq), K, V)) + xq)
 int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const void* xq, const void* K, int ldk,
-               const void* V, int ldv, int S, void* out, float* lse2) {
+               const void* V, int ldv, int S, void* out, float* lse2, bool frames = false) {
   const mavlm_config& c = x->cfg;
   const int R = c.mem_tokens * c.patches, D = c.hidden, H = c.heads, dt = c.dtype, Dp = padded_width(c);
   MAVLM_TRY(gemm_x(x, s, xq, D, aw.wq, D, aw.bq, ws(x, x->o_q), Dp, R, Dp, D, MAVLM_EPI_BIAS));
@@ -151,6 +162,11 @@ int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const 
   a.split_ws = x->o_gsplit > x->o_split ? (float*)ws(x, x->o_split) : nullptr;
   if (wide_heads(c)) {
     MAVLM_TRY(mavlm_launch_attention_hd(a, c.hidden / c.heads, dt, s));
+  } else if (frames) {                      // forward + per-frame probability mass in one pass (no column-sum pass)
+    a.frame_scr = (float*)ws(x, x->o_fscr);
+    a.frame_out = (float*)ws(x, x->o_fout);
+    a.frame_keys = c.patches;
+    MAVLM_TRY(mavlm_launch_attention3_frames(a, dt, s));
   } else {
     MAVLM_TRY(mavlm_launch_attention(a, dt, s));
   }
@@ -199,6 +215,17 @@ int mavlm_set_attention_streamk_waves(int32_t waves) {
 int mavlm_set_attention_colsum_wgs(int32_t wgs) {
   if (wgs != 0 && (wgs < 64 || wgs > 1024)) return MAVLM_E_ARG;
   g_mavlm_colsum_wgs = wgs;
+  return 0;
+}
+
+int mavlm_frame_scores_fused(int32_t R, int32_t S, int32_t H, int32_t patches) {
+  return (g_mavlm_frame_score_mode == 1 && g_mavlm_attn_impl != 2 && R > 0 && H > 0 &&
+          mavlm_attention_frames_supported(R, S, H, patches)) ? 1 : 0;
+}
+
+int mavlm_set_frame_score_mode(int32_t mode) {
+  if (mode != 0 && mode != 1) return MAVLM_E_ARG;
+  g_mavlm_frame_score_mode = mode;
   return 0;
 }
 
@@ -317,10 +344,15 @@ int mavlm_step(mavlm_ctx* x, const void* seg, int32_t F, void* frame_scores, int
     const bool want_scores = last && frame_scores != nullptr;
     const char* Kl = kvs + (size_t)(2 * l) * Dp * 2;
     const char* Vl = Kl + (size_t)Dp * 2;
-    float* lse = want_scores ? (float*)ws(x, x->o_lse) : nullptr;
-    int rc = attn_block(x, s, x->w.layer_attn[l], cur, Kl, ldkv, Vl, ldkv, S, ws(x, x->o_a), lse);
+    // frame scores: fused into this layer's forward (default), or the column-sum pass over its Q / K / lse2
+    const bool fused_scores = want_scores && !wide_heads(c) && x->o_fscr != 0 && mavlm_frame_scores_fused(R, S, H, c.patches);
+    float* lse = want_scores ? (float*)ws(x, x->o_lse) : nullptr;      // (the fused form does not need it; kept for inspection)
+    int rc = attn_block(x, s, x->w.layer_attn[l], cur, Kl, ldkv, Vl, ldkv, S, ws(x, x->o_a), lse, fused_scores);
     if (rc) return rc;
-    if (want_scores) {
+    if (fused_scores) {
+      MAVLM_TRY(mavlm_launch_frame_finish((const float*)ws(x, x->o_fout), H * ((R + 127) / 128) * 4, F, c.patches, frame_scores,
+                                          scores_f32, dt, s));
+    } else if (want_scores) {
       mavlm_colsum_args ca;
       ca.Q = ws(x, x->o_q); ca.ldq = Dp; ca.K = Kl; ca.ldk = ldkv; ca.lse2 = lse; ca.part = (float*)ws(x, x->o_part);
       ca.R = R; ca.S = S; ca.H = H; ca.scale = attn_scale(c);

@@ -44,8 +44,20 @@ struct mavlm_attn_args {
   int R, S, H;
   float scale;                   // 1/sqrt(head_dim)
   float* split_ws = nullptr;     // mavlm_attention_split_ws_floats(R,S,H) floats, or null = never split the keys
+  // frame-score variant (mavlm_launch_attention3_frames): the keys are S / frame_keys frames of frame_keys patches
+  float* frame_scr = nullptr;    // mavlm_attention_frames_scr_floats(...) floats of scratch
+  float* frame_out = nullptr;    // mavlm_attention_frames_out_floats(...) floats: per-wave partial frame sums
+  int frame_keys = 0;
 };
 hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream_t s);
+// forward + per-frame probability mass in one pass (attention3.hip; head_dim 128, frame_keys % 4 == 0, <= 64 frames)
+bool mavlm_attention_frames_supported(int R, int S, int H, int frame_keys);
+size_t mavlm_attention_frames_scr_floats(int R, int S, int H, int frame_keys);
+size_t mavlm_attention_frames_out_floats(int R, int S, int H, int frame_keys);
+hipError_t mavlm_launch_attention3_frames(const mavlm_attn_args& a, int dtype, hipStream_t s);
+hipError_t mavlm_launch_frame_finish(const float* fout, int rows, int F, int P, void* out, int out_f32, int dtype,
+                                     hipStream_t s);
+extern int g_mavlm_frame_score_mode;   // 1 (default) = fused into the last layer's forward, 0 = column-sum pass
 // split-KV plan for grids too small to fill the chip (attention3.hip): number of key splits (1 = none)
 int mavlm_attention_splits(int R, int S, int H, int* tiles_per_split);
 // stream-K schedule of the head_dim-128 forward (more units than workgroup slots): persistent workgroups, 0 = not used

@@ -110,7 +110,8 @@ class RowShardedMemory:
         kvs = ag.project_kv(atts, frames)
         stats = None
         for li, layer in enumerate(p.layers):
-            a, stats = ag.attention_block(atts[li], m, kvs[li][0], kvs[li][1], want_stats=li == len(p.layers) - 1)
+            a, stats = ag.attention_block(atts[li], m, kvs[li][0], kvs[li][1], want_stats=li == len(p.layers) - 1,
+                                          patches_per_frame=P)
             m = ag.mlp_block(layer, a)
         full = torch.empty((R, D), device=m.device, dtype=dt)
         if self.world > 1:

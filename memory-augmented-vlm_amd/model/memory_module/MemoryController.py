@@ -496,7 +496,7 @@ class TransformerProjector(nn.Module):
         for li, layer in enumerate(self.layers):                   # :132-133
             last_layer = li == len(self.layers) - 1
             a, stats = ag.attention_block(atts[li], m, kvs[li][0], kvs[li][1],
-                                          want_stats=last_layer and self.compute_frame_scores)
+                                          want_stats=last_layer and self.compute_frame_scores, patches_per_frame=P)
             m = ag.mlp_block(layer, a)
         self._memory_cache.append(m.reshape(self.num_memory_tokens, P, D))             # :152
         self._train_steps += 1

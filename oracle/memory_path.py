@@ -436,6 +436,7 @@ LAZY_SCORE_ELEMS = 1 << 27  # ... and above which a block's scores are produced 
 
 # Heads and query blocks are independent: large problems spread them over a few threads (numpy releases the GIL inside
 # its kernels).  Same operations on the same data in the same order per head / block - results do not depend on it.
+FRAME_SCORES_FUSED = True        # mirror of mavlm_set_frame_score_mode (1 = default)
 PAR_THREADS = max(1, min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
 PAR_MIN_ELEMS = 1 << 22          # below this much work per call the threads cost more than they bring
 _par_tls = threading.local()
@@ -458,7 +459,7 @@ def _par_map(fn, items):
 
 def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mode: str = "fp32",
                     want_colsum: bool = False, want_probs: bool = False, kv_tile: Optional[int] = None,
-                    wave_rows: Optional[int] = None):
+                    wave_rows: Optional[int] = None, plain: bool = False):
     """Query-blocked driver of ``_attention_heads``: attention rows are independent (the wave-uniform rescale decision
     couples groups of ``wave_rows`` = 32 / 16 consecutive queries only, and the key-split plan depends on the TOTAL
     row count, which is passed down), so large problems (BASELINE configs[4]: 25 088 queries x 250 880 keys) run in
@@ -466,11 +467,11 @@ def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mod
     R, Lk = Q.shape[0], K.shape[0]
     blk = 3136                                     # multiple of 32 and of 16
     if want_probs or R * Lk <= ROW_BLOCK_ELEMS or R <= blk:
-        return _attention_heads(Q, K, V, heads, mode, want_colsum, want_probs, kv_tile, wave_rows, R)
+        return _attention_heads(Q, K, V, heads, mode, want_colsum, want_probs, kv_tile, wave_rows, R, 0, plain)
     ctxs, lses, cs = [], [], None
 
     def one_block(r0):
-        return _attention_heads(Q[r0:r0 + blk], K, V, heads, mode, want_colsum, False, kv_tile, wave_rows, R, r0)
+        return _attention_heads(Q[r0:r0 + blk], K, V, heads, mode, want_colsum, False, kv_tile, wave_rows, R, r0, plain)
     for c_, l_, s_, _ in _par_map(one_block, list(range(0, R, blk))):      # (results in block order: sums stay deterministic)
         ctxs.append(c_)
         lses.append(l_)
@@ -481,7 +482,8 @@ def attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mod
 
 def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mode: str = "fp32",
                      want_colsum: bool = False, want_probs: bool = False, kv_tile: Optional[int] = None,
-                     wave_rows: Optional[int] = None, plan_rows: Optional[int] = None, row0: int = 0):
+                     wave_rows: Optional[int] = None, plan_rows: Optional[int] = None, row0: int = 0,
+                     plain: bool = False):
     """softmax(Q K^T / sqrt(d)) V per head (MemoryController.py:51-54).  Returns
     (ctx [R,H*d] unrounded float32, lse2 [H,R] log2-domain log-sum-exp, colsum [H,Lk] | None, probs | None).
 
@@ -563,7 +565,9 @@ def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mo
                 return sum(np.exp(p_[1] - lse_t, dtype=F32) * p_[0] for p_ in parts).astype(F32), lse_t
 
             sk_cuts = {}
-            if kv_tile == KV_TILE:            # attention3.hip (head_dim <= 128)
+            if plain:                         # the never-split grid (mavlm_attention; the fused step's last layer when
+                ns, tps = 1, 0                # it carries the frame scores): one sweep over the keys for every row
+            elif kv_tile == KV_TILE:          # attention3.hip (head_dim <= 128)
                 ns, tps = split_plan(plan_rows or R, Lk, heads)
                 sk_qb, sk_all = streamk_split_tiles(plan_rows or R, Lk, heads)
                 sk_cuts = {qb: a for (hh_, qb), a in sk_all.items() if hh_ == h}
@@ -648,7 +652,12 @@ def mha(Xq: np.ndarray, Xkv: np.ndarray, w: Dict[str, np.ndarray], prefix: str, 
         V = r(linear(Xkv, w[f"{prefix}.v_proj.weight"], w[f"{prefix}.v_proj.bias"]))
     else:
         K, V = kv_cached
-    ctx, _, colsum_h, probs = attention_heads(Q, K, V, cfg.heads, mode, want_colsum, want_probs)
+    # the fused step computes the frame scores inside this attention when it can (mavlm_frame_scores_fused): that launch
+    # is the plain, never-split grid
+    d_head = Q.shape[1] // cfg.heads
+    plain = bool(FRAME_SCORES_FUSED and want_colsum and d_head <= 128 and cfg.patches % 4 == 0 and
+                 K.shape[0] % cfg.patches == 0 and K.shape[0] // cfg.patches <= 64)
+    ctx, _, colsum_h, probs = attention_heads(Q, K, V, cfg.heads, mode, want_colsum, want_probs, plain=plain)
     colsum = colsum_h.astype(np.float64).sum(axis=0).astype(F32) if want_colsum else None   # :135 sum over heads
     ctx = r(ctx)
     pre = linear(ctx, w[f"{prefix}.residual.dense.weight"], w[f"{prefix}.residual.dense.bias"]) + Xq
