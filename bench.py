@@ -417,7 +417,11 @@ def run_replica(args, rank, world, local, device, dist_info):
     capi.check(lib.mavlm_attention_plan(MEM_TOKENS * PATCHES, 32 * PATCHES, HEADS, info), "mavlm_attention_plan")
     kname = f"attn_fwd3_kernel<BF16, {info[0]}>"
     mi = capi.KERNEL_KINDS.index("attention_merge")
-    knote = ("HIP-event bracket around this kernel only (all its launches of a step: formation and evolution shapes); "
+    fi = capi.KERNEL_KINDS.index("attention_fwd_frames")
+    knote = ("HIP-event bracket around this kernel only (all its launches of a step: formation and evolution shapes; the last "
+             "formation layer of a step runs the frame-score variant attn_fwd3_kernel<BF16, 4, 1> on the plain grid instead - "
+             f"{ms[fi] / max(ln[fi], 1) * 1e3:.1f} us per launch, kernels.attention_fwd_frames - which replaces the "
+             "column-sum pass); "
              + (f"schedule: levelled stream-K, {info[1]} workgroups of {info[0]} waves, {info[2]} level(s); its merge kernel "
                 f"attn_combine_sk_kernel<BF16> is bracketed separately: {ms[mi] / max(ln[mi], 1) * 1e3:.1f} us per launch "
                 "(kernels.attention_merge)" if info[1] else "plain grid"))

@@ -126,6 +126,15 @@ int mavlm_fuse_emit(mavlm_ctx* ctx, const void* x_pe, const int64_t* fine_idx, i
  * 3 bias+residual -> fp32 C, 4 bias -> fp32 C.   nn.Linear call sites: MemoryController.py:23,37-39,63-67; llava_arch.py:132-136 */
 int mavlm_linear(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const void* res, int32_t ldr,
                  void* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t dtype, void* stream);
+/* mavlm_attention on the plain grid + the frame scores of MemoryController.py:135-139 in the same pass: the S keys are
+ * S / patches frames of `patches` consecutive keys (patches % 4 == 0, <= 64 frames), frame_scores[f] (fp32) = mean over the
+ * frame's keys of the column sums (over heads and queries) of the normalised probabilities.  ws:
+ * mavlm_attention_frames_ws_floats(...) floats of scratch (0 = shape not supported).  What mavlm_step runs for the last
+ * formation layer (mavlm_frame_scores_fused). */
+int64_t mavlm_attention_frames_ws_floats(int32_t R, int32_t S, int32_t H, int32_t patches);
+int mavlm_attention_frames(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
+                           int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, int32_t patches,
+                           float* ws, int64_t ws_floats, float* frame_scores, int32_t dtype, void* stream);
 /* ctx[R,H*128] = softmax(Q K^T / sqrt(128)) V per head; lse2 [H,R] fp32 optional.  MemoryController.py:51-54 */
 int mavlm_attention(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                     int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream);
@@ -274,16 +283,18 @@ int mavlm_set_attention_colsum_wgs(int32_t wgs);
  * values up to fp32 summation order. */
 int mavlm_set_frame_score_mode(int32_t mode);
 /* 1 if mavlm_step takes the fused form for a last-layer attention of R memory rows over S = F * patches keys with heads of
- * <= 128 columns (then that attention runs the plain, never-split grid - what mavlm_attention computes - so a host that
+ * <= 128 columns - patches % 4 == 0, patches >= 64, <= 64 frames, and not one of the small grids that split their keys
+ * (mavlm_attention_ws_floats) - (then that attention runs the plain, never-split grid - what mavlm_attention computes - so a host that
  * mirrors the step operator by operator, e.g. the training path, calls mavlm_attention there to stay bit-identical) */
 int mavlm_frame_scores_fused(int32_t R, int32_t S, int32_t H, int32_t patches);
 
 /* --- measurement hooks (bench.py only; new - the reference has no profiling) ------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on its own stream.  Kinds: 0 GEMM, 1 attention
  * forward, 2 attention column-sum, 3 LayerNorm (forward and backward), 4 row-add, 5 misc, 6 attention backward,
- * 7 split-K GEMM, 8 transpose, 9 attention merge (split-KV / stream-K partials).  Not re-entrant, not graph-capturable. */
+ * 7 split-K GEMM, 8 transpose, 9 attention merge (split-KV / stream-K partials), 10 attention forward carrying the frame
+ * masses (last formation layer).  Not re-entrant, not graph-capturable. */
 int mavlm_prof_enable(int32_t on);
-/* host arrays of length nkinds >= 10: total milliseconds, launches, algorithmic flops, algorithmic bytes per kind */
+/* host arrays of length nkinds >= 11: total milliseconds, launches, algorithmic flops, algorithmic bytes per kind */
 int mavlm_prof_read(double* ms, int64_t* launches, double* flops, double* bytes, int32_t nkinds);
 
 #ifdef __cplusplus

@@ -96,6 +96,9 @@ SIGNATURES = {
     "mavlm_set_attention_colsum_wgs": (C.c_int, [i32]),
     "mavlm_set_frame_score_mode": (C.c_int, [i32]),
     "mavlm_frame_scores_fused": (C.c_int, [i32, i32, i32, i32]),
+    "mavlm_attention_frames_ws_floats": (C.c_int64, [i32, i32, i32, i32]),
+    "mavlm_attention_frames": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.c_float, i32, vp, C.c_int64,
+                                          vp, i32, vp]),
     "mavlm_attention_colsum_floats": (C.c_int64, [i32, i32, i32]),
     "mavlm_attention_colsum_plan": (C.c_int, [i32, i32, i32, C.POINTER(i32)]),
     "mavlm_prof_enable": (C.c_int, [i32]),
@@ -104,7 +107,7 @@ SIGNATURES = {
 }
 
 KERNEL_KINDS = ("gemm", "attention_fwd", "attention_colsum", "layernorm", "row_add", "misc", "attention_bwd",
-                "gemm_splitk", "transpose", "attention_merge")
+                "gemm_splitk", "transpose", "attention_merge", "attention_fwd_frames")
 
 _lib = None
 

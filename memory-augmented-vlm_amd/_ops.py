@@ -109,6 +109,30 @@ def attention(q, k, v, heads, want_lse=False, out=None, head_dim=128, wide_kerne
     return out, lse
 
 
+def attention_frames(q, k, v, heads, patches, want_lse=False, scale=None):
+    """`attention(..., plain=True)` plus the frame scores in one pass (head_dim 128; the keys are k.shape[0] / patches
+    frames of `patches` keys): returns (ctx, lse2 | None, scores [F] fp32)."""
+    _need_gpu(q, k, v)
+    R, _, ldq = _rows(q)
+    S, _, ldk = _rows(k)
+    _, _, ldv = _rows(v)
+    W = heads * 128
+    lib = capi.lib()
+    nws = int(lib.mavlm_attention_frames_ws_floats(R, S, heads, patches))
+    if nws == 0:
+        raise capi.MavlmError("attention_frames: shape not supported (patches % 4, S % patches, <= 64 frames)")
+    out = torch.empty((R, W), device=q.device, dtype=q.dtype)
+    lse = torch.empty((heads, R), device=q.device, dtype=torch.float32) if want_lse else None
+    ws = torch.empty((nws,), device=q.device, dtype=torch.float32)
+    scores = torch.empty((S // patches,), device=q.device, dtype=torch.float32)
+    capi.check(lib.mavlm_attention_frames(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, out.data_ptr(),
+                                          out.stride(0), lse.data_ptr() if want_lse else 0, R, S, heads,
+                                          1.0 / math.sqrt(128.0) if scale is None else float(scale), patches,
+                                          ws.data_ptr(), nws, scores.data_ptr(), dtype_code(q.dtype), stream_ptr()),
+               "mavlm_attention_frames")
+    return out, lse, scores
+
+
 def attention_colsum(q, k, lse2, heads, head_dim=128, wide_kernel=False, scale=None):
     """part[h,s] = sum_q softmax probability of key s for head h (fp32)."""
     _need_gpu(q, k, lse2)

@@ -461,18 +461,32 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
       step(IC<14>{}); step(IC<15>{});
     }
     l_run += psum;
+    bool flushed = false;                                     // (wave-uniform)
     if constexpr (FR != 0) {
       const int k_end = (t + 1) * KT3;
       if (f_end <= k_end) {                                   // the current frame ends inside (or at the end of) this tile
+        flushed = true;
         const int kofs = f_end - t * KT3;                     // keys [0, kofs) of the tile belong to it: 4 <= kofs <= 64
-        float plo = 0.f;
+        // plo = this lane's mass of the keys below the boundary.  Only the 32-key block that holds the boundary is
+        // looked at (4 of the lane's 8 four-key groups: keys 32 b + 8 g4 + 4 hh + 0..3); the other block is wholly on
+        // one side and comes out of psum.
+        float plo;
+        if (kofs <= 32) {                                     // boundary in block 0: plo = its groups below the boundary
+          plo = 0.f;
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {                    // a lane's 4-key group: keys 32 b + 8 g4 + 4 hh + 0..3
-            const float s4 = (st[P][b][4 * g4] + st[P][b][4 * g4 + 1]) + (st[P][b][4 * g4 + 2] + st[P][b][4 * g4 + 3]);
-            plo += (32 * b + 8 * g4 + 4 * hh < kofs) ? s4 : 0.f;
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float s4 = (st[P][0][4 * g4] + st[P][0][4 * g4 + 1]) + (st[P][0][4 * g4 + 2] + st[P][0][4 * g4 + 3]);
+            plo += (8 * g4 + 4 * hh < kofs) ? s4 : 0.f;
           }
+        } else {                                              // boundary in block 1: psum minus its groups at / above it
+          float phi = 0.f;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float s4 = (st[P][1][4 * g4] + st[P][1][4 * g4 + 1]) + (st[P][1][4 * g4 + 2] + st[P][1][4 * g4 + 3]);
+            phi += (32 + 8 * g4 + 4 * hh >= kofs) ? s4 : 0.f;
+          }
+          plo = psum - phi;
+        }
         const float a_done = xhalf_sum(a_cur + plo);          // both key halves of the row
         if (hh == 0) {
           u32x2 e;
@@ -505,7 +519,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
           for (int i = 0; i < 16; ++i) ot[d][i] *= alpha;
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMAs of K(t+2), V(t+1) have landed
+    // this wave's DMAs of K(t+2), V(t+1) have landed.  A frame entry stored in this tile is the YOUNGEST vector-memory
+    // operation (the DMAs were issued in phase A) and retires last: leaving it in flight keeps its ~1 000-clock round trip
+    // off the critical path of the barrier (waiting for it cost ~20 us per launch).
+    if (FR != 0 && flushed) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -556,20 +574,27 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
     // Lane j takes frame j (FN <= 64): for each of the wave's 32 queries it reads the (a, m) entry [h][q][j] - one 8-byte
     // load per lane, a query's F entries are contiguous - and adds a 2^(m c - lse2[q]).  The entries were written by this
     // wave (all stores retired by the vmcnt(0) that ended the last tile); nobody else has touched these lines.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every entry of this wave is in memory
     const float my_lse = m_run * c + log2f(l_tot);            // lane (r, hh): query q0 + r
     float fsum = 0.f;
     const int fj = lane < FN ? lane : FN - 1;
-#pragma unroll 4
+    // all 64 loads are issued before the first use (the accumulators are dead, registers are free): as a loop of dependent
+    // batches this epilogue cost ~10 us per unit
+    float ea[32], em[32];
+#pragma unroll
     for (int i = 0; i < 32; ++i) {
-      const float lse_i = __shfl(my_lse, i);                  // lanes i and i + 32 hold the same row
       int qi = q0 + i;
-      const bool ok = qi < R && lane < FN;
       qi = qi < R ? qi : R - 1;
       // (two dword loads: with the b64 form of the builtin hipcc emitted ONE buffer_load_dword and used it for both halves)
       const int eoff = ((h * R + qi) * FN + fj) * 8;
-      const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frs, eoff, 0, 1 /* glc: not from L1 */));
-      const float mm = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frs, eoff + 4, 0, 1));
-      fsum += ok ? a * __builtin_amdgcn_exp2f(mm * c - lse_i) : 0.f;
+      ea[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frs, eoff, 0, 1 /* glc: not from L1 */));
+      em[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frs, eoff + 4, 0, 1));
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float lse_i = __shfl(my_lse, i);                  // lanes i and i + 32 hold the same row
+      const bool ok = q0 + i < R && lane < FN;
+      fsum += ok ? ea[i] * __builtin_amdgcn_exp2f(em[i] * c - lse_i) : 0.f;
     }
     if (lane < FN) fout[((size_t)(h * nqb + qblk) * NW + wave) * FN + lane] = fsum;
   }
@@ -840,7 +865,8 @@ __global__ __launch_bounds__(256) void frame_finish_kernel(const float* __restri
 // Frame-score variant of the forward (fused step, last formation layer): plain grid of 4-wave workgroups, whole units.
 bool mavlm_attention_frames_supported(int R, int S, int H, int frame_keys) {
   // (the size bound is taken at the largest frame count, 64: the answer depends on S only through S % frame_keys and S / frame_keys <= 64)
-  return frame_keys >= 4 && (frame_keys & 3) == 0 && S > 0 && S % frame_keys == 0 && S / frame_keys <= 64 &&
+  // frame_keys >= 64: at most one frame boundary per 64-key tile; % 4: a boundary never cuts a lane's 4-key group
+  return frame_keys >= KT3 && (frame_keys & 3) == 0 && S > 0 && S % frame_keys == 0 && S / frame_keys <= 64 &&
          (double)H * R * 64.0 * 8.0 < 4294967296.0;
 }
 size_t mavlm_attention_frames_scr_floats(int R, int S, int H, int frame_keys) { return (size_t)H * R * (S / frame_keys) * 2; }
@@ -855,7 +881,7 @@ hipError_t mavlm_launch_attention3_frames(const mavlm_attn_args& a, int dtype, h
   const int FN = a.S / a.frame_keys;
   const dim3 grid(((a.R + 127) / 128) * a.H);
   const attn3_sk_plan plan = {};
-  mavlm_prof_scope prof(MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD3, 2.0 * HD3 * a.H * (2.0 * a.R + 2.0 * a.S), s);
+  mavlm_prof_scope prof(MAVLM_K_ATTN_FRAMES, 4.0 * a.R * (double)a.S * a.H * HD3, 2.0 * HD3 * a.H * (2.0 * a.R + 2.0 * a.S), s);
   if (dtype == MAVLM_F16) {
     auto kern = attn_fwd3_kernel<F16, 4, 1>;
     static mavlm_per_device_once once;

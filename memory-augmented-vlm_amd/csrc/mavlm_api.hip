@@ -219,8 +219,10 @@ int mavlm_set_attention_colsum_wgs(int32_t wgs) {
 }
 
 int mavlm_frame_scores_fused(int32_t R, int32_t S, int32_t H, int32_t patches) {
+  // not for the small grids that split their keys (few query blocks x heads, e.g. 8 memory tokens): the frame masses ride on
+  // the never-split grid, which would leave most of the chip idle there - those shapes keep the column-sum pass
   return (g_mavlm_frame_score_mode == 1 && g_mavlm_attn_impl != 2 && R > 0 && H > 0 &&
-          mavlm_attention_frames_supported(R, S, H, patches)) ? 1 : 0;
+          mavlm_attention_frames_supported(R, S, H, patches) && mavlm_attention_splits(R, S, H, nullptr) <= 1) ? 1 : 0;
 }
 
 int mavlm_set_frame_score_mode(int32_t mode) {
@@ -462,6 +464,29 @@ int mavlm_attention(const void* Q, int32_t ldq, const void* K, int32_t ldk, cons
   a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.lse2 = lse2;
   a.R = R; a.S = S; a.H = H; a.scale = scale;
   hipError_t e = mavlm_launch_attention(a, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+int64_t mavlm_attention_frames_ws_floats(int32_t R, int32_t S, int32_t H, int32_t patches) {
+  if (R <= 0 || H <= 0 || !mavlm_attention_frames_supported(R, S, H, patches)) return 0;
+  return (int64_t)(mavlm_attention_frames_scr_floats(R, S, H, patches) + mavlm_attention_frames_out_floats(R, S, H, patches));
+}
+
+int mavlm_attention_frames(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
+                           int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, int32_t patches,
+                           float* ws_, int64_t ws_floats, float* frame_scores, int32_t dtype, void* stream) {
+  const int64_t need = mavlm_attention_frames_ws_floats(R, S, H, patches);
+  if (!Q || !K || !V || !O || !frame_scores || need == 0 || !ws_ || ws_floats < need) return MAVLM_E_ARG;
+  mavlm_attn_args a;
+  a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.lse2 = lse2;
+  a.R = R; a.S = S; a.H = H; a.scale = scale;
+  a.frame_scr = ws_;
+  a.frame_out = ws_ + mavlm_attention_frames_scr_floats(R, S, H, patches);
+  a.frame_keys = patches;
+  hipError_t e = mavlm_launch_attention3_frames(a, dtype, (hipStream_t)stream);
+  if (e == hipSuccess)
+    e = mavlm_launch_frame_finish(a.frame_out, H * ((R + 127) / 128) * 4, S / patches, patches, frame_scores, 1, dtype,
+                                  (hipStream_t)stream);
   return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
 }
 

@@ -157,7 +157,7 @@ hipError_t mavlm_launch_pool_bilinear(const void* x, void* out, const void* tabl
 
 // ---- optional per-kernel HIP-event profiling (bench.py roofline line); off by default, zero cost when off.
 enum { MAVLM_K_GEMM = 0, MAVLM_K_ATTN = 1, MAVLM_K_COLSUM = 2, MAVLM_K_LN = 3, MAVLM_K_ROWADD = 4, MAVLM_K_MISC = 5,
-       MAVLM_K_ATTN_BWD = 6, MAVLM_K_GEMM_SPLITK = 7, MAVLM_K_TRANSPOSE = 8, MAVLM_K_ATTN_MERGE = 9, MAVLM_K_COUNT = 10 };
+       MAVLM_K_ATTN_BWD = 6, MAVLM_K_GEMM_SPLITK = 7, MAVLM_K_TRANSPOSE = 8, MAVLM_K_ATTN_MERGE = 9, MAVLM_K_ATTN_FRAMES = 10, MAVLM_K_COUNT = 11 };
 struct mavlm_prof_scope {
   int slot;
   hipStream_t s;

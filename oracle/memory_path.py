@@ -655,8 +655,9 @@ def mha(Xq: np.ndarray, Xkv: np.ndarray, w: Dict[str, np.ndarray], prefix: str, 
     # the fused step computes the frame scores inside this attention when it can (mavlm_frame_scores_fused): that launch
     # is the plain, never-split grid
     d_head = Q.shape[1] // cfg.heads
-    plain = bool(FRAME_SCORES_FUSED and want_colsum and d_head <= 128 and cfg.patches % 4 == 0 and
-                 K.shape[0] % cfg.patches == 0 and K.shape[0] // cfg.patches <= 64)
+    plain = bool(FRAME_SCORES_FUSED and want_colsum and d_head <= 128 and cfg.patches % 4 == 0 and cfg.patches >= 64 and
+                 K.shape[0] % cfg.patches == 0 and K.shape[0] // cfg.patches <= 64 and
+                 split_plan(Q.shape[0], K.shape[0], cfg.heads)[0] <= 1)          # (small grids keep their key splits)
     ctx, _, colsum_h, probs = attention_heads(Q, K, V, cfg.heads, mode, want_colsum, want_probs, plain=plain)
     colsum = colsum_h.astype(np.float64).sum(axis=0).astype(F32) if want_colsum else None   # :135 sum over heads
     ctx = r(ctx)

@@ -195,6 +195,31 @@ def test_attention_split_kv_small_grids(mode, R, S, H):
                                   ops.dtype_code(dq.dtype), ops.stream_ptr()) == capi.E_ARG
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("R,F,P,H", [(1568, 3, 196, 8), (300, 5, 196, 2), (129, 64, 64, 1), (8330, 2, 100, 8), (4100, 7, 68, 3)])
+def test_attention_frames_vs_oracle(mode, R, F, P, H):
+    """Forward + frame scores in one pass (what the fused step runs for the last formation layer): the context and the
+    log-sum-exp are BIT-identical to the plain-grid forward (the frame bookkeeping does not touch them), the scores match
+    the oracle's column sums averaged per frame; frame boundaries inside a 64-key tile (P = 196, 100, 68) and at tile ends
+    (P = 64, the smallest frame: one boundary per tile, 64 frames), ragged last tiles and query blocks."""
+    S = F * P
+    r = O.rounder(mode)
+    q = r(O.hash_normal_like((R, H * 128), 51)) * 2.0
+    k = r(O.hash_normal_like((S, H * 128), 52))
+    v = r(O.hash_normal_like((S, H * 128), 53))
+    q[3] *= 8.0                                       # rows whose maximum jumps: the deferred rescale scales the frame mass too
+    dq, dk, dv = to_dev(q, mode), to_dev(k, mode), to_dev(v, mode)
+    assert capi.lib().mavlm_attention_frames_ws_floats(R, S, H, P) > 0 and capi.lib().mavlm_attention_frames_ws_floats(R, 32 * 60, H, 60) == 0
+    got, lse, scores = ops.attention_frames(dq, dk, dv, H, P, want_lse=True)
+    plain, lse_p = ops.attention(dq, dk, dv, H, want_lse=True, plain=True)
+    assert torch.equal(got, plain) and torch.equal(lse, lse_p)
+    _, _, col = _attn_oracle(q, k, v, H, mode)        # (plan-independent up to rounding: column sums of the probabilities)
+    ref = col.astype(np.float64).sum(0).reshape(F, P).mean(1)
+    assert O.rel_l2(to_np(scores), ref) < TOL and abs(float(scores.sum()) * P - H * R) < 1e-3 * H * R
+    again = ops.attention_frames(dq, dk, dv, H, P)[2]
+    assert torch.equal(again, scores)
+
+
 @pytest.mark.parametrize("wgs", [0, 64, 200, 1024])
 @pytest.mark.parametrize("mode,R,S,H", [("bf16", 1568, 1000, 3), ("fp16", 4100, 64 * 9 + 5, 8), ("bf16", 130, 6272, 8)])
 def test_colsum_balanced_schedule(mode, R, S, H, wgs, request):
