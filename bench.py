@@ -415,7 +415,7 @@ def run_replica(args, rank, world, local, device, dist_info):
     di = capi.KERNEL_KINDS.index(dom)
     info = (ctypes.c_int32 * 4)()       # which instantiation the plan picks at the formation shape (S = one chunk's keys)
     capi.check(lib.mavlm_attention_plan(MEM_TOKENS * PATCHES, 32 * PATCHES, HEADS, info), "mavlm_attention_plan")
-    kname = f"attn_fwd3_kernel<BF16, {info[0]}>"
+    kname = f"attn_fwd3_kernel<BF16, {info[0]}, 0>"
     mi = capi.KERNEL_KINDS.index("attention_merge")
     fi = capi.KERNEL_KINDS.index("attention_fwd_frames")
     knote = ("HIP-event bracket around this kernel only (all its launches of a step: formation and evolution shapes; the last "
