@@ -415,6 +415,14 @@ def streamk_split_tiles(R: int, S: int, heads: int):
     return QB, out
 
 
+def frame_scores_fused(R: int, S: int, heads: int, patches: int, head_dim: int = 128) -> bool:
+    """Mirrors mavlm_frame_scores_fused (csrc/mavlm_api.hip) for head_dim <= 128: does the fused step compute the frame
+    scores inside the last formation layer's forward (which then runs the plain, never-split grid)?"""
+    return bool(FRAME_SCORES_FUSED and head_dim <= 128 and patches % 4 == 0 and patches >= KV_TILE and S > 0 and
+                S % patches == 0 and S // patches <= 64 and heads * R * 64.0 * 8.0 < 4294967296.0 and
+                split_plan(R, S, heads)[0] <= 1)          # (small grids keep their key splits)
+
+
 def split_plan_wide(R: int, S: int, heads: int) -> Tuple[int, int]:
     """(number of key splits, tiles per split) of the wide-head kernel (32-key tiles) - mirrors
     mavlm_attention_hd_splits (csrc/attention_hd.hip)."""
@@ -654,10 +662,7 @@ def mha(Xq: np.ndarray, Xkv: np.ndarray, w: Dict[str, np.ndarray], prefix: str, 
         K, V = kv_cached
     # the fused step computes the frame scores inside this attention when it can (mavlm_frame_scores_fused): that launch
     # is the plain, never-split grid
-    d_head = Q.shape[1] // cfg.heads
-    plain = bool(FRAME_SCORES_FUSED and want_colsum and d_head <= 128 and cfg.patches % 4 == 0 and cfg.patches >= 64 and
-                 K.shape[0] % cfg.patches == 0 and K.shape[0] // cfg.patches <= 64 and
-                 split_plan(Q.shape[0], K.shape[0], cfg.heads)[0] <= 1)          # (small grids keep their key splits)
+    plain = bool(want_colsum and frame_scores_fused(Q.shape[0], K.shape[0], cfg.heads, cfg.patches, Q.shape[1] // cfg.heads))
     ctx, _, colsum_h, probs = attention_heads(Q, K, V, cfg.heads, mode, want_colsum, want_probs, plain=plain)
     colsum = colsum_h.astype(np.float64).sum(axis=0).astype(F32) if want_colsum else None   # :135 sum over heads
     ctx = r(ctx)

@@ -1,0 +1,77 @@
+"""CPU: the plans that are part of a result's rounding - key splits of small grids, the levelled stream-K schedule, the
+rule for computing the frame scores inside the forward - are pure host functions of the shape in the C library, and the
+oracle's emulation re-states them (oracle/memory_path.py).  The parity gates rely on the two agreeing for EVERY shape:
+swept here without a GPU (no kernel is launched)."""
+import ctypes
+import itertools
+
+import pytest
+
+import memory_augmented_vlm_amd  # noqa: F401
+from memory_augmented_vlm_amd import _capi as capi
+from oracle import memory_path as O
+
+ROWS = [1, 100, 128, 784, 1568, 3136, 4100, 8192, 8320, 12544, 25088]
+KEYS = [1, 64, 196, 588, 1000, 1024, 4032, 4096, 6272, 12544, 62720, 250880]
+HEADS = [1, 2, 3, 8, 64]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return capi.lib()
+
+
+def test_attention_plans_match_the_oracle(lib):
+    info = (ctypes.c_int32 * 4)()
+    for R, S, H in itertools.product(ROWS, KEYS, HEADS):
+        capi.check(lib.mavlm_attention_plan(R, S, H, info), "plan")
+        G, QB, full, levels = O.streamk_plan(R, S, H)
+        ns, _ = O.split_plan(R, S, H)
+        assert info[1] == G, (R, S, H)
+        if G:
+            assert info[0] == QB // 32 and info[2] == len(levels) and info[3] == 1, (R, S, H)
+        else:
+            assert info[3] == ns, (R, S, H)
+        # a workspace is needed exactly when a schedule cuts keys
+        need = lib.mavlm_attention_ws_floats(R, S, H)
+        assert (need > 0) == bool(G or ns > 1), (R, S, H)
+        if G:
+            assert need == G * len(levels) * (QB * 128 + QB), (R, S, H)
+
+
+def test_wide_head_splits_match_the_oracle(lib):
+    for R, S, H in itertools.product(ROWS, KEYS, [1, 2, 8]):
+        ns, _ = O.split_plan_wide(R, S, H)
+        need = lib.mavlm_attention_hd_ws_floats(R, S, H, 448)
+        assert (need > 0) == (ns > 1), (R, S, H)
+        if ns > 1:
+            assert need == ns * (R * H * 448 + H * R), (R, S, H)
+
+
+def test_frame_score_rule_matches_the_oracle(lib):
+    for R, H, P in itertools.product(ROWS, HEADS, [4, 60, 64, 100, 196, 198]):
+        for F in (1, 2, 3, 32, 40, 64, 65):
+            S = F * P
+            assert bool(lib.mavlm_frame_scores_fused(R, S, H, P)) == O.frame_scores_fused(R, S, H, P), (R, S, H, P)
+            assert (lib.mavlm_attention_frames_ws_floats(R, S, H, P) > 0) == (P % 4 == 0 and P >= 64 and F <= 64), (R, S, H, P)
+        assert not lib.mavlm_frame_scores_fused(R, 3 * P + 4, H, P)          # keys that are not whole frames
+    try:
+        capi.check(lib.mavlm_set_frame_score_mode(0), "mode")
+        assert not lib.mavlm_frame_scores_fused(12544, 6272, 8, 196)
+    finally:
+        lib.mavlm_set_frame_score_mode(1)
+    assert lib.mavlm_frame_scores_fused(12544, 6272, 8, 196) and not lib.mavlm_frame_scores_fused(1568, 6272, 8, 196)
+
+
+def test_column_sum_plan_is_consistent(lib):
+    info = (ctypes.c_int32 * 2)()
+    for R, S, H in itertools.product(ROWS, KEYS, [1, 3, 8]):
+        capi.check(lib.mavlm_attention_colsum_plan(R, S, H, info), "colsum plan")
+        wgs, planes = info[0], info[1]
+        nkb, ntq = -(-S // 128), -(-R // 64)
+        total = nkb * H * ntq
+        assert 1 <= wgs <= min(512, total) and planes >= 1, (R, S, H)
+        assert lib.mavlm_attention_colsum_floats(R, S, H) >= planes * H * S, (R, S, H)
+        # the planes bound: a unit's ntq tiles are spread over at most ceil((ntq - 1) / floor(total / wgs)) + 1 workgroups
+        q = total // wgs
+        assert planes <= (ntq - 1 + q - 1) // q + 1, (R, S, H)
