@@ -23,8 +23,9 @@
 extern "C" {
 #endif
 
-#define MAVLM_ABI_VERSION 1
+#define MAVLM_ABI_VERSION 2
 #define MAVLM_MAX_DEPTH 8
+#define MAVLM_MAX_BATCH 64
 
 #define MAVLM_E_ARG (-1)        /* null pointer / bad size */
 #define MAVLM_E_SHAPE (-2)      /* shape not supported by the kernels */
@@ -45,6 +46,11 @@ typedef struct mavlm_config {
   int32_t max_chunk_frames; /* largest F passed to mavlm_step (32) */
   int32_t dtype;            /* 0 = bf16, 1 = fp16 */
   float eps;                /* mm_layer_norm_eps (1e-12) */
+  int32_t batch;            /* B: independent videos stepped together over ONE set of weights (0 / 1 = a single video, the
+                             * reference's limit, llava_arch.py:436).  The memory rows of the B videos are stacked into every
+                             * weight-shared GEMM / LayerNorm launch ([B*M*P, D]); the attention serves B*heads (video, head)
+                             * pairs, each video over its own keys.  head_dim <= 128 only.  Buffers: see mavlm_buffers,
+                             * mavlm_weights.mem0; protocol: mavlm_step_batch / mavlm_fuse_emit_batch. */
 } mavlm_config;
 
 /* One `Attention` block (MemoryController.py:31-57) minus its K/V projections.  Weights [out,in] 16-bit
@@ -61,7 +67,7 @@ typedef struct mavlm_attn_weights {
 /* Borrowed device pointers into the packed parameter storage (packed once by the host module from the
  * reference state-dict names listed in SURVEY.md §8b). */
 typedef struct mavlm_weights {
-  const void* mem0;                     /* [M*P, D] 16-bit: initial_memory + memory_pos_embed (MemoryController.py:123) */
+  const void* mem0;                     /* [B*M*P, D] 16-bit: initial_memory + memory_pos_embed (MemoryController.py:123), repeated for each of the B = max(batch,1) videos */
   const void* w_kv_seg; const float* b_kv_seg; /* [2*L*Dp, D]: rows K_0,V_0,K_1,V_1,... of layers[l].memory_segment_fusion_attention.{k,v}_proj (head-padded) */
   mavlm_attn_weights layer_attn[MAVLM_MAX_DEPTH];
   const void* w_up[MAVLM_MAX_DEPTH];   const float* b_up[MAVLM_MAX_DEPTH];   /* layers[l].mlp.0          [I,D] */
@@ -76,8 +82,10 @@ typedef struct mavlm_weights {
 
 /* Caller-allocated state and scratch (the module owns them as torch tensors). */
 typedef struct mavlm_buffers {
-  void* mem_ring;       /* [cache_cap, M*P, D]  16-bit  memory_cache entries, slot = step % cache_cap */
-  void* evo_kv_ring;    /* [cache_cap, M*P, 2Dp] 16-bit K|V projections of each cached memory (projected once) */
+  void* mem_ring;       /* [cache_cap, B, M*P, D]  16-bit  memory_cache entries, slot = step % cache_cap (B = max(batch,1): a slot
+                         * holds the memory of every video of the row batch - one contiguous [B*M*P, D] GEMM operand) */
+  void* evo_kv_ring;    /* [B, cache_cap, M*P, 2Dp] 16-bit K|V projections of each cached memory (projected once); the keys
+                         * of ONE video are contiguous over its slots */
   void* workspace;      /* mavlm_workspace_bytes() bytes, 256-B aligned */
   size_t workspace_bytes;
 } mavlm_buffers;
@@ -112,6 +120,13 @@ int mavlm_pe_add(const void* x, const int64_t* idx, const void* table, void* out
  * frame_scores: null, or [F] (fp32 if scores_f32 else 16-bit) = probs.sum(heads).sum(queries).view(F,P).mean(1)
  * of the last layer (:135-139). */
 int mavlm_step(mavlm_ctx* ctx, const void* seg, int32_t F, void* frame_scores, int32_t scores_f32, void* stream);
+/* the same step for the B videos of a row-batched context (config.batch = B): segs = HOST array of B device pointers, the
+ * chunk [F,P,D] of each video (all videos step with the same F - group videos by shape); frame_scores: null or [B, F].
+ * The reference runs one video per forward (llava_arch.py:436, batch 1 per GPU); stacking the memory rows of several is
+ * exact for every row-wise operator, the attention keeps each video on its own keys.  Not bit-identical to B single-video
+ * contexts where the attention schedule differs (fp32 summation order of the cut units); same rounding points. */
+int mavlm_step_batch(mavlm_ctx* ctx, const void* const* segs, int32_t F, void* frame_scores, int32_t scores_f32, void* stream);
+int mavlm_batch(const mavlm_ctx* ctx);      /* B = max(config.batch, 1) */
 
 /* replaces memory_fuser(cat(memory_cache)) + token_type add + fine-frame gather/add + prompt/newline concat
  * (llava_arch.py:513-524,545-554,620-629,708-731).  Writes
@@ -120,15 +135,24 @@ int mavlm_step(mavlm_ctx* ctx, const void* seg, int32_t F, void* frame_scores, i
 int mavlm_fuse_emit(mavlm_ctx* ctx, const void* x_pe, const int64_t* fine_idx, int32_t n_fine, const void* mem_prompt,
                     int32_t n_mem_prompt, const void* frame_prompt, int32_t n_frame_prompt, const void* newline,
                     int32_t with_frames, void* out, int64_t out_capacity_rows, int64_t* rows, void* stream);
+/* the same for a row-batched context: x_pe = HOST array of B device pointers (each video's PE-added frames; fine_idx is
+ * shared: the videos have the same length), out = [B, rows_per_video, D] - video b's block starts b * rows_per_video rows
+ * into it; *rows = rows written per video. */
+int mavlm_fuse_emit_batch(mavlm_ctx* ctx, const void* const* x_pe, const int64_t* fine_idx, int32_t n_fine,
+                          const void* mem_prompt, int32_t n_mem_prompt, const void* frame_prompt, int32_t n_frame_prompt,
+                          const void* newline, int32_t with_frames, void* out, int64_t rows_per_video, int64_t* rows,
+                          void* stream);
 
 /* --- operator-level entry points (used by the parity tests; same kernels the step uses) --------------- */
 /* C = epi(A[M,K] . W[N,K]^T + bias); epilogue: 0 bias, 1 bias+ReLU, 2 bias+GELU(erf),
  * 3 bias+residual -> fp32 C, 4 bias -> fp32 C.   nn.Linear call sites: MemoryController.py:23,37-39,63-67; llava_arch.py:132-136 */
 int mavlm_linear(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const void* res, int32_t ldr,
                  void* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t dtype, void* stream);
-/* mavlm_attention on the plain grid + the frame scores of MemoryController.py:135-139 in the same pass: the S keys are
- * S / patches frames of `patches` consecutive keys (patches % 4 == 0, <= 64 frames), frame_scores[f] (fp32) = mean over the
- * frame's keys of the column sums (over heads and queries) of the normalised probabilities.  ws:
+/* The attention forward + the frame scores of MemoryController.py:135-139 in the same pass: the S keys are S / patches
+ * frames of `patches` consecutive keys (patches % 4 == 0, patches >= 64, <= 64 frames), frame_scores[f] (fp32) = mean over
+ * the frame's keys of the column sums (over heads and queries) of the normalised probabilities.  Runs the schedule
+ * mavlm_attention_ws runs for the shape (plain grid or levelled stream-K: O and lse2 are bit-identical to its results);
+ * the small grids that mavlm_attention_ws splits over the keys run the plain grid here (= mavlm_attention).  ws:
  * mavlm_attention_frames_ws_floats(...) floats of scratch (0 = shape not supported).  What mavlm_step runs for the last
  * formation layer (mavlm_frame_scores_fused). */
 int64_t mavlm_attention_frames_ws_floats(int32_t R, int32_t S, int32_t H, int32_t patches);
@@ -179,12 +203,12 @@ int mavlm_attention_colsum_hd(const void* Q, int32_t ldq, const void* K, int32_t
 /* part[H,S] fp32 = column sums over queries of the normalised probabilities.  MemoryController.py:135
  * `part` is also the pass's scratch: it must hold mavlm_attention_colsum_floats(R,S,H) floats (>= H*S: the balanced
  * schedule writes one plane of [H,S] per piece of a (key block, head) unit and adds the planes in order - deterministic,
- * no atomics); the result is its first H*S floats. */
+ * no atomics); the result is its first H*S floats.  part_floats = the floats `part` holds: MAVLM_E_ARG when too few. */
 int64_t mavlm_attention_colsum_floats(int32_t R, int32_t S, int32_t H);
 /* the schedule the pass runs (pure function of the shape): info[0] = workgroups, info[1] = planes it writes */
 int mavlm_attention_colsum_plan(int32_t R, int32_t S, int32_t H, int32_t info[2]);
 int mavlm_attention_colsum(const void* Q, int32_t ldq, const void* K, int32_t ldk, const float* lse2, float* part,
-                           int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream);
+                           int64_t part_floats, int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream);
 /* out = LayerNorm(x fp32 [rows,D] + res) * gamma + beta -> 16-bit; res: 16-bit [rows, ldr] residual or null.
  * MemoryController.py:24,26-28 */
 int mavlm_layernorm(const float* x, const void* res, int32_t ldr, const float* gamma, const float* beta, void* out,
@@ -267,7 +291,9 @@ int mavlm_set_gemm_rows(int32_t rows);
 /* tuning hook: attention forward kernel - 2 = register-staged (attention.hip), 3 = software-pipelined LDS-DMA
  * (attention3.hip), 0 = default (3).  Same rounding points; results equal up to fp32 summation order. */
 int mavlm_set_attention_impl(int32_t impl);
-/* tuning / test hook: the head_dim-128 forward switches to its stream-K schedule (persistent workgroups over equal ranges of
+/* (all tuning hooks below that are "part of the result" are process-wide: a context created before a change keeps working -
+ * its workspace covers either stream-K workgroup shape - and mavlm_step returns MAVLM_E_STATE if a plan would not fit it)
+ * tuning / test hook: the head_dim-128 forward switches to its stream-K schedule (persistent workgroups over equal ranges of
  * the global key-tile sequence) when there are more units than workgroup slots AND at least this many 64-key
  * tiles per unit (default 64).  The schedule is part of the result (fp32 summation order): set it before sizing workspaces. */
 int mavlm_set_attention_streamk_min_tiles(int32_t tiles);
@@ -282,10 +308,10 @@ int mavlm_set_attention_colsum_wgs(int32_t wgs);
  * current frame next to its row sum; 0 = the separate column-sum pass over Q, K and lse2.  Same
  * values up to fp32 summation order. */
 int mavlm_set_frame_score_mode(int32_t mode);
-/* 1 if mavlm_step takes the fused form for a last-layer attention of R memory rows over S = F * patches keys with heads of
- * <= 128 columns - patches % 4 == 0, patches >= 64, <= 64 frames, and not one of the small grids that split their keys
- * (mavlm_attention_ws_floats) - (then that attention runs the plain, never-split grid - what mavlm_attention computes - so a host that
- * mirrors the step operator by operator, e.g. the training path, calls mavlm_attention there to stay bit-identical) */
+/* 1 if mavlm_step (single video) takes the fused form for a last-layer attention of R memory rows over S = F * patches keys
+ * with heads of <= 128 columns - patches % 4 == 0, patches >= 64, <= 64 frames, and not one of the small grids that split
+ * their keys (mavlm_attention_ws_floats), which keep the column-sum pass.  The fused launch runs the SAME schedule as the
+ * plain forward of that shape (mavlm_attention_ws): the context and the memory do not depend on whether scores are asked for. */
 int mavlm_frame_scores_fused(int32_t R, int32_t S, int32_t H, int32_t patches);
 
 /* --- measurement hooks (bench.py only; new - the reference has no profiling) ------------- */

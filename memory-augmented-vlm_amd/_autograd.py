@@ -174,10 +174,9 @@ def attention_block(attn, q_in, k, v, want_stats=False, patches_per_frame=196):
     dt = q_in.dtype      # parameters kept in fp32 (master weights) are cast per use; the cast is autograd-transparent
     q = LinearFn.apply(q_in, pad_heads_out(attn.q_proj.weight, H, hd).to(dt), pad_heads_out(attn.q_proj.bias, H, hd),
                        ACT_NONE)
-    # the fused step runs the last formation layer's attention on the plain grid when it carries the frame scores
-    plain = bool(want_stats and hd <= 128 and
-                 capi.lib().mavlm_frame_scores_fused(q.shape[0], k.shape[0], H, patches_per_frame))
-    ctxv, lse = AttentionFn.apply(q, k, v, H, scale, head_width(hd), plain)
+    # (the fused step's last formation layer carries the frame scores on the SAME schedule as every other attention of
+    # the shape - round 3 - so there is no special case here: `ops.attention` takes that schedule)
+    ctxv, lse = AttentionFn.apply(q, k, v, H, scale, head_width(hd), False)
     d = attn.residual
     out = DenseResidualNormFn.apply(ctxv, pad_heads_in(d.dense.weight, H, hd).to(dt), d.dense.bias, q_in,
                                     d.layernorm.weight, d.layernorm.bias, d.layernorm.eps)

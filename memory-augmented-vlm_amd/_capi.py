@@ -19,7 +19,8 @@ i32 = C.c_int32
 
 class Config(C.Structure):
     _fields_ = [("hidden", i32), ("heads", i32), ("patches", i32), ("mem_tokens", i32), ("depth", i32),
-                ("inter", i32), ("cache_cap", i32), ("max_chunk_frames", i32), ("dtype", i32), ("eps", C.c_float)]
+                ("inter", i32), ("cache_cap", i32), ("max_chunk_frames", i32), ("dtype", i32), ("eps", C.c_float),
+                ("batch", i32)]
 
 
 class AttnWeights(C.Structure):
@@ -55,6 +56,10 @@ SIGNATURES = {
     "mavlm_steps": (C.c_int, [vp]),
     "mavlm_pe_add": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mavlm_step": (C.c_int, [vp, vp, i32, vp, i32, vp]),
+    "mavlm_step_batch": (C.c_int, [vp, C.POINTER(vp), i32, vp, i32, vp]),
+    "mavlm_batch": (C.c_int, [vp]),
+    "mavlm_fuse_emit_batch": (C.c_int, [vp, C.POINTER(vp), vp, i32, vp, i32, vp, i32, vp, i32, vp, C.c_int64,
+                                        C.POINTER(C.c_int64), vp]),
     "mavlm_fuse_emit": (C.c_int, [vp, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, C.c_int64,
                                   C.POINTER(C.c_int64), vp]),
     "mavlm_linear": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
@@ -68,7 +73,7 @@ SIGNATURES = {
     "mavlm_attention_hd_ws": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, C.c_float, vp, C.c_int64,
                                         i32, vp]),
     "mavlm_attention_colsum_hd": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, C.c_float, i32, vp]),
-    "mavlm_attention_colsum": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, i32, i32, C.c_float, i32, vp]),
+    "mavlm_attention_colsum": (C.c_int, [vp, i32, vp, i32, vp, vp, C.c_int64, i32, i32, i32, C.c_float, i32, vp]),
     "mavlm_layernorm": (C.c_int, [vp, vp, i32, vp, vp, vp, i32, i32, C.c_float, i32, vp]),
     "mavlm_row_add": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mavlm_pool_bilinear": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -133,7 +138,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.mavlm_abi_version() != 1:
+        if l.mavlm_abi_version() != 2:
             raise MavlmError("libmavlm.so ABI version mismatch - rebuild")
         _lib = l
     return _lib

@@ -143,7 +143,7 @@ def attention_colsum(q, k, lse2, heads, head_dim=128, wide_kernel=False, scale=N
         buf = torch.empty((int(capi.lib().mavlm_attention_colsum_floats(R, S, heads)),), device=q.device, dtype=torch.float32)
         part = buf[:heads * S].view(heads, S)
         capi.check(capi.lib().mavlm_attention_colsum(q.data_ptr(), ldq, k.data_ptr(), ldk, lse2.data_ptr(), part.data_ptr(),
-                                                     R, S, heads, 1.0 / math.sqrt(128.0) if scale is None else float(scale),
+                                                     buf.numel(), R, S, heads, 1.0 / math.sqrt(128.0) if scale is None else float(scale),
                                                      dtype_code(q.dtype), stream_ptr()),
                    "mavlm_attention_colsum")
     else:

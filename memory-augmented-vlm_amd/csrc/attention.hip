@@ -416,11 +416,13 @@ static bool attn_args_ok(const void* q, int ldq, const void* k, int ldk, int R, 
 int g_mavlm_attn_impl = 0;
 
 hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream_t s) {
-  if (!attn_args_ok(a.Q, a.ldq, a.K, a.ldk, a.R, a.S, a.H) || !a.V || !a.O || (a.ldv & 7) || (a.ldo & 3))
+  const int nb = a.nb > 0 ? a.nb : 1;
+  if (a.H % nb != 0 || !attn_args_ok(a.Q, a.ldq, a.K, a.ldk, a.R, a.S, a.H / nb) || !a.V || !a.O || (a.ldv & 7) || (a.ldo & 3))
     return hipErrorInvalidValue;
   const float c = a.scale * 1.44269504088896340736f;
   dim3 grid(((a.R + 127) / 128) * a.H);
   if (g_mavlm_attn_impl != 2) return mavlm_launch_attention3(a, dtype, s);     // (brackets its kernels itself)
+  if (nb != 1) return hipErrorInvalidValue;                                     // the register-staged kernel: single videos only
   mavlm_prof_scope prof(MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD,
                         2.0 * HD * a.H * (2.0 * a.R + 2.0 * a.S), s);
   return launch_attention2(a, dtype, s, c, grid);

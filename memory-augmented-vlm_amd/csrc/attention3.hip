@@ -74,7 +74,15 @@ struct attn3_sk_plan {
 // scratch entry [h][q][frame] when the key loop crosses a frame boundary (FP % 4 == 0: a boundary never cuts one of the
 // 4-key groups a lane holds).  With the final log-sum-exp of the row known, the wave turns its 32 x F entries into F
 // partial frame sums, sum_q a 2^(m c - lse2); frame_finish_kernel adds the partial sums of all waves in a fixed order.
-// Whole units only (plain grid, no key splits): an entry has one writer.
+// On the levelled stream-K schedule a cut unit's pieces start in the middle of a frame: piece p writes the part of frame
+// f it saw to entry f + p of the row (a row has FNE = FN + 31 entries: pieces and frames both ascend along the keys, so
+// f + p is unique), flushes its last, unfinished frame after its key loop, and attn_combine_sk_kernel - which knows the
+// row's final log-sum-exp - turns the entries of the cut units into partial frame sums in the same [unit][wave] layout.
+// An entry has exactly one writer: rows past R (clamped duplicates of row R-1) store to an offset behind the buffer
+// descriptor's end, which the hardware drops.
+//
+// Row batch (HB < H): the launch serves B = H / HB independent videos.  "Head" index h = b HB + hv: queries / outputs of
+// video b are the rows [b R, (b+1) R) of Q / O, its keys start kv_bs elements after video b-1's; lse2 is [B HB, R].
 template <typename T, int NW, int FR = 0>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* __restrict__ Q, int ldq,
                                                            const uint16_t* __restrict__ Kall, int ldk,
@@ -82,8 +90,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
                                                            uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
                                                            int R, int S_all, int H, float c, float* __restrict__ Opart,
                                                            float* __restrict__ lse_part, int tps, attn3_sk_plan plan,
+                                                           int HB, long long kv_bs,
                                                            float* __restrict__ fscr = nullptr,
-                                                           float* __restrict__ fout = nullptr, int FP = 0, int FN = 0) {
+                                                           float* __restrict__ fout = nullptr, int FP = 0, int FN = 0,
+                                                           int FNE = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
   for (int si = 0; si < nseg; ++si) {
   // ---- this segment: unit (h, q-block), key tiles [t_lo, t_lo + nt)
   int h, qblk, t_lo, nt, out_kind, split = 0;                 // out_kind 0: O/lse2, 1: split-KV partial, 2: stream-K partial
-  int sk_slot = 0;
+  int sk_slot = 0, sk_piece = 0;
   if (plan.wgs > 0) {
     int u;
     if (si < plan.full) {
@@ -124,6 +134,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
       nt = (int)(((long long)(piece + 1) * nt_all) >> lk) - t_lo;
       out_kind = 2;
       sk_slot = lslot + sk_v;
+      sk_piece = piece;
       if (nt == 0) {                                           // fewer key tiles than pieces: a neutral partial (weight 0)
         float* pp = Opart + ((size_t)sk_slot * QB + wave * 32 + r) * HD3 + 64 * hh;
 #pragma unroll
@@ -142,8 +153,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
     nt = tps > 0 ? ((nt_all - t_lo < tps) ? nt_all - t_lo : tps) : nt_all;
     out_kind = tps > 0 ? 1 : 0;
   }
-  const uint16_t* K = Kall + (size_t)t_lo * KT3 * ldk;
-  const uint16_t* V = Vall + (size_t)t_lo * KT3 * ldv;
+  const int hb = h / HB, hv = h - hb * HB;                    // video of the row batch, head inside it
+  const uint16_t* K = Kall + (size_t)hb * kv_bs + (size_t)t_lo * KT3 * ldk;
+  const uint16_t* V = Vall + (size_t)hb * kv_bs + (size_t)t_lo * KT3 * ldv;
   const int S = (S_all - t_lo * KT3 < nt * KT3) ? S_all - t_lo * KT3 : nt * KT3;      // keys of this segment
   const int q0 = qblk * QB + wave * 32;
 
@@ -152,7 +164,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
   {
     int qrow = q0 + r;
     qrow = qrow < R ? qrow : R - 1;
-    const uint16_t* qp = Q + (size_t)qrow * ldq + h * HD3 + 8 * hh;
+    const uint16_t* qp = Q + ((size_t)hb * R + qrow) * ldq + hv * HD3 + 8 * hh;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const typename T::vec8*)(qp + 16 * ks);
   }
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
   const int drow = 4 * w4 + (lane >> 4);                      // + 16 i
   const int dch = (lane & 15) ^ (((lane >> 4) << 2) | w4);
   auto head_rsrc = [&](const uint16_t* base, int ld) {
-    const uintptr_t a = (uintptr_t)(base + h * HD3);
+    const uintptr_t a = (uintptr_t)(base + hv * HD3);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
     const uint32_t bytes = __builtin_amdgcn_readfirstlane((uint32_t)(S - 1) * (uint32_t)ld * 2u + (uint32_t)HD3 * 2u);
@@ -239,11 +251,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
     const uintptr_t fa = (uintptr_t)fscr;
     const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)fa);          // (uint32_t: readfirstlane returns int - no
     const uint32_t fhi = __builtin_amdgcn_readfirstlane((uint32_t)(fa >> 32));  //  sign extension into the high word)
-    const uint32_t fbytes = __builtin_amdgcn_readfirstlane((uint32_t)H * (uint32_t)R * (uint32_t)FN * 8u);
+    const uint32_t fbytes = __builtin_amdgcn_readfirstlane((uint32_t)H * (uint32_t)R * (uint32_t)FNE * 8u);
     frs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)fhi << 32) | flo), 0, fbytes, 0x00020000);
-    int qrow = q0 + r;
-    qrow = qrow < R ? qrow : R - 1;                           // (rows past R: duplicates of the last row, never read back)
-    f_voff = (h * R + qrow) * FN * 8;                         // entry [h][q][f] = (a, m): 8 bytes
+    // entry [h][q][f + piece] = (a, m): 8 bytes.  Rows past R are clamped duplicates of row R-1 in every other respect; their
+    // entry stores must land NOWHERE (a whole wave of duplicates can take a rescale the owning wave does not, and would
+    // race with it): an offset behind the descriptor's end is dropped by the hardware, and the store stays issued, so the
+    // vmcnt accounting of the tile loop does not change.
+    f_voff = q0 + r < R ? ((h * R + q0 + r) * FNE + sk_piece) * 8 : 0x7ffffff0;
+    // a piece of a cut unit starts at key t_lo * 64 of its unit: the frame that holds that key, and where it ends in
+    // piece-local key numbers
+    f_cur = (t_lo * KT3) / FP;
+    f_end = (f_cur + 1) * FP - t_lo * KT3;
   }
 
   // S(t) = K(t).Q^T into st[P] (no overlap; used for tile 0 only)
@@ -536,6 +554,20 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
   }
   if (t < nt) iteration(IC<0>{}, t);
 
+  if constexpr (FR != 0) {
+    // a piece that ends inside a frame: the mass of that frame's keys seen so far is still in a_cur (whole units end on a
+    // frame boundary: S % FP == 0, the last flush happened in the loop and the next frame starts at key S)
+    if (f_end - FP < S) {
+      const float a_done = xhalf_sum(a_cur);
+      if (hh == 0) {
+        u32x2 e;
+        e[0] = __builtin_bit_cast(unsigned, a_done);
+        e[1] = __builtin_bit_cast(unsigned, m_run);
+        __builtin_amdgcn_raw_buffer_store_b64(e, frs, f_voff, f_cur * 8, 0);
+      }
+    }
+  }
+
   // ---- epilogue: O[q][h*128 + 32db + 8g + 4hh + 0..3] = O^T / l
   const float l_tot = xhalf_sum(l_run);
   const float inv = 1.0f / l_tot;
@@ -560,7 +592,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
                                                   ot[db][4 * g + 3] * inv};
       if (hh == 0) lse_part[((size_t)split * H + h) * R + q] = m_run * c + log2f(l_tot);
     } else {
-      uint16_t* op = O + (size_t)q * ldo + h * HD3 + 4 * hh;
+      uint16_t* op = O + ((size_t)hb * R + q) * ldo + hv * HD3 + 4 * hh;
 #pragma unroll
       for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -570,7 +602,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
       if (lse2 != nullptr && hh == 0) lse2[(size_t)h * R + q] = m_run * c + log2f(l_tot);
     }
   }
-  if constexpr (FR != 0) {
+  if (FR != 0 && out_kind == 0) {                             // whole unit: the row's final log-sum-exp is known here
     // Lane j takes frame j (FN <= 64): for each of the wave's 32 queries it reads the (a, m) entry [h][q][j] - one 8-byte
     // load per lane, a query's F entries are contiguous - and adds a 2^(m c - lse2[q]).  The entries were written by this
     // wave (all stores retired by the vmcnt(0) that ended the last tile); nobody else has touched these lines.
@@ -586,7 +618,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
       int qi = q0 + i;
       qi = qi < R ? qi : R - 1;
       // (two dword loads: with the b64 form of the builtin hipcc emitted ONE buffer_load_dword and used it for both halves)
-      const int eoff = ((h * R + qi) * FN + fj) * 8;
+      const int eoff = ((h * R + qi) * FNE + fj) * 8;
       ea[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frs, eoff, 0, 1 /* glc: not from L1 */));
       em[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frs, eoff + 4, 0, 1));
     }
@@ -608,13 +640,46 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
 // (NP = 2^k is a compile-time constant per level so that the 2^k log-sum-exp loads and the 2^k partial-row loads of a query
 // row are issued back to back: as run-time loops each load waited for the previous one - 96 dependent round trips per row
 // at k = 5, 283 us for the whole merge against 600 us for the attention itself.)
-template <typename T, int NP>
+// FR: the frame-score variant (see attn_fwd3_kernel).  The pieces of a cut unit left (a, m) entries for the parts of the
+// frames they saw; with the merged log-sum-exp of a row known here, lane c4 of the row's 32 lanes takes frames c4 and c4 + 32
+// and adds a 2^(m c - lse) over the pieces that hold keys of the frame; the workgroup's 32 rows are then added in a fixed
+// order (LDS) into ONE partial frame sum per (unit, 32-row group) - the slot a whole unit's wave fills in the main kernel.
+struct attn3_frames_args {
+  const float* scr;    // [H][R][FNE] entries (a, m)
+  float* out;          // [units][QB / 32][FN] partial frame sums
+  int FP, FN, FNE, S;  // keys per frame, frames, entries per row, keys
+  float c;
+};
+
+template <typename T, int NP, int FR>
 __device__ __forceinline__ void combine_sk_rows(const float* __restrict__ Opart, const float* __restrict__ lse_part, size_t s0,
                                                 uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2, int R, int h, int qblk,
-                                                int quarter, int QB) {
+                                                int quarter, int QB, int HB, int lk, int u, const attn3_frames_args& fa,
+                                                float* fsh) {
   const int c4 = threadIdx.x & 31, rsub = threadIdx.x >> 5;
+  const int hb = h / HB, hv = h - hb * HB;
+  float fs[2] = {0.f, 0.f};
+  // frame f = c4 + 32 ff: the pieces [fp0, fp1] that hold its keys (piece p owns the key tiles [(p nt) >> lk, ((p+1) nt) >> lk))
+  int fp0[2] = {0, 0}, fp1[2] = {-1, -1};
+  const int nt_all_ = FR != 0 ? (fa.S + KT3 - 1) / KT3 : 1;
+  if constexpr (FR != 0) {
+    const int nt_all = (fa.S + KT3 - 1) / KT3;
+    auto piece_of = [&](int tile) {                            // the (non-empty) piece that owns key tile `tile`
+      int p = (int)(((long long)tile << lk) / nt_all);
+      while (p + 1 < (1 << lk) && (int)(((long long)(p + 1) * nt_all) >> lk) <= tile) ++p;
+      return p;
+    };
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {                             // a workgroup merges 32 of the unit's 128 rows
+    for (int ff = 0; ff < 2; ++ff) {
+      const int f = c4 + 32 * ff;
+      if (f < fa.FN) {
+        fp0[ff] = piece_of((f * fa.FP) / KT3);
+        fp1[ff] = piece_of(((f + 1) * fa.FP - 1) / KT3);
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {                             // a workgroup merges 32 of the unit's rows
     const int row = quarter * 32 + it * 8 + rsub;
     const int q = qblk * QB + row;
     if (q >= R) continue;
@@ -641,15 +706,41 @@ __device__ __forceinline__ void combine_sk_rows(const float* __restrict__ Opart,
         acc[0] += w * a[j][0]; acc[1] += w * a[j][1]; acc[2] += w * a[j][2]; acc[3] += w * a[j][3];
       }
     }
-    *(u32x2*)(O + (size_t)q * ldo + h * HD3 + 4 * c4) = pack4<T>(acc[0], acc[1], acc[2], acc[3]);
+    *(u32x2*)(O + ((size_t)hb * R + q) * ldo + hv * HD3 + 4 * c4) = pack4<T>(acc[0], acc[1], acc[2], acc[3]);
     if (lse2 != nullptr && c4 == 0) lse2[(size_t)h * R + q] = lse;
+    if constexpr (FR != 0) {
+      const float* er = fa.scr + ((size_t)h * R + q) * fa.FNE * 2;
+#pragma unroll
+      for (int ff = 0; ff < 2; ++ff) {
+        const int f = c4 + 32 * ff;
+        for (int p = fp0[ff]; p <= fp1[ff]; ++p) {             // (empty for f >= FN)
+          // pieces without key tiles (fewer tiles than pieces) wrote no entry
+          if ((int)(((long long)(p + 1) * nt_all_) >> lk) == (int)(((long long)p * nt_all_) >> lk)) continue;
+          const f32x2 e = *(const f32x2*)(er + 2 * (f + p));
+          fs[ff] += e[0] * __builtin_amdgcn_exp2f(e[1] * fa.c - lse);
+        }
+      }
+    }
+  }
+  if constexpr (FR != 0) {
+    fsh[rsub * 64 + c4] = fs[0];
+    fsh[rsub * 64 + 32 + c4] = fs[1];
+    __syncthreads();
+    if (threadIdx.x < 64 && (int)threadIdx.x < fa.FN) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t += fsh[i * 64 + threadIdx.x];
+      fa.out[((size_t)u * (QB / 32) + quarter) * fa.FN + threadIdx.x] = t;
+    }
   }
 }
 
-template <typename T>
+template <typename T, int FR>
 __global__ __launch_bounds__(256) void attn_combine_sk_kernel(const float* __restrict__ Opart, const float* __restrict__ lse_part,
                                                               uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
-                                                              int R, int H, attn3_sk_plan plan, int QB) {
+                                                              int R, int H, attn3_sk_plan plan, int QB, int HB,
+                                                              attn3_frames_args fa) {
+  __shared__ float fsh[FR != 0 ? 512 : 1];
   const int wpu = QB / 32;                                     // workgroups per cut unit (32 query rows each)
   int b = blockIdx.x / wpu, lk = 0, lbase = 0, lslot = 0;
   const int quarter = blockIdx.x - b * wpu;
@@ -667,11 +758,11 @@ __global__ __launch_bounds__(256) void attn_combine_sk_kernel(const float* __res
   const int h = u / nqb, qblk = u - h * nqb;
   const size_t s0 = (size_t)lslot + ((size_t)b << lk);
   switch (lk) {
-    case 1: combine_sk_rows<T, 2>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter, QB); break;
-    case 2: combine_sk_rows<T, 4>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter, QB); break;
-    case 3: combine_sk_rows<T, 8>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter, QB); break;
-    case 4: combine_sk_rows<T, 16>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter, QB); break;
-    default: combine_sk_rows<T, 32>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter, QB); break;
+    case 1: combine_sk_rows<T, 2, FR>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter, QB, HB, lk, u, fa, fsh); break;
+    case 2: combine_sk_rows<T, 4, FR>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter, QB, HB, lk, u, fa, fsh); break;
+    case 3: combine_sk_rows<T, 8, FR>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter, QB, HB, lk, u, fa, fsh); break;
+    case 4: combine_sk_rows<T, 16, FR>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter, QB, HB, lk, u, fa, fsh); break;
+    default: combine_sk_rows<T, 32, FR>(Opart, lse_part, s0, O, ldo, lse2, R, h, qblk, quarter, QB, HB, lk, u, fa, fsh); break;
   }
 }
 
@@ -803,6 +894,18 @@ size_t mavlm_attention_split_ws_floats(int R, int S, int H) {
   return ns > 1 ? (size_t)ns * R * H * HD3 + (size_t)ns * H * R : 0;
 }
 
+// workspace that covers the plan of either workgroup shape (4 / 8 waves): for buffers sized before the tuning hook
+// mavlm_set_attention_streamk_waves may change
+size_t mavlm_attention_split_ws_floats_max(int R, int S, int H) {
+  size_t m = mavlm_attention_split_ws_floats(R, S, H);
+  for (int w = 4; w <= 8; w += 4) {
+    const attn3_sk_plan pl = attn3_plan_for(R, S, H, w);
+    const size_t v = pl.wgs > 0 ? (size_t)pl.wgs * pl.nlev * ((size_t)pl.qb * HD3 + pl.qb) : 0;
+    if (v > m) m = v;
+  }
+  return m;
+}
+
 namespace {
 struct attn3_launch_args {
   dim3 grid;
@@ -811,19 +914,24 @@ struct attn3_launch_args {
   float* lpart;
   int tps, ns, cut_units;
   attn3_sk_plan plan;
+  int HB;              // heads per video (a.H / a.nb)
+  int FNE;             // frame-score variant: entries per row of the scratch
 };
-template <typename T, int NW>
+template <typename T, int NW, int FR>
 hipError_t attn3_launch(const mavlm_attn_args& a, const attn3_launch_args& la, hipStream_t s) {
-  auto kern = attn_fwd3_kernel<T, NW>;
+  auto kern = attn_fwd3_kernel<T, NW, FR>;
   static mavlm_per_device_once once;
   hipError_t e = once.dyn_lds((const void*)kern, ATTN3_LDS);
   if (e != hipSuccess) return e;
+  const int FN = FR ? a.S / a.frame_keys : 0;
   {  // (bench.py's instrumented pass: the main kernel and the merge are bracketed separately, so the main kernel's average
      // is directly comparable with its line in a rocprofv3 summary)
-    mavlm_prof_scope prof(MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD3, 2.0 * HD3 * a.H * (2.0 * a.R + 2.0 * a.S), s);
+    mavlm_prof_scope prof(FR ? MAVLM_K_ATTN_FRAMES : MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD3,
+                          2.0 * HD3 * a.H * (2.0 * a.R + 2.0 * a.S), s);
     hipLaunchKernelGGL(kern, la.grid, dim3(64 * NW), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K, a.ldk,
                        (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, la.c, la.opart, la.lpart,
-                       la.tps, la.plan, (float*)nullptr, (float*)nullptr, 0, 0);
+                       la.tps, la.plan, la.HB, (long long)a.kv_bstride, FR ? a.frame_scr : (float*)nullptr,
+                       FR ? a.frame_out : (float*)nullptr, FR ? a.frame_keys : 0, FN, la.FNE);
   }
   double parts = la.ns > 1 ? (double)la.ns * a.R * a.H : 0.0;      // fp32 partial rows the merge reads
   if (la.plan.wgs > 0) {
@@ -832,95 +940,96 @@ hipError_t attn3_launch(const mavlm_attn_args& a, const attn3_launch_args& la, h
   }
   mavlm_prof_scope prof(la.plan.wgs > 0 ? (la.cut_units > 0 ? MAVLM_K_ATTN_MERGE : -1) : (la.ns > 1 ? MAVLM_K_ATTN_MERGE : -1),
                         0.0, parts * 4.0 * (HD3 + 1), s);
-  if (la.plan.wgs > 0 && la.cut_units > 0)
-    hipLaunchKernelGGL(attn_combine_sk_kernel<T>, dim3(la.cut_units * (la.plan.qb / 32)), dim3(256), 0, s, la.opart, la.lpart,
-                       (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.H, la.plan, la.plan.qb);
-  else if (la.ns > 1)
+  if (la.plan.wgs > 0 && la.cut_units > 0) {
+    attn3_frames_args fa = {};
+    if (FR) fa = attn3_frames_args{a.frame_scr, a.frame_out, a.frame_keys, FN, la.FNE, a.S, la.c};
+    hipLaunchKernelGGL((attn_combine_sk_kernel<T, FR>), dim3(la.cut_units * (la.plan.qb / 32)), dim3(256), 0, s, la.opart,
+                       la.lpart, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.H, la.plan, la.plan.qb, la.HB, fa);
+  } else if (la.ns > 1) {
     hipLaunchKernelGGL(attn_combine_kernel<T>, dim3((a.R + 3) / 4), dim3(256), 0, s, la.opart, la.lpart, (uint16_t*)a.O, a.ldo,
                        a.lse2, a.R, a.H, HD3, la.ns);
+  }
   return hipGetLastError();
 }
 }  // namespace
 
 int g_mavlm_frame_score_mode = 1;   // mavlm_step: 1 = frame scores fused into the last layer's forward, 0 = column-sum pass
 
-// scores[f] = (1 / P) * sum of the per-wave partial frame sums, rows added in a fixed order (one workgroup per frame)
+// scores[b][f] = (1 / P) * sum of the partial frame sums of video b (rows [b rows, (b+1) rows) of fout), added in a fixed
+// order (one workgroup per (frame, video))
 template <typename T>
 __global__ __launch_bounds__(256) void frame_finish_kernel(const float* __restrict__ fout, int rows, int F, int P,
                                                            void* __restrict__ out, int out_f32) {
   __shared__ float wsum[4];
-  const int f = blockIdx.x, tid = threadIdx.x;
+  const int f = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* fo = fout + (size_t)b * rows * F;
   float s = 0.f;
-  for (int i = tid; i < rows; i += 256) s += fout[(size_t)i * F + f];
+  for (int i = tid; i < rows; i += 256) s += fo[(size_t)i * F + f];
   s = wave_sum(s);
   if ((tid & 63) == 0) wsum[tid >> 6] = s;
   __syncthreads();
   if (tid == 0) {
     s = (((wsum[0] + wsum[1]) + wsum[2]) + wsum[3]) / (float)P;
-    if (out_f32) ((float*)out)[f] = s;
-    else ((uint16_t*)out)[f] = T::from_f32(s);
+    if (out_f32) ((float*)out)[(size_t)b * F + f] = s;
+    else ((uint16_t*)out)[(size_t)b * F + f] = T::from_f32(s);
   }
 }
 
-// Frame-score variant of the forward (fused step, last formation layer): plain grid of 4-wave workgroups, whole units.
+// Frame-score variant of the forward (fused step, last formation layer).  Runs whatever schedule the plain forward of the
+// same shape runs (plain grid or levelled stream-K - never the split-KV form of the small grids, which keep the column-sum
+// pass): context and log-sum-exp are bit-identical to mavlm_launch_attention3's.
+constexpr int ATTN3_FR_EXTRA = 31;      // extra entries per row: a unit is cut into at most 32 pieces
 bool mavlm_attention_frames_supported(int R, int S, int H, int frame_keys) {
-  // (the size bound is taken at the largest frame count, 64: the answer depends on S only through S % frame_keys and S / frame_keys <= 64)
-  // frame_keys >= 64: at most one frame boundary per 64-key tile; % 4: a boundary never cuts a lane's 4-key group
+  // frame_keys >= 64: at most one frame boundary per 64-key tile; % 4: a boundary never cuts a lane's 4-key group;
+  // the scratch is addressed through 32-bit offsets below the "dropped store" offset 0x7ffffff0
   return frame_keys >= KT3 && (frame_keys & 3) == 0 && S > 0 && S % frame_keys == 0 && S / frame_keys <= 64 &&
-         (double)H * R * 64.0 * 8.0 < 4294967296.0;
+         (double)H * R * (64.0 + ATTN3_FR_EXTRA) * 8.0 < 2147483000.0;
 }
-size_t mavlm_attention_frames_scr_floats(int R, int S, int H, int frame_keys) { return (size_t)H * R * (S / frame_keys) * 2; }
+size_t mavlm_attention_frames_scr_floats(int R, int S, int H, int frame_keys) {
+  return (size_t)H * R * (S / frame_keys + ATTN3_FR_EXTRA) * 2;
+}
+// one partial frame sum per (unit, 32-query group): units of 128 or 256 queries cover ceil(R/128)*4 or ceil(R/256)*8 groups
+size_t mavlm_attention_frames_out_rows(int R, int H) {
+  const size_t g4 = (size_t)((R + 127) / 128) * 4, g8 = (size_t)((R + 255) / 256) * 8;
+  return (size_t)H * (g4 > g8 ? g4 : g8);
+}
 size_t mavlm_attention_frames_out_floats(int R, int S, int H, int frame_keys) {
-  return (size_t)H * ((R + 127) / 128) * 4 * (S / frame_keys);
+  return mavlm_attention_frames_out_rows(R, H) * (S / frame_keys);
 }
 
-hipError_t mavlm_launch_attention3_frames(const mavlm_attn_args& a, int dtype, hipStream_t s) {
-  if (!a.frame_scr || !a.frame_out || !mavlm_attention_frames_supported(a.R, a.S, a.H, a.frame_keys)) return hipErrorInvalidValue;
-  if ((double)a.S * a.ldk * 2.0 >= 2147483648.0 || (double)a.S * a.ldv * 2.0 >= 2147483648.0) return hipErrorInvalidValue;
-  const float c = a.scale * 1.44269504088896340736f;
-  const int FN = a.S / a.frame_keys;
-  const dim3 grid(((a.R + 127) / 128) * a.H);
-  const attn3_sk_plan plan = {};
-  mavlm_prof_scope prof(MAVLM_K_ATTN_FRAMES, 4.0 * a.R * (double)a.S * a.H * HD3, 2.0 * HD3 * a.H * (2.0 * a.R + 2.0 * a.S), s);
-  if (dtype == MAVLM_F16) {
-    auto kern = attn_fwd3_kernel<F16, 4, 1>;
-    static mavlm_per_device_once once;
-    hipError_t e = once.dyn_lds((const void*)kern, ATTN3_LDS);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K, a.ldk,
-                       (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, (float*)nullptr,
-                       (float*)nullptr, 0, plan, a.frame_scr, a.frame_out, a.frame_keys, FN);
-  } else {
-    auto kern = attn_fwd3_kernel<BF16, 4, 1>;
-    static mavlm_per_device_once once;
-    hipError_t e = once.dyn_lds((const void*)kern, ATTN3_LDS);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, dim3(256), ATTN3_LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K, a.ldk,
-                       (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c, (float*)nullptr,
-                       (float*)nullptr, 0, plan, a.frame_scr, a.frame_out, a.frame_keys, FN);
-  }
-  return hipGetLastError();
-}
-
-hipError_t mavlm_launch_frame_finish(const float* fout, int rows, int F, int P, void* out, int out_f32, int dtype,
+hipError_t mavlm_launch_frame_finish(const float* fout, int rows, int nb, int F, int P, void* out, int out_f32, int dtype,
                                      hipStream_t s) {
-  if (!fout || !out || rows <= 0 || F <= 0 || P <= 0) return hipErrorInvalidValue;
-  mavlm_prof_scope prof(MAVLM_K_MISC, 0.0, 4.0 * rows * (double)F, s);
-  if (dtype == MAVLM_F16) hipLaunchKernelGGL(frame_finish_kernel<F16>, dim3(F), dim3(256), 0, s, fout, rows, F, P, out, out_f32);
-  else hipLaunchKernelGGL(frame_finish_kernel<BF16>, dim3(F), dim3(256), 0, s, fout, rows, F, P, out, out_f32);
+  if (!fout || !out || rows <= 0 || F <= 0 || P <= 0 || nb <= 0) return hipErrorInvalidValue;
+  mavlm_prof_scope prof(MAVLM_K_MISC, 0.0, 4.0 * rows * (double)F * nb, s);
+  if (dtype == MAVLM_F16) hipLaunchKernelGGL(frame_finish_kernel<F16>, dim3(F, nb), dim3(256), 0, s, fout, rows, F, P, out, out_f32);
+  else hipLaunchKernelGGL(frame_finish_kernel<BF16>, dim3(F, nb), dim3(256), 0, s, fout, rows, F, P, out, out_f32);
   return hipGetLastError();
 }
 
-hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStream_t s) {
+// rows of `frame_out` per video that mavlm_launch_attention3_frames fills for this shape (the argument of the finish kernel)
+int mavlm_attention_frames_rows_per_video(const mavlm_attn_args& a) {
+  const int nb = a.nb > 0 ? a.nb : 1;
+  attn3_sk_plan plan = {};
+  if (a.split_ws != nullptr) plan = attn3_plan(a.R, a.S, a.H);
+  const int qb = plan.wgs > 0 ? plan.qb : 128;
+  return (a.H / nb) * ((a.R + qb - 1) / qb) * (qb / 32);
+}
+
+static hipError_t attn3_dispatch(const mavlm_attn_args& a, int dtype, bool frames, hipStream_t s) {
   // K / V are addressed through 32-bit buffer offsets (one descriptor per head): the key block must span < 4 GiB
   // (2 GiB: the scalar offset of the tile after the last one must not wrap either)
   if ((double)a.S * a.ldk * 2.0 >= 2147483648.0 || (double)a.S * a.ldv * 2.0 >= 2147483648.0) return hipErrorInvalidValue;
+  const int nb = a.nb > 0 ? a.nb : 1;
+  if (a.H % nb != 0) return hipErrorInvalidValue;
+  if (frames && (!a.frame_scr || !a.frame_out || !mavlm_attention_frames_supported(a.R, a.S, a.H, a.frame_keys)))
+    return hipErrorInvalidValue;
   const float c = a.scale * 1.44269504088896340736f;
   int tps = 0, ns = 1;
   attn3_sk_plan plan = {};
   if (a.split_ws != nullptr) {
     plan = attn3_plan(a.R, a.S, a.H);
-    if (plan.wgs == 0) ns = mavlm_attention_splits(a.R, a.S, a.H, &tps);
+    // the split-KV form of the small grids: single videos only, and never with the frame masses (one writer per entry)
+    if (plan.wgs == 0 && nb == 1 && !frames) ns = mavlm_attention_splits(a.R, a.S, a.H, &tps);
   }
   const int skg = plan.wgs;
   int cut_units = 0;
@@ -933,10 +1042,19 @@ hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStrea
   const int units = ((a.R + 127) / 128) * a.H;
   const dim3 grid(skg > 0 ? skg : units, skg > 0 ? 1 : ns);
   const bool w8 = skg > 0 && plan.qb == 256;
-  const attn3_launch_args la = {grid, c, opart, lpart, tps, ns, cut_units, plan};
-  if (dtype == MAVLM_F16) return w8 ? attn3_launch<F16, 8>(a, la, s) : attn3_launch<F16, 4>(a, la, s);
-  return w8 ? attn3_launch<BF16, 8>(a, la, s) : attn3_launch<BF16, 4>(a, la, s);
+  const attn3_launch_args la = {grid, c, opart, lpart, tps, ns, cut_units, plan, a.H / nb,
+                                frames ? a.S / a.frame_keys + ATTN3_FR_EXTRA : 0};
+  const bool h16 = dtype == MAVLM_F16;
+  if (frames) {
+    if (h16) return w8 ? attn3_launch<F16, 8, 1>(a, la, s) : attn3_launch<F16, 4, 1>(a, la, s);
+    return w8 ? attn3_launch<BF16, 8, 1>(a, la, s) : attn3_launch<BF16, 4, 1>(a, la, s);
+  }
+  if (h16) return w8 ? attn3_launch<F16, 8, 0>(a, la, s) : attn3_launch<F16, 4, 0>(a, la, s);
+  return w8 ? attn3_launch<BF16, 8, 0>(a, la, s) : attn3_launch<BF16, 4, 0>(a, la, s);
 }
+
+hipError_t mavlm_launch_attention3_frames(const mavlm_attn_args& a, int dtype, hipStream_t s) { return attn3_dispatch(a, dtype, true, s); }
+hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStream_t s) { return attn3_dispatch(a, dtype, false, s); }
 
 // ------------------------------------------------------------------------------------------------------------
 // attn_colsum3_kernel: column sums of the normalised probabilities (frame scores, MemoryController.py:135-139).

@@ -281,6 +281,20 @@ size_t mavlm_gemm_split_ws_floats(int M, int N, int K, int epilogue, int ldc) {
 
 hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s) {
   if (g.M <= 0) return hipSuccess;
+  if (g.c_rpb > 0) {
+    // row-batched output: only the 256-column-tile kernels scatter their rows (the stacked rows of several videos fill
+    // the chip - there is no small-grid case to serve)
+    if (g.M % g.c_rpb != 0 || g.c_nb < 1 || (g.M / g.c_rpb) % g.c_nb != 0 || (g.c_bstride & 7) || g.epilogue == MAVLM_EPI_RES_F32 ||
+        !mavlm_gemm256_supported(g) || ((uintptr_t)g.C & 15) || (g.ldc & 7) || (g.lda & 7) || (g.ldw & 7))
+      return hipErrorInvalidValue;
+    const double osz = g.epilogue == MAVLM_EPI_F32 ? 4.0 : 2.0;
+    mavlm_prof_scope prof(MAVLM_K_GEMM, 2.0 * g.M * (double)g.N * g.K,
+                          2.0 * ((double)g.M * g.K + (double)g.N * g.K) + osz * g.M * (double)g.N, s);
+    const int rows = mavlm_gemm_tile_rows(g.M, g.N);
+    const long tiles = (long)((g.M + rows - 1) / rows) * (g.N / 256);
+    if (tiles > 256 && mavlm_gemm256p_supported(g)) return mavlm_launch_gemm256p(g, dtype, s);
+    return mavlm_launch_gemm256(g, dtype, s);
+  }
   if (g.splitk_ws != nullptr && g_mavlm_gemm_tile == 0) {
     // few output tiles, long contraction (e.g. the 4D -> D projections at 8 memory tokens): one workgroup per CU would
     // walk all K-tiles alone; split the contraction over blockIdx.y instead and apply bias + epilogue in the reduce

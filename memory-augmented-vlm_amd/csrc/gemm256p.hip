@@ -67,7 +67,8 @@ template <typename T, int EPI, int MT1>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __restrict__ A, int lda,
                                                           const uint16_t* __restrict__ W, int ldw,
                                                           const float* __restrict__ bias, void* __restrict__ Cout,
-                                                          int ldc, int M, int N, int K, int total_tiles) {
+                                                          int ldc, int M, int N, int K, int total_tiles, int c_rpb,
+                                                          int c_nb, long long c_bs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -248,16 +249,23 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
       if (EPI == MAVLM_EPI_GELU) return gelu_erf_fast(v);
       return v;
     };
+    // element offset of output row m; row-batched outputs: see gemm256_kernel / mavlm_gemm_args::c_rpb
+    auto crow = [&](int m) -> size_t {
+      if (c_rpb <= 0) return (size_t)m * ldc;
+      const int q = m / c_rpb, r = m - q * c_rpb;
+      return (size_t)(q % c_nb) * (size_t)c_bs + ((size_t)(q / c_nb) * c_rpb + r) * ldc;
+    };
 #pragma unroll
     for (int i = 0; i < 4 + MT1; ++i) {
       const int m = m0c + wm * MHALF + i * 16 + fr;
+      const size_t co = crow(m < M ? m : M - 1);
       if (EPI == MAVLM_EPI_F32) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int n = n0c + wn * 64 + j * 16 + fq * 4;
           const f32x4 o = acc[i][j] + bv[j];
           acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (m < M) *(f32x4*)((float*)Cout + (size_t)m * ldc + n) = o;
+          if (m < M) *(f32x4*)((float*)Cout + co + n) = o;
         }
       } else {
 #pragma unroll
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
           const u32x4 w = widen_pair(pack4<T>(act(x[0]), act(x[1]), act(x[2]), act(x[3])),
                                      pack4<T>(act(y[0]), act(y[1]), act(y[2]), act(y[3])));
           const int n = n0c + wn * 64 + 16 * (j + (fq & 1)) + 8 * (fq >> 1);
-          if (m < M) *(u32x4*)((uint16_t*)Cout + (size_t)m * ldc + n) = w;
+          if (m < M) *(u32x4*)((uint16_t*)Cout + co + n) = w;
         }
       }
     }
@@ -310,7 +318,7 @@ hipError_t launch256ph(const mavlm_gemm_args& g, hipStream_t s) {
   const int tiles = ((g.M + BMT - 1) / BMT) * (g.N / BN2);
   const int grid = tiles < cus ? tiles : cus;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), GEMM256P_LDS, s, (const uint16_t*)g.A, g.lda, (const uint16_t*)g.W,
-                     g.ldw, g.bias, g.C, g.ldc, g.M, g.N, g.K, tiles);
+                     g.ldw, g.bias, g.C, g.ldc, g.M, g.N, g.K, tiles, g.c_rpb, g.c_nb > 0 ? g.c_nb : 1, (long long)g.c_bstride);
   return hipGetLastError();
 }
 

@@ -17,6 +17,7 @@ struct mavlm_ctx {
   // workspace carve (byte offsets)
   size_t o_kv, o_q, o_ctx, o_a, o_h, o_pre, o_mA, o_mB, o_lse, o_part, o_split, o_gsplit, gsplit_floats, total;
   size_t o_fscr = 0, o_fout = 0;   // frame-score variant of the last layer's forward (0 = not available for this config)
+  size_t split_floats = 0;         // floats carved at o_split (attention partials: split-KV / stream-K)
   int fuse_mems = 1;   // cached memories the Memory-Fuser MLP takes per GEMM launch (mavlm_fuse_emit)
 };
 
@@ -30,14 +31,17 @@ bool cfg_ok(const mavlm_config* c) {
       c->depth > MAVLM_MAX_DEPTH || c->inter <= 0 || c->cache_cap <= 0 || c->max_chunk_frames <= 0)
     return false;
   if (c->dtype != 0 && c->dtype != 1) return false;
+  if (c->batch < 0 || c->batch > MAVLM_MAX_BATCH) return false;
   return true;
 }
+inline int nbatch(const mavlm_config& c) { return c.batch > 1 ? c.batch : 1; }
 
 // shapes the gfx950 kernels implement (DESIGN.md "Supported shapes"): head_dim <= 128 (heads are zero-padded to
 // 128 columns in the Q/K/V/ctx buffers and in the packed weights), D and I multiples of 128
 bool shape_ok(const mavlm_config* c) {
   if (c->hidden % 128 != 0 || c->hidden % c->heads != 0 || c->inter % 128 != 0) return false;
   const int hd = c->hidden / c->heads;
+  if (c->batch > 1 && hd > 128) return false;       // the row batch rides on the head_dim <= 128 kernels (attention3.hip)
   return hd <= 128 || hd == 448;      // 448: wide-head kernels (attention_hd.hip), no padding
 }
 inline bool wide_heads(const mavlm_config& c) { return c.hidden / c.heads > 128; }
@@ -47,9 +51,9 @@ inline float attn_scale(const mavlm_config& c) { return 1.0f / sqrtf((float)(c.h
 // Memory-Fuser batching: the fuser MLP is row-independent, and the FIFO ring is one contiguous [cap, R, D] buffer, so
 // cached memories that sit in consecutive slots go through ONE pair of GEMMs.  At the reference's 8 memory tokens
 // (R = 1568) a launch per memory fills 7 of 256 CUs' worth of 256-row tiles; up to FUSE_ROWS rows per launch fill the chip.
-constexpr int FUSE_ROWS = 16384;
+constexpr int FUSE_ROWS = 32768;
 inline int fuse_mems_per_launch(const mavlm_config& c) {
-  const int R = c.mem_tokens * c.patches;
+  const int R = c.mem_tokens * c.patches * nbatch(c);       // rows of one FIFO slot (all videos of the row batch)
   int k = FUSE_ROWS / R;
   if (k < 1) k = 1;
   return k > c.cache_cap ? c.cache_cap : k;
@@ -57,10 +61,13 @@ inline int fuse_mems_per_launch(const mavlm_config& c) {
 
 void carve(mavlm_ctx* x) {
   const mavlm_config& c = x->cfg;
-  const size_t R = (size_t)c.mem_tokens * c.patches, S = (size_t)c.max_chunk_frames * c.patches, D = c.hidden,
-               I = c.inter, L = c.depth, H = c.heads, Dp = (size_t)padded_width(c);
+  const size_t B = (size_t)nbatch(c);
+  const size_t R1 = (size_t)c.mem_tokens * c.patches;          // memory rows of ONE video
+  const size_t R = R1 * B;                                     // rows of every row-wise operator (all videos stacked)
+  const size_t S = (size_t)c.max_chunk_frames * c.patches, D = c.hidden, I = c.inter, L = c.depth, H = c.heads,
+               Dp = (size_t)padded_width(c);
   size_t o = 0;
-  x->o_kv = o;   o += al(S * 2 * L * Dp * 2);
+  x->o_kv = o;   o += al(B * S * 2 * L * Dp * 2);
   x->o_q = o;    o += al(R * Dp * 2);
   x->o_ctx = o;  o += al(R * Dp * 2);
   x->o_a = o;    o += al(R * D * 2);
@@ -69,30 +76,36 @@ void carve(mavlm_ctx* x) {
   x->o_pre = o;  o += al(R * D * 4);
   x->o_mA = o;   o += al(R * D * 2);
   x->o_mB = o;   o += al(R * D * 2);
-  x->o_lse = o;  o += al(H * R * 4);
+  x->o_lse = o;  o += al(B * H * R1 * 4);
   {   // column-sum planes (attention3.hip: balanced schedule): the plane count depends on the chunk's key count
     size_t fl = H * S;
     if (!wide_heads(c))
       for (int f = 1; f <= c.max_chunk_frames; ++f) {
-        const size_t v = mavlm_colsum_part_floats((int)R, f * c.patches, (int)H);
+        const size_t v = mavlm_colsum_part_floats((int)R1, f * c.patches, (int)H);
         if (v > fl) fl = v;
       }
     x->o_part = o; o += al(fl * 4);
   }
-  // split-KV partials of the attention (small grids only: mavlm_attention_splits): worst case over the key count
+  // attention partials.  Single videos: split-KV of the small grids (mavlm_attention_splits), worst case over the key
+  // count, or the levelled stream-K schedule (more units than workgroup slots; independent of the key count).  The
+  // stream-K size is the maximum over both workgroup shapes (4 / 8 waves), so that mavlm_set_attention_streamk_waves
+  // may change after the context exists; attn_block checks the carved size anyway.
   x->o_split = o;
   {
-    const size_t items = ((R + 127) / 128) * H;
-    size_t cap;
-    if (!wide_heads(c)) cap = items < 320 ? (512 / items > 8 ? 8 : 512 / items) : 0;      // mavlm_attention_splits
-    else cap = items < 200 ? (400 / items > 8 ? 8 : 400 / items) : 0;                      // mavlm_attention_hd_splits
-    size_t fl = cap >= 2 ? cap * (R * Dp + H * R) : 0;
-    // stream-K partials of the head_dim-128 forward (more units than workgroup slots): independent of the key count
+    const size_t items = ((R1 + 127) / 128) * H;
+    size_t fl = 0;
+    if (B == 1) {
+      size_t cap;
+      if (!wide_heads(c)) cap = items < 320 ? (512 / items > 8 ? 8 : 512 / items) : 0;      // mavlm_attention_splits
+      else cap = items < 200 ? (400 / items > 8 ? 8 : 400 / items) : 0;                      // mavlm_attention_hd_splits
+      fl = cap >= 2 ? cap * (R1 * Dp + H * R1) : 0;
+    }
     if (!wide_heads(c)) {
       const int s_long = 1 << 20;        // (the schedule only depends on "enough key tiles")
-      const size_t sk = mavlm_attention_split_ws_floats((int)R, s_long, (int)H);
-      if (mavlm_attention_streamk_wgs((int)R, s_long, (int)H) > 0 && sk > fl) fl = sk;
+      const size_t sk = mavlm_attention_split_ws_floats_max((int)R1, s_long, (int)(H * B));
+      if (sk > fl) fl = sk;
     }
+    x->split_floats = fl;
     if (fl) o += al(fl * 4);
   }
   // split-K planes of the GEMMs with few output tiles and a long contraction (mavlm_gemm_splits): the I -> D
@@ -111,13 +124,13 @@ void carve(mavlm_ctx* x) {
   }
   o += al(x->gsplit_floats * 4);
   // scratch of the frame-score variant of the last formation layer's forward (attention3.hip): (a, m) per (head, memory
-  // row, frame) and the per-wave partial frame sums
+  // row, frame) and the partial frame sums per (unit, 32-query group)
   x->o_fscr = x->o_fout = 0;
   {
     const int fc = c.max_chunk_frames < 64 ? c.max_chunk_frames : 64;      // chunks of more frames take the column-sum pass
-    if (!wide_heads(c) && mavlm_attention_frames_supported((int)R, fc * c.patches, (int)H, c.patches)) {
-      x->o_fscr = o; o += al(mavlm_attention_frames_scr_floats((int)R, fc * c.patches, (int)H, c.patches) * 4);
-      x->o_fout = o; o += al(mavlm_attention_frames_out_floats((int)R, fc * c.patches, (int)H, c.patches) * 4);
+    if (!wide_heads(c) && mavlm_attention_frames_supported((int)R1, fc * c.patches, (int)(H * B), c.patches)) {
+      x->o_fscr = o; o += al(mavlm_attention_frames_scr_floats((int)R1, fc * c.patches, (int)(H * B), c.patches) * 4);
+      x->o_fout = o; o += al(mavlm_attention_frames_out_floats((int)R1, fc * c.patches, (int)(H * B), c.patches) * 4);
     }
   }
   x->total = o;
@@ -150,29 +163,140 @@ inline hipError_t gemm_x(mavlm_ctx* x, hipStream_t s, const void* A, int lda, co
               x->gsplit_floats ? (float*)ws(x, x->o_gsplit) : nullptr, x->gsplit_floats);
 }
 
-// One `Attention` block given projected K/V:  out = LN(dense(attn(q_proj(xq), K, V)) + xq)
+// One `Attention` block given projected K/V:  out = LN(dense(attn(q_proj(xq), K, V)) + xq).  All videos of the row batch
+// at once: xq / out are [B R, D]; video b's S keys start kv_bs elements after video b-1's.
+// frame_rows (out): rows of the partial frame sums per video when `frames` (argument of the finish kernel)
 int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const void* xq, const void* K, int ldk,
-               const void* V, int ldv, int S, void* out, float* lse2, bool frames = false) {
+               const void* V, int ldv, long long kv_bs, int S, void* out, float* lse2, bool frames = false,
+               int* frame_rows = nullptr) {
   const mavlm_config& c = x->cfg;
-  const int R = c.mem_tokens * c.patches, D = c.hidden, H = c.heads, dt = c.dtype, Dp = padded_width(c);
+  const int B = nbatch(c), R1 = c.mem_tokens * c.patches, R = R1 * B, D = c.hidden, H = c.heads, dt = c.dtype,
+            Dp = padded_width(c);
   MAVLM_TRY(gemm_x(x, s, xq, D, aw.wq, D, aw.bq, ws(x, x->o_q), Dp, R, Dp, D, MAVLM_EPI_BIAS));
   mavlm_attn_args a;
   a.Q = ws(x, x->o_q); a.ldq = Dp; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = ws(x, x->o_ctx); a.ldo = Dp;
-  a.lse2 = lse2; a.R = R; a.S = S; a.H = H; a.scale = attn_scale(c);
-  a.split_ws = x->o_gsplit > x->o_split ? (float*)ws(x, x->o_split) : nullptr;
+  a.lse2 = lse2; a.R = R1; a.S = S; a.H = H * B; a.nb = B; a.kv_bstride = kv_bs; a.scale = attn_scale(c);
   if (wide_heads(c)) {
+    a.split_ws = x->split_floats ? (float*)ws(x, x->o_split) : nullptr;
     MAVLM_TRY(mavlm_launch_attention_hd(a, c.hidden / c.heads, dt, s));
-  } else if (frames) {                      // forward + per-frame probability mass in one pass (no column-sum pass)
-    a.frame_scr = (float*)ws(x, x->o_fscr);
-    a.frame_out = (float*)ws(x, x->o_fout);
-    a.frame_keys = c.patches;
-    MAVLM_TRY(mavlm_launch_attention3_frames(a, dt, s));
   } else {
-    MAVLM_TRY(mavlm_launch_attention(a, dt, s));
+    // the schedule is part of the result: take it only when the carved workspace covers this shape's plan under the
+    // CURRENT tuning hooks (they may have changed since mavlm_create) - never write past the carve
+    // (a row batch never takes the split-KV form of the small grids: attention3.hip)
+    const size_t need = (B == 1 || mavlm_attention_streamk_wgs(R1, S, H * B) > 0) ? mavlm_attention_split_ws_floats(R1, S, H * B) : 0;
+    if (need > x->split_floats) return MAVLM_E_STATE;
+    a.split_ws = x->split_floats ? (float*)ws(x, x->o_split) : nullptr;
+    if (frames) {                           // forward + per-frame probability mass in one pass (no column-sum pass)
+      a.frame_scr = (float*)ws(x, x->o_fscr);
+      a.frame_out = (float*)ws(x, x->o_fout);
+      a.frame_keys = c.patches;
+      if (frame_rows) *frame_rows = mavlm_attention_frames_rows_per_video(a);
+      MAVLM_TRY(mavlm_launch_attention3_frames(a, dt, s));
+    } else {
+      MAVLM_TRY(mavlm_launch_attention(a, dt, s));
+    }
   }
   // Residual: dense + bias in fp32 (GEMM epilogue), + residual and LayerNorm in the row kernel (MemoryController.py:26-29)
   MAVLM_TRY(gemm_x(x, s, ws(x, x->o_ctx), Dp, aw.wo, Dp, aw.bo, ws(x, x->o_pre), D, R, D, Dp, MAVLM_EPI_F32));
   MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), xq, D, aw.ln_g, aw.ln_b, out, R, D, c.eps, dt, s));
+  return 0;
+}
+
+// does the step take the fused frame scores for a last-layer attention over S keys?  (single videos: not the small grids
+// that split their keys - mavlm_frame_scores_fused; a row batch never splits)
+bool step_frames_fused(const mavlm_ctx* x, int S) {
+  const mavlm_config& c = x->cfg;
+  const int B = nbatch(c), R1 = c.mem_tokens * c.patches;
+  if (wide_heads(c) || x->o_fscr == 0) return false;
+  if (B == 1) return mavlm_frame_scores_fused(R1, S, c.heads, c.patches) != 0;
+  return g_mavlm_frame_score_mode == 1 && g_mavlm_attn_impl != 2 && mavlm_attention_frames_supported(R1, S, c.heads * B, c.patches);
+}
+
+int step_impl(mavlm_ctx* x, const void* const* segs, int32_t F, void* frame_scores, int32_t scores_f32, hipStream_t s) {
+  const mavlm_config& c = x->cfg;
+  const int B = nbatch(c), R1 = c.mem_tokens * c.patches, R = R1 * B, D = c.hidden, I = c.inter, L = c.depth, H = c.heads,
+            dt = c.dtype;
+  const int Dp = padded_width(c);
+  const int S = F * c.patches;
+  const size_t slot_bytes = (size_t)R * D * 2;                // one FIFO slot: the newest memory of every video, [B, R1, D]
+  const int cap = c.cache_cap;
+  const int n = x->steps < cap ? x->steps : cap;
+  // evolution K/V ring: [B][cap][R1][2 Dp] - the keys of ONE video are contiguous over its slots
+  const long long evo_bs = (long long)cap * R1 * 2 * Dp;
+
+  const void* cur = x->w.mem0;
+  if (x->steps > 0) {
+    // ---- memory evolution (MemoryController.py:89-97): q = newest memory, kv = every cached memory.
+    const int newest = (x->steps - 1) % cap;
+    const char* mem_new = (const char*)x->b.mem_ring + (size_t)newest * slot_bytes;
+    char* kv_new = (char*)x->b.evo_kv_ring + (size_t)newest * R1 * 2 * Dp * 2;
+    // K/V of a cached memory are row-independent -> project each memory once, when it becomes the newest.  Row batch: ONE
+    // GEMM over the stacked rows, block b of R1 rows lands in video b's ring
+    {
+      mavlm_gemm_args g;
+      g.A = mem_new; g.lda = D; g.W = x->w.w_kv_evo; g.ldw = D; g.bias = x->w.b_kv_evo; g.res = nullptr; g.ldr = 0;
+      g.C = kv_new; g.ldc = 2 * Dp; g.M = R; g.N = 2 * Dp; g.K = D; g.epilogue = MAVLM_EPI_BIAS;
+      if (B > 1) { g.c_rpb = R1; g.c_nb = B; g.c_bstride = evo_bs; }
+      else if (x->gsplit_floats && mavlm_gemm_split_ws_floats(R, 2 * Dp, D, MAVLM_EPI_BIAS, 2 * Dp) <= x->gsplit_floats)
+        g.splitk_ws = (float*)ws(x, x->o_gsplit);
+      MAVLM_TRY(mavlm_launch_gemm(g, dt, s));
+    }
+    const char* kv = (const char*)x->b.evo_kv_ring;
+    int rc = attn_block(x, s, x->w.evo, mem_new, kv, 2 * Dp, kv + (size_t)Dp * 2, 2 * Dp, evo_bs, n * R1, ws(x, x->o_mA), nullptr);
+    if (rc) return rc;
+    cur = ws(x, x->o_mA);
+  }
+
+  // ---- memory formation (MemoryController.py:132-133): K/V of the chunk for all L layers in one GEMM per video (the shape
+  // does not depend on the memory rows: nothing to gain from stacking, and the videos' frames stay where they are)
+  char* kvs = ws(x, x->o_kv);
+  const int ldkv = 2 * L * Dp;
+  for (int b = 0; b < B; ++b)
+    MAVLM_TRY(gemm_x(x, s, segs[b], D, x->w.w_kv_seg, D, x->w.b_kv_seg, kvs + (size_t)b * S * ldkv * 2, ldkv, S, ldkv, D,
+                     MAVLM_EPI_BIAS));
+  for (int l = 0; l < L; ++l) {
+    const bool last = l == L - 1;
+    const bool want_scores = last && frame_scores != nullptr;
+    const char* Kl = kvs + (size_t)(2 * l) * Dp * 2;
+    const char* Vl = Kl + (size_t)Dp * 2;
+    // frame scores: fused into this layer's forward (default), or the column-sum pass over its Q / K / lse2
+    const bool fused_scores = want_scores && step_frames_fused(x, S);
+    float* lse = want_scores ? (float*)ws(x, x->o_lse) : nullptr;      // (the fused form does not need it; kept for inspection)
+    int frows = 0;
+    int rc = attn_block(x, s, x->w.layer_attn[l], cur, Kl, ldkv, Vl, ldkv, (long long)S * ldkv, S, ws(x, x->o_a), lse,
+                        fused_scores, &frows);
+    if (rc) return rc;
+    if (fused_scores) {
+      MAVLM_TRY(mavlm_launch_frame_finish((const float*)ws(x, x->o_fout), frows, B, F, c.patches, frame_scores, scores_f32, dt, s));
+    } else if (want_scores) {
+      for (int b = 0; b < B; ++b) {          // (one pass per video: the column-sum kernels know nothing of the row batch)
+        mavlm_colsum_args ca;
+        ca.Q = ws(x, x->o_q) + (size_t)b * R1 * Dp * 2; ca.ldq = Dp; ca.K = Kl + (size_t)b * S * ldkv * 2; ca.ldk = ldkv;
+        ca.lse2 = lse + (size_t)b * H * R1; ca.part = (float*)ws(x, x->o_part);
+        ca.R = R1; ca.S = S; ca.H = H; ca.scale = attn_scale(c);
+        int planes = 1;
+        if (wide_heads(c)) {
+          MAVLM_TRY(mavlm_launch_colsum_hd(ca, c.hidden / c.heads, dt, s));
+        } else {
+          ca.keep_planes = 1;                   // frame_scores_kernel adds the planes (same order as the reduce kernel)
+          planes = mavlm_colsum_planes(R1, S, H);
+          MAVLM_TRY(mavlm_launch_colsum(ca, dt, s));
+        }
+        void* fs = scores_f32 ? (void*)((float*)frame_scores + (size_t)b * F) : (void*)((uint16_t*)frame_scores + (size_t)b * F);
+        MAVLM_TRY(mavlm_launch_frame_scores(ca.part, planes, H, S, F, c.patches, fs, scores_f32, dt, s));
+      }
+    }
+    // MLP: Linear(D,I)+ReLU -> Residual(I->D)  (MemoryController.py:63-67,71)
+    MAVLM_TRY(gemm_x(x, s, ws(x, x->o_a), D, x->w.w_up[l], D, x->w.b_up[l], ws(x, x->o_h), I, R, I, D, MAVLM_EPI_RELU));
+    MAVLM_TRY(gemm_x(x, s, ws(x, x->o_h), I, x->w.w_down[l], I, x->w.b_down[l], ws(x, x->o_pre), D, R, D, I,
+                     MAVLM_EPI_F32));
+    void* dst = last ? (void*)((char*)x->b.mem_ring + (size_t)(x->steps % cap) * slot_bytes)
+                     : (void*)ws(x, (l & 1) ? x->o_mA : x->o_mB);
+    MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), ws(x, x->o_a), D, x->w.ln2_g[l], x->w.ln2_b[l], dst, R, D,
+                                     c.eps, dt, s));
+    cur = dst;
+  }
+  x->steps += 1;   // append; the slot written above evicts the oldest entry once the ring is full (:152-154)
   return 0;
 }
 
@@ -313,100 +437,51 @@ int mavlm_pe_add(const void* xin, const int64_t* idx, const void* table, void* o
 int mavlm_step(mavlm_ctx* x, const void* seg, int32_t F, void* frame_scores, int32_t scores_f32, void* stream) {
   if (!x || !seg) return MAVLM_E_ARG;
   if (!x->has_w || !x->has_b) return MAVLM_E_STATE;
-  const mavlm_config& c = x->cfg;
-  if (F <= 0 || F > c.max_chunk_frames) return MAVLM_E_SHAPE;
-  hipStream_t s = (hipStream_t)stream;
-  const int R = c.mem_tokens * c.patches, D = c.hidden, I = c.inter, L = c.depth, H = c.heads, dt = c.dtype;
-  const int Dp = padded_width(c);
-  const int S = F * c.patches;
-  const size_t mem_bytes = (size_t)R * D * 2, kv_bytes = (size_t)R * 2 * Dp * 2;
-  const int cap = c.cache_cap;
-  const int n = x->steps < cap ? x->steps : cap;
-
-  const void* cur = x->w.mem0;
-  if (x->steps > 0) {
-    // ---- memory evolution (MemoryController.py:89-97): q = newest memory, kv = every cached memory.
-    const int newest = (x->steps - 1) % cap;
-    const char* mem_new = (const char*)x->b.mem_ring + (size_t)newest * mem_bytes;
-    char* kv_new = (char*)x->b.evo_kv_ring + (size_t)newest * kv_bytes;
-    // K/V of a cached memory are row-independent -> project each memory once, when it becomes the newest
-    MAVLM_TRY(gemm_x(x, s, mem_new, D, x->w.w_kv_evo, D, x->w.b_kv_evo, kv_new, 2 * Dp, R, 2 * Dp, D, MAVLM_EPI_BIAS));
-    const char* kv = (const char*)x->b.evo_kv_ring;
-    int rc = attn_block(x, s, x->w.evo, mem_new, kv, 2 * Dp, kv + (size_t)Dp * 2, 2 * Dp, n * R, ws(x, x->o_mA), nullptr);
-    if (rc) return rc;
-    cur = ws(x, x->o_mA);
-  }
-
-  // ---- memory formation (MemoryController.py:132-133): K/V of the chunk for all L layers in one GEMM
-  char* kvs = ws(x, x->o_kv);
-  const int ldkv = 2 * L * Dp;
-  MAVLM_TRY(gemm_x(x, s, seg, D, x->w.w_kv_seg, D, x->w.b_kv_seg, kvs, ldkv, S, ldkv, D, MAVLM_EPI_BIAS));
-  for (int l = 0; l < L; ++l) {
-    const bool last = l == L - 1;
-    const bool want_scores = last && frame_scores != nullptr;
-    const char* Kl = kvs + (size_t)(2 * l) * Dp * 2;
-    const char* Vl = Kl + (size_t)Dp * 2;
-    // frame scores: fused into this layer's forward (default), or the column-sum pass over its Q / K / lse2
-    const bool fused_scores = want_scores && !wide_heads(c) && x->o_fscr != 0 && mavlm_frame_scores_fused(R, S, H, c.patches);
-    float* lse = want_scores ? (float*)ws(x, x->o_lse) : nullptr;      // (the fused form does not need it; kept for inspection)
-    int rc = attn_block(x, s, x->w.layer_attn[l], cur, Kl, ldkv, Vl, ldkv, S, ws(x, x->o_a), lse, fused_scores);
-    if (rc) return rc;
-    if (fused_scores) {
-      MAVLM_TRY(mavlm_launch_frame_finish((const float*)ws(x, x->o_fout), H * ((R + 127) / 128) * 4, F, c.patches, frame_scores,
-                                          scores_f32, dt, s));
-    } else if (want_scores) {
-      mavlm_colsum_args ca;
-      ca.Q = ws(x, x->o_q); ca.ldq = Dp; ca.K = Kl; ca.ldk = ldkv; ca.lse2 = lse; ca.part = (float*)ws(x, x->o_part);
-      ca.R = R; ca.S = S; ca.H = H; ca.scale = attn_scale(c);
-      int planes = 1;
-      if (wide_heads(c)) {
-        MAVLM_TRY(mavlm_launch_colsum_hd(ca, c.hidden / c.heads, dt, s));
-      } else {
-        ca.keep_planes = 1;                   // frame_scores_kernel adds the planes (same order as the reduce kernel)
-        planes = mavlm_colsum_planes(R, S, H);
-        MAVLM_TRY(mavlm_launch_colsum(ca, dt, s));
-      }
-      MAVLM_TRY(mavlm_launch_frame_scores(ca.part, planes, H, S, F, c.patches, frame_scores, scores_f32, dt, s));
-    }
-    // MLP: Linear(D,I)+ReLU -> Residual(I->D)  (MemoryController.py:63-67,71)
-    MAVLM_TRY(gemm_x(x, s, ws(x, x->o_a), D, x->w.w_up[l], D, x->w.b_up[l], ws(x, x->o_h), I, R, I, D, MAVLM_EPI_RELU));
-    MAVLM_TRY(gemm_x(x, s, ws(x, x->o_h), I, x->w.w_down[l], I, x->w.b_down[l], ws(x, x->o_pre), D, R, D, I,
-                     MAVLM_EPI_F32));
-    void* dst = last ? (void*)((char*)x->b.mem_ring + (size_t)(x->steps % cap) * mem_bytes)
-                     : (void*)ws(x, (l & 1) ? x->o_mA : x->o_mB);
-    MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), ws(x, x->o_a), D, x->w.ln2_g[l], x->w.ln2_b[l], dst, R, D,
-                                     c.eps, dt, s));
-    cur = dst;
-  }
-  x->steps += 1;   // append; the slot written above evicts the oldest entry once the ring is full (:152-154)
-  return 0;
+  if (nbatch(x->cfg) != 1) return MAVLM_E_STATE;             // a row-batched context steps through mavlm_step_batch
+  if (F <= 0 || F > x->cfg.max_chunk_frames) return MAVLM_E_SHAPE;
+  return step_impl(x, &seg, F, frame_scores, scores_f32, (hipStream_t)stream);
 }
 
-int mavlm_fuse_emit(mavlm_ctx* x, const void* x_pe, const int64_t* fine_idx, int32_t n_fine, const void* mem_prompt,
-                    int32_t n_mem_prompt, const void* frame_prompt, int32_t n_frame_prompt, const void* newline,
-                    int32_t with_frames, void* out, int64_t cap_rows, int64_t* rows, void* stream) {
-  if (!x || !out || !newline || !rows) return MAVLM_E_ARG;
+int mavlm_step_batch(mavlm_ctx* x, const void* const* segs, int32_t F, void* frame_scores, int32_t scores_f32, void* stream) {
+  if (!x || !segs) return MAVLM_E_ARG;
   if (!x->has_w || !x->has_b) return MAVLM_E_STATE;
+  if (F <= 0 || F > x->cfg.max_chunk_frames) return MAVLM_E_SHAPE;
+  for (int b = 0; b < nbatch(x->cfg); ++b)
+    if (!segs[b]) return MAVLM_E_ARG;
+  return step_impl(x, segs, F, frame_scores, scores_f32, (hipStream_t)stream);
+}
+
+int mavlm_batch(const mavlm_ctx* x) { return x ? nbatch(x->cfg) : MAVLM_E_ARG; }
+
+namespace {
+int fuse_emit_impl(mavlm_ctx* x, const void* const* x_pe, const int64_t* fine_idx, int32_t n_fine, const void* mem_prompt,
+                   int32_t n_mem_prompt, const void* frame_prompt, int32_t n_frame_prompt, const void* newline,
+                   int32_t with_frames, void* out, int64_t cap_rows, int64_t* rows, hipStream_t s) {
   if (!x->w.w_f1 || !x->w.b_f1 || !x->w.w_f2 || !x->w.b_f2_type0 || (with_frames && !x->w.type1)) return MAVLM_E_STATE;
   if (n_mem_prompt < 0 || n_frame_prompt < 0 || n_fine < 0 || (n_mem_prompt && !mem_prompt) ||
       (with_frames && ((n_frame_prompt && !frame_prompt) || (n_fine && (!x_pe || !fine_idx)))))
     return MAVLM_E_ARG;
   const mavlm_config& c = x->cfg;
-  hipStream_t s = (hipStream_t)stream;
-  const int R = c.mem_tokens * c.patches, D = c.hidden, I = c.inter, dt = c.dtype, cap = c.cache_cap;
+  const int B = nbatch(c), R1 = c.mem_tokens * c.patches, R = R1 * B, D = c.hidden, I = c.inter, dt = c.dtype, cap = c.cache_cap;
   const int n = x->steps < cap ? x->steps : cap;
   if (n == 0) return MAVLM_E_STATE;
-  int64_t need = (int64_t)n_mem_prompt + (int64_t)n * R + 1;
+  int64_t need = (int64_t)n_mem_prompt + (int64_t)n * R1 + 1;
   if (with_frames) need += (int64_t)n_frame_prompt + (int64_t)n_fine * c.patches + 1;
   if (cap_rows < need) return MAVLM_E_ARG;
+  if (with_frames && n_fine)
+    for (int b = 0; b < B; ++b)
+      if (!x_pe[b]) return MAVLM_E_ARG;
   const size_t rowb = (size_t)D * 2;
+  const size_t vstride = (size_t)cap_rows * rowb;             // video b's token block starts b * cap_rows rows into `out`
   char* o = (char*)out;
   int64_t row = 0;
-  if (n_mem_prompt) MAVLM_TRY(hipMemcpyAsync(o, mem_prompt, rowb * n_mem_prompt, hipMemcpyDeviceToDevice, s));
+  for (int b = 0; b < B && n_mem_prompt; ++b)
+    MAVLM_TRY(hipMemcpyAsync(o + b * vstride, mem_prompt, rowb * n_mem_prompt, hipMemcpyDeviceToDevice, s));
   row += n_mem_prompt;
   const int oldest = x->steps <= cap ? 0 : x->steps % cap;
   // torch.cat(memory_cache) order = oldest first (llava_arch.py:545) = ring slots oldest..cap-1, then 0..oldest-1: at most
-  // two contiguous slot ranges, each fused in batches of up to fuse_mems memories per GEMM pair (llava_arch.py:546)
+  // two contiguous slot ranges, each fused in batches of up to fuse_mems memories per GEMM pair (llava_arch.py:546).  A
+  // slot holds the memories of all B videos ([B, R1, D]): the second GEMM writes block b of a slot into video b's tokens.
   for (int done = 0; done < n;) {
     const int slot = (oldest + done) % cap;
     int run = n - done < cap - slot ? n - done : cap - slot;
@@ -414,24 +489,56 @@ int mavlm_fuse_emit(mavlm_ctx* x, const void* x_pe, const int64_t* fine_idx, int
     const int rows_ = run * R;
     const char* mem = (const char*)x->b.mem_ring + (size_t)slot * R * rowb;
     MAVLM_TRY(gemm_x(x, s, mem, D, x->w.w_f1, D, x->w.b_f1, ws(x, x->o_h), I, rows_, I, D, MAVLM_EPI_GELU));
-    MAVLM_TRY(gemm_x(x, s, ws(x, x->o_h), I, x->w.w_f2, I, x->w.b_f2_type0, o + (size_t)row * rowb, D, rows_, D, I,
-                     MAVLM_EPI_BIAS));
-    row += rows_;
+    if (B == 1) {
+      MAVLM_TRY(gemm_x(x, s, ws(x, x->o_h), I, x->w.w_f2, I, x->w.b_f2_type0, o + (size_t)row * rowb, D, rows_, D, I,
+                       MAVLM_EPI_BIAS));
+    } else {
+      mavlm_gemm_args g;
+      g.A = ws(x, x->o_h); g.lda = I; g.W = x->w.w_f2; g.ldw = I; g.bias = x->w.b_f2_type0; g.res = nullptr; g.ldr = 0;
+      g.C = o + (size_t)row * rowb; g.ldc = D; g.M = rows_; g.N = D; g.K = I; g.epilogue = MAVLM_EPI_BIAS;
+      g.c_rpb = R1; g.c_nb = B; g.c_bstride = (long long)cap_rows * D;
+      MAVLM_TRY(mavlm_launch_gemm(g, dt, s));
+    }
+    row += (int64_t)run * R1;
     done += run;
   }
-  MAVLM_TRY(hipMemcpyAsync(o + (size_t)row * rowb, newline, rowb, hipMemcpyDeviceToDevice, s));
+  for (int b = 0; b < B; ++b)
+    MAVLM_TRY(hipMemcpyAsync(o + b * vstride + (size_t)row * rowb, newline, rowb, hipMemcpyDeviceToDevice, s));
   row += 1;
   if (with_frames) {
-    if (n_frame_prompt)
-      MAVLM_TRY(hipMemcpyAsync(o + (size_t)row * rowb, frame_prompt, rowb * n_frame_prompt, hipMemcpyDeviceToDevice, s));
+    for (int b = 0; b < B && n_frame_prompt; ++b)
+      MAVLM_TRY(hipMemcpyAsync(o + b * vstride + (size_t)row * rowb, frame_prompt, rowb * n_frame_prompt, hipMemcpyDeviceToDevice, s));
     row += n_frame_prompt;
-    MAVLM_TRY(mavlm_launch_row_add(x_pe, fine_idx, x->w.type1, nullptr, o + (size_t)row * rowb, n_fine, c.patches, D, dt, s));
+    for (int b = 0; b < B && n_fine; ++b)
+      MAVLM_TRY(mavlm_launch_row_add(x_pe[b], fine_idx, x->w.type1, nullptr, o + b * vstride + (size_t)row * rowb, n_fine,
+                                     c.patches, D, dt, s));
     row += (int64_t)n_fine * c.patches;
-    MAVLM_TRY(hipMemcpyAsync(o + (size_t)row * rowb, newline, rowb, hipMemcpyDeviceToDevice, s));
+    for (int b = 0; b < B; ++b)
+      MAVLM_TRY(hipMemcpyAsync(o + b * vstride + (size_t)row * rowb, newline, rowb, hipMemcpyDeviceToDevice, s));
     row += 1;
   }
   *rows = row;
   return 0;
+}
+}  // namespace
+
+int mavlm_fuse_emit(mavlm_ctx* x, const void* x_pe, const int64_t* fine_idx, int32_t n_fine, const void* mem_prompt,
+                    int32_t n_mem_prompt, const void* frame_prompt, int32_t n_frame_prompt, const void* newline,
+                    int32_t with_frames, void* out, int64_t cap_rows, int64_t* rows, void* stream) {
+  if (!x || !out || !newline || !rows) return MAVLM_E_ARG;
+  if (!x->has_w || !x->has_b) return MAVLM_E_STATE;
+  if (nbatch(x->cfg) != 1) return MAVLM_E_STATE;
+  return fuse_emit_impl(x, x_pe ? &x_pe : nullptr, fine_idx, n_fine, mem_prompt, n_mem_prompt, frame_prompt, n_frame_prompt, newline,
+                        with_frames, out, cap_rows, rows, (hipStream_t)stream);
+}
+
+int mavlm_fuse_emit_batch(mavlm_ctx* x, const void* const* x_pe, const int64_t* fine_idx, int32_t n_fine, const void* mem_prompt,
+                          int32_t n_mem_prompt, const void* frame_prompt, int32_t n_frame_prompt, const void* newline,
+                          int32_t with_frames, void* out, int64_t rows_per_video, int64_t* rows, void* stream) {
+  if (!x || !out || !newline || !rows) return MAVLM_E_ARG;
+  if (!x->has_w || !x->has_b) return MAVLM_E_STATE;
+  return fuse_emit_impl(x, x_pe, fine_idx, n_fine, mem_prompt, n_mem_prompt, frame_prompt, n_frame_prompt, newline, with_frames,
+                        out, rows_per_video, rows, (hipStream_t)stream);
 }
 
 int mavlm_linear(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const void* res, int32_t ldr,
@@ -469,7 +576,9 @@ int mavlm_attention(const void* Q, int32_t ldq, const void* K, int32_t ldk, cons
 
 int64_t mavlm_attention_frames_ws_floats(int32_t R, int32_t S, int32_t H, int32_t patches) {
   if (R <= 0 || H <= 0 || !mavlm_attention_frames_supported(R, S, H, patches)) return 0;
-  return (int64_t)(mavlm_attention_frames_scr_floats(R, S, H, patches) + mavlm_attention_frames_out_floats(R, S, H, patches));
+  // [entries | partial frame sums | partials of the stream-K schedule, when this shape runs it]
+  const size_t sk = mavlm_attention_streamk_wgs(R, S, H) > 0 ? mavlm_attention_split_ws_floats(R, S, H) : 0;
+  return (int64_t)(mavlm_attention_frames_scr_floats(R, S, H, patches) + mavlm_attention_frames_out_floats(R, S, H, patches) + sk);
 }
 
 int mavlm_attention_frames(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
@@ -483,10 +592,12 @@ int mavlm_attention_frames(const void* Q, int32_t ldq, const void* K, int32_t ld
   a.frame_scr = ws_;
   a.frame_out = ws_ + mavlm_attention_frames_scr_floats(R, S, H, patches);
   a.frame_keys = patches;
+  if (mavlm_attention_streamk_wgs(R, S, H) > 0)
+    a.split_ws = a.frame_out + mavlm_attention_frames_out_floats(R, S, H, patches);
+  const int frows = mavlm_attention_frames_rows_per_video(a);
   hipError_t e = mavlm_launch_attention3_frames(a, dtype, (hipStream_t)stream);
   if (e == hipSuccess)
-    e = mavlm_launch_frame_finish(a.frame_out, H * ((R + 127) / 128) * 4, S / patches, patches, frame_scores, 1, dtype,
-                                  (hipStream_t)stream);
+    e = mavlm_launch_frame_finish(a.frame_out, frows, 1, S / patches, patches, frame_scores, 1, dtype, (hipStream_t)stream);
   return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
 }
 
@@ -572,7 +683,8 @@ int mavlm_attention_colsum_plan(int32_t R, int32_t S, int32_t H, int32_t info[2]
 }
 
 int mavlm_attention_colsum(const void* Q, int32_t ldq, const void* K, int32_t ldk, const float* lse2, float* part,
-                           int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream) {
+                           int64_t part_floats, int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream) {
+  if (R <= 0 || S <= 0 || H <= 0 || !part || part_floats < (int64_t)mavlm_colsum_part_floats(R, S, H)) return MAVLM_E_ARG;
   mavlm_colsum_args a;
   a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.lse2 = lse2; a.part = part; a.R = R; a.S = S; a.H = H; a.scale = scale;
   hipError_t e = mavlm_launch_colsum(a, dtype, (hipStream_t)stream);

@@ -7,16 +7,19 @@
 // One-time kernel attributes (hipFuncAttributeMaxDynamicSharedMemorySize) are per DEVICE, not per process: a process
 // that drives a second GPU must set them there as well, or its 64-128 KiB-LDS kernels fail to launch on that device.
 struct mavlm_per_device_once {
-  unsigned long long seen[4] = {0, 0, 0, 0};           // one bit per device ordinal (256 ordinals)
+  // one bit per device ordinal (256 ordinals).  Atomic: a host may drive the library from several threads (one per device
+  // or per stream); setting the attribute twice is harmless, a torn read-modify-write of the mask is not.
+  unsigned long long seen[4] = {0, 0, 0, 0};
   // returns hipSuccess once `bytes` of dynamic LDS are allowed for `fn` on the CURRENT device
   hipError_t dyn_lds(const void* fn, int bytes) {
     int d = 0;
     hipError_t e = hipGetDevice(&d);
     if (e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (d & 63);
-    if (seen[(d >> 6) & 3] & bit) return hipSuccess;
+    unsigned long long* word = &seen[(d >> 6) & 3];
+    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) seen[(d >> 6) & 3] |= bit;
+    if (e == hipSuccess) __atomic_fetch_or(word, bit, __ATOMIC_RELEASE);
     return e;
   }
 };

@@ -15,6 +15,12 @@ struct mavlm_gemm_args {
   int M, N, K;
   int epilogue;
   float* splitk_ws = nullptr;    // mavlm_gemm_split_ws_floats(M,N,K) floats, or null = never split the contraction
+  // Row-batched output (256-column-tile kernels only; 0 = plain [M, ldc] output): the M rows are blocks of c_rpb rows; block
+  // q goes to batch element b = q % c_nb as its (q / c_nb)-th block, i.e. row m lands at
+  // C + b * c_bstride + ((q / c_nb) * c_rpb + m % c_rpb) * ldc (elements).  Used where the stacked rows of several videos
+  // (mavlm_config::batch) are written to per-video buffers: the evolution K/V ring, the fused-token blocks.
+  int c_rpb = 0, c_nb = 1;
+  long long c_bstride = 0;
 };
 hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s);
 // split-K plan for GEMMs with few output tiles and a long contraction (small M, K >= 2048): 1 = none.  Pure function of
@@ -48,6 +54,11 @@ struct mavlm_attn_args {
   float* frame_scr = nullptr;    // mavlm_attention_frames_scr_floats(...) floats of scratch
   float* frame_out = nullptr;    // mavlm_attention_frames_out_floats(...) floats: per-wave partial frame sums
   int frame_keys = 0;
+  // row batch (attention3.hip): the launch serves nb independent videos.  H counts ALL heads (nb x heads per video); Q / O
+  // hold the nb x R query rows of the videos one after the other, video b's keys start kv_bstride elements after video
+  // b-1's (K and V alike); lse2 is [H, R].  nb = 1: a single video.
+  int nb = 1;
+  long long kv_bstride = 0;
 };
 hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream_t s);
 // forward + per-frame probability mass in one pass (attention3.hip; head_dim 128, frame_keys % 4 == 0, <= 64 frames)
@@ -55,8 +66,10 @@ bool mavlm_attention_frames_supported(int R, int S, int H, int frame_keys);
 size_t mavlm_attention_frames_scr_floats(int R, int S, int H, int frame_keys);
 size_t mavlm_attention_frames_out_floats(int R, int S, int H, int frame_keys);
 hipError_t mavlm_launch_attention3_frames(const mavlm_attn_args& a, int dtype, hipStream_t s);
-hipError_t mavlm_launch_frame_finish(const float* fout, int rows, int F, int P, void* out, int out_f32, int dtype,
+// scores[b][f] = (1 / P) sum of video b's `rows` partial frame sums (mavlm_attention_frames_rows_per_video)
+hipError_t mavlm_launch_frame_finish(const float* fout, int rows, int nb, int F, int P, void* out, int out_f32, int dtype,
                                      hipStream_t s);
+int mavlm_attention_frames_rows_per_video(const mavlm_attn_args& a);
 extern int g_mavlm_frame_score_mode;   // 1 (default) = fused into the last layer's forward, 0 = column-sum pass
 // split-KV plan for grids too small to fill the chip (attention3.hip): number of key splits (1 = none)
 int mavlm_attention_splits(int R, int S, int H, int* tiles_per_split);
@@ -64,6 +77,7 @@ int mavlm_attention_splits(int R, int S, int H, int* tiles_per_split);
 int mavlm_attention_streamk_wgs(int R, int S, int H);
 void mavlm_attention_plan_info(int R, int S, int H, int info[4]);
 size_t mavlm_attention_split_ws_floats(int R, int S, int H);
+size_t mavlm_attention_split_ws_floats_max(int R, int S, int H);   // ... over both stream-K workgroup shapes (4 / 8 waves)
 // the same for the wide-head kernel (attention_hd.hip) and the merge kernel both use (attention3.hip)
 int mavlm_attention_hd_splits(int R, int S, int H, int* tiles_per_split);
 size_t mavlm_attention_hd_split_ws_floats(int R, int S, int H, int head_dim);

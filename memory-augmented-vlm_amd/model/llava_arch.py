@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from .. import _capi as capi
 from .. import _ops as ops
-from .memory_module.MemoryController import Config, TransformerProjector
+from .memory_module.MemoryController import BatchedProjector, Config, TransformerProjector
 from .memory_module.position_encoding import TemporalPositionalEncoding
 from .memory_module.segment import uniform_segment_variant
 
@@ -188,6 +188,60 @@ def video_memory_tokens(model, image: torch.Tensor, frame_idx_cpu: torch.Tensor,
     return out, info
 
 
+@torch.no_grad()
+def video_memory_tokens_batched(model, bp: BatchedProjector, images, frame_idx_cpu: torch.Tensor,
+                                memory_prompt_embeds: torch.Tensor, frame_prompt_embeds: torch.Tensor,
+                                image_newline: torch.Tensor, with_frames: bool = True, chunk: int = 32,
+                                fine_frames: int = 32, out: Optional[torch.Tensor] = None):
+    """`video_memory_tokens` for B videos of the SAME length stepped together (row batch, `BatchedProjector`): every
+    weight-shared GEMM / LayerNorm of the path runs once over the stacked memory rows of all videos.  `images`: B tensors
+    [T,196,D]; `frame_idx_cpu`: the original frame indices (shared: same length, same sampling).  Returns
+    (tokens [B, rows, D] - video b's block is tokens[b] -, info).  Inference only."""
+    B = bp.batch
+    if len(images) != B:
+        raise capi.MavlmError(f"video_memory_tokens_batched: {B} videos expected")
+    T, P, D = images[0].shape
+    for im in images:
+        if not im.is_cuda or tuple(im.shape) != (T, P, D) or im.dtype != images[0].dtype:
+            raise capi.MavlmError("video_memory_tokens_batched: GPU frame tokens of one shape / dtype expected")
+    pe: TemporalPositionalEncoding = model.positional_encoding
+    rm: TransformerProjector = model.recurrent_memory_transformer
+    dev, dt = images[0].device, images[0].dtype
+    pe.check_indices(frame_idx_cpu)
+    idx_dev = _device_indices(frame_idx_cpu, dev)
+    xs = [pe(im, idx_dev, indices_checked=True) for im in images]                           # :510-511
+    fine_cpu = fine_frame_indices(T, fine_frames)                                          # :513-522
+    bounds = uniform_segment_variant(T, chunk)                                             # :528
+    bp.reset()                                                                             # :532
+    for i in range(len(bounds) - 1):                                                       # :534-537
+        bp.step([x[bounds[i]:bounds[i + 1]] for x in xs])
+    eng = bp.engine(dev, dt)
+    n = min(len(bounds) - 1, eng.c.cache_cap)
+    R = rm.num_memory_tokens * P
+    n_fine = fine_cpu.numel()
+    rows = memory_prompt_embeds.shape[0] + n * R + 1
+    if with_frames:
+        rows += frame_prompt_embeds.shape[0] + n_fine * P + 1
+    if out is None:
+        out = torch.empty((B, rows, D), device=dev, dtype=dt)
+    elif tuple(out.shape) != (B, rows, D) or out.dtype != dt or not out.is_contiguous() or not out.is_cuda:
+        raise capi.MavlmError(f"video_memory_tokens_batched: `out` must be a contiguous [{B},{rows},{D}] {dt} GPU tensor")
+    mp = memory_prompt_embeds.to(dt).contiguous()
+    fp = frame_prompt_embeds.to(dt).contiguous()
+    nl = image_newline.to(device=dev, dtype=dt).contiguous()
+    import ctypes
+    written = ctypes.c_int64(0)
+    xptrs = (capi.vp * B)(*[x.data_ptr() for x in xs])
+    capi.check(capi.lib().mavlm_fuse_emit_batch(eng.ctx, xptrs, _device_indices(fine_cpu, dev).data_ptr(), n_fine,
+                                                mp.data_ptr(), mp.shape[0], fp.data_ptr(), fp.shape[0], nl.data_ptr(),
+                                                1 if with_frames else 0, out.data_ptr(), rows, ctypes.byref(written),
+                                                ops.stream_ptr()), "mavlm_fuse_emit_batch")
+    assert written.value == rows
+    info = {"num_memories": n, "pe_frames": xs, "fine_idx": fine_cpu, "memory_rows": (mp.shape[0], mp.shape[0] + n * R),
+            "frame_scores": bp.frame_scores}
+    return out, info
+
+
 def _tail_wants_grad(model, *tensors) -> bool:
     """Can anything AFTER the recurrent steps receive a gradient?  (`memory_fuser`, `token_type_embedding`, and the
     tensors the caller hands in: prompt embeddings of a trainable `embed_tokens`, `image_newline`.)"""
@@ -255,11 +309,19 @@ class MemoryPathPool:
 
     usage:  pool = MemoryPathPool(model, 2)
             outs = pool.run([(frames0, idx0), (frames1, idx1), ...], mem_prompt, frame_prompt, newline)
+
+    `batch` > 1 (round 3): each stream steps `batch` videos TOGETHER as a row batch (`BatchedProjector`: the memory rows of
+    the videos stacked into every weight-shared GEMM / LayerNorm launch) instead of one.  Consecutive videos of equal length
+    and equal frame indices form a batch; whatever does not fill one runs through the single-video slots.  At the
+    reference's 8 memory tokens this is what fills the chip (1568-row operands otherwise).
     """
 
-    def __init__(self, model, n: int = 2):
+    def __init__(self, model, n: int = 2, batch: int = 1):
         rm = model.recurrent_memory_transformer
+        self.model = model
         self.slots = [model] + [_ReplicaView(model, rm.spawn_replica()) for _ in range(n - 1)]
+        self.batch = int(batch)
+        self.bslots = [BatchedProjector(rm, self.batch) for _ in range(n)] if self.batch > 1 else []
         self.streams = None
 
     @torch.no_grad()           # inference feature: the replicas' FIFOs are ring views, not autograd tensors
@@ -270,8 +332,30 @@ class MemoryPathPool:
         for st in self.streams:
             st.wait_stream(cur)
         outs = [None] * len(videos)
-        for i, (frames, idx_cpu) in enumerate(videos):
-            k = i % len(self.slots)
+        singles = list(range(len(videos)))
+        if self.batch > 1:
+            # groups of `batch` consecutive videos with the same shape and frame indices step together
+            singles, i, g = [], 0, 0
+            while i < len(videos):
+                grp = videos[i:i + self.batch]
+                same = len(grp) == self.batch and all(v[0].shape == grp[0][0].shape and torch.equal(v[1], grp[0][1])
+                                                      for v in grp[1:])
+                if not same:
+                    singles.append(i)
+                    i += 1
+                    continue
+                k = g % len(self.bslots)
+                with torch.cuda.stream(self.streams[k]):
+                    toks = video_memory_tokens_batched(self.model, self.bslots[k], [v[0] for v in grp], grp[0][1],
+                                                       memory_prompt_embeds, frame_prompt_embeds, image_newline, with_frames)[0]
+                    for j, v in enumerate(grp):
+                        outs[i + j] = toks[j]
+                        v[0].record_stream(self.streams[k])
+                i += self.batch
+                g += 1
+        for j, i in enumerate(singles):
+            frames, idx_cpu = videos[i]
+            k = j % len(self.slots)
             with torch.cuda.stream(self.streams[k]):
                 outs[i] = video_memory_tokens(self.slots[k], frames, idx_cpu, memory_prompt_embeds, frame_prompt_embeds,
                                               image_newline, with_frames)[0]

@@ -154,13 +154,14 @@ class TransformerLayer(nn.Module):
 class _Engine:
     """Owns the C handle, the packed parameter views and the device buffers of one TransformerProjector."""
 
-    def __init__(self, proj: "TransformerProjector", device, dtype, max_chunk_frames):
+    def __init__(self, proj: "TransformerProjector", device, dtype, max_chunk_frames, batch: int = 1):
         cfg = proj.config
         self.device, self.dtype = device, dtype
+        self.batch = int(batch)
         self.c = capi.Config(hidden=cfg.mm_hidden_size, heads=cfg.mm_num_attention_heads, patches=cfg.patch_size,
                              mem_tokens=cfg.num_memory_tokens, depth=cfg.depth, inter=cfg.mm_intermediate_size,
                              cache_cap=getattr(cfg, "cache_cap", 10), max_chunk_frames=max_chunk_frames,
-                             dtype=ops.dtype_code(dtype), eps=cfg.mm_layer_norm_eps)
+                             dtype=ops.dtype_code(dtype), eps=cfg.mm_layer_norm_eps, batch=self.batch)
         lib = capi.lib()
         h = capi.vp()
         capi.check(lib.mavlm_create(self.c, h), "mavlm_create")
@@ -169,8 +170,14 @@ class _Engine:
         self.head_dim = D // self.c.heads
         # attention buffer width: heads zero-padded to 128 columns, or native for the wide-head kernel (448, OV-7B)
         self.Dp = D if self.head_dim > 128 else self.c.heads * 128
-        self.mem_ring = torch.empty((self.c.cache_cap, self.c.mem_tokens, self.c.patches, D), device=device, dtype=dtype)
-        self.evo_kv = torch.empty((self.c.cache_cap, R, 2 * self.Dp), device=device, dtype=dtype)
+        # row batch (batch > 1): a FIFO slot holds the memory of every video ([cap, B, M, P, D] - one contiguous GEMM
+        # operand per slot), the evolution K/V of ONE video are contiguous over its slots ([B, cap, R, 2Dp]); include/mavlm.h
+        if self.batch > 1:
+            self.mem_ring = torch.empty((self.c.cache_cap, self.batch, self.c.mem_tokens, self.c.patches, D), device=device, dtype=dtype)
+            self.evo_kv = torch.empty((self.batch, self.c.cache_cap, R, 2 * self.Dp), device=device, dtype=dtype)
+        else:
+            self.mem_ring = torch.empty((self.c.cache_cap, self.c.mem_tokens, self.c.patches, D), device=device, dtype=dtype)
+            self.evo_kv = torch.empty((self.c.cache_cap, R, 2 * self.Dp), device=device, dtype=dtype)
         nbytes = lib.mavlm_workspace_bytes(self.c)
         self.workspace = torch.empty(nbytes + 256, device=device, dtype=torch.uint8)
         base = (self.workspace.data_ptr() + 255) & ~255
@@ -230,7 +237,8 @@ class _Engine:
         W = capi.Weights()
         R, D = self.c.mem_tokens * self.c.patches, self.c.hidden
         # initial_memory + memory_pos_embed in the parameter dtype, then cast (MemoryController.py:123-124)
-        W.mem0 = w16("mem0", (proj.initial_memory + proj.memory_pos_embed).reshape(R, D))
+        mem0 = (proj.initial_memory + proj.memory_pos_embed).reshape(R, D)
+        W.mem0 = w16("mem0", mem0.repeat(self.batch, 1) if self.batch > 1 else mem0)     # [B*R, D]: every video starts from it
         ats = [l.memory_segment_fusion_attention for l in proj.layers]
         W.w_kv_seg = w16("wkv", torch.cat([pad_out(t) for a in ats for t in (a.k_proj.weight, a.v_proj.weight)], dim=0))
         W.b_kv_seg = f32("bkv", torch.cat([pad_out(t) for a in ats for t in (a.k_proj.bias, a.v_proj.bias)], dim=0))
@@ -513,3 +521,81 @@ class TransformerProjector(nn.Module):
                                             scale=ops.attn_scale(att.attention_head_size))
                 self.frame_attn_scores.append(part.sum(dim=0).view(F, P).mean(dim=1).to(dt))
         return self._memory_cache, self.frame_attn_scores
+
+
+class BatchedProjector:
+    """B independent videos stepped TOGETHER over the parameters of one `TransformerProjector` (row batch).
+
+    The reference runs one video per forward (llava_arch.py:436) and every Linear / LayerNorm of the path sees the
+    R = M*196 memory rows of that one video.  Those operators are row-independent and the weights are shared, so the rows
+    of B videos stack into ONE [B*R, D] operand per launch (`mavlm_config.batch`): at the reference's M = 8 that turns
+    1568-row GEMMs (7 of 256 CUs' worth of tiles) into chip-filling ones; the attention serves B*heads (video, head)
+    pairs, each video over its own keys.  Videos of a batch step with the same chunk sizes (same length).
+
+        bp = BatchedProjector(rm, 8)
+        bp.reset()
+        for chunk in chunks:  bp.step([x_b[lo:hi] for x_b in videos])      # x_b: [T, P, D] PE-added frames of video b
+        bp.memory_cache(b) -> list of [M, P, D] ring views of video b;  bp.frame_scores -> list of [B, F] per chunk
+    Inference only (no autograd path).  Same kernels and rounding points as the single-video engine; the attention's fp32
+    summation order follows the schedule of the stacked grid."""
+
+    def __init__(self, proj: TransformerProjector, batch: int):
+        if batch < 2:
+            raise capi.MavlmError("BatchedProjector: batch >= 2 (a single video runs through TransformerProjector itself)")
+        self.proj, self.batch = proj, int(batch)
+        self._engine = None
+        self.compute_frame_scores = True
+        self.frame_scores: List[torch.Tensor] = []
+        self._n = 0
+
+    def engine(self, device, dtype, frames=None) -> _Engine:
+        proj = self.proj
+        need = max(int(getattr(proj.config, "max_chunk_frames", 32)), int(frames or 0))
+        e = self._engine
+        if e is None or e.device != device or e.dtype != dtype or e.c.max_chunk_frames < need:
+            if e is not None and e.steps:
+                raise capi.MavlmError("device / dtype / chunk size changed in the middle of a video batch")
+            e = self._engine = _Engine(proj, device, dtype, need, batch=self.batch)
+        v = proj._param_version()
+        if e.version != v:
+            fuser, temb = proj._fuser_refs if proj._fuser_refs is not None else (None, None)
+            e.pack(proj, fuser, temb)
+            e.version = v
+        return e
+
+    def reset(self):
+        """`memory_cache = []` for every video of the batch (llava_arch.py:532)."""
+        self.frame_scores = []
+        self._n = 0
+        if self._engine is not None:
+            capi.check(capi.lib().mavlm_reset(self._engine.ctx), "mavlm_reset")
+            if self.proj._weights_maybe_stale():
+                self._engine.version = None
+
+    @torch.no_grad()
+    def step(self, segs):
+        """one chunk of every video: segs = B tensors [F, P, D] (contiguous, same F)"""
+        if len(segs) != self.batch:
+            raise capi.MavlmError(f"BatchedProjector.step: {self.batch} chunks expected")
+        F, P, D = segs[0].shape
+        for t in segs:
+            if not t.is_cuda or tuple(t.shape) != (F, P, D) or not t.is_contiguous() or t.dtype != segs[0].dtype:
+                raise capi.MavlmError("BatchedProjector.step: contiguous GPU chunks of one shape / dtype expected")
+        if P != self.proj.patch_size or D != self.proj.hidden_size:
+            raise capi.MavlmError(f"expected [F,{self.proj.patch_size},{self.proj.hidden_size}] chunks")
+        eng = self.engine(segs[0].device, segs[0].dtype, F)
+        ptrs = (capi.vp * self.batch)(*[t.data_ptr() for t in segs])
+        scores = torch.empty((self.batch, F), device=segs[0].device, dtype=segs[0].dtype) if self.compute_frame_scores else None
+        capi.check(capi.lib().mavlm_step_batch(eng.ctx, ptrs, F, scores.data_ptr() if scores is not None else 0, 0,
+                                               ops.stream_ptr()), "mavlm_step_batch")
+        self._n += 1
+        if scores is not None:
+            self.frame_scores.append(scores)
+        return scores
+
+    def memory_cache(self, b: int) -> List[torch.Tensor]:
+        """video b's FIFO, oldest first (ring views, as TransformerProjector.memory_cache)"""
+        eng = self._engine
+        cap = eng.c.cache_cap
+        n = min(self._n, cap)
+        return [eng.mem_ring[(self._n - n + i) % cap, b] for i in range(n)]

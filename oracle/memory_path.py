@@ -417,9 +417,10 @@ def streamk_split_tiles(R: int, S: int, heads: int):
 
 def frame_scores_fused(R: int, S: int, heads: int, patches: int, head_dim: int = 128) -> bool:
     """Mirrors mavlm_frame_scores_fused (csrc/mavlm_api.hip) for head_dim <= 128: does the fused step compute the frame
-    scores inside the last formation layer's forward (which then runs the plain, never-split grid)?"""
+    scores inside the last formation layer's forward?  (Round 3: that launch runs the same schedule as the plain forward
+    of the shape, so the answer no longer changes the rounding plan - kept for the tests of the C function.)"""
     return bool(FRAME_SCORES_FUSED and head_dim <= 128 and patches % 4 == 0 and patches >= KV_TILE and S > 0 and
-                S % patches == 0 and S // patches <= 64 and heads * R * 64.0 * 8.0 < 4294967296.0 and
+                S % patches == 0 and S // patches <= 64 and heads * R * (64.0 + 31.0) * 8.0 < 2147483000.0 and
                 split_plan(R, S, heads)[0] <= 1)          # (small grids keep their key splits)
 
 
@@ -445,6 +446,10 @@ LAZY_SCORE_ELEMS = 1 << 27  # ... and above which a block's scores are produced 
 # Heads and query blocks are independent: large problems spread them over a few threads (numpy releases the GIL inside
 # its kernels).  Same operations on the same data in the same order per head / block - results do not depend on it.
 FRAME_SCORES_FUSED = True        # mirror of mavlm_set_frame_score_mode (1 = default)
+# Row batch (mavlm_config.batch, csrc/mavlm_api.hip): (b, B) = this computation is video b of B stepped together.  The
+# arithmetic of a video does not change - only the attention SCHEDULE does: the stream-K plan is laid over B * heads
+# "heads" (video-major), the small grids' split-KV form is not used.  (0, 1) = a single video.
+ROW_BATCH = (0, 1)
 PAR_THREADS = max(1, min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
 PAR_MIN_ELEMS = 1 << 22          # below this much work per call the threads cost more than they bring
 _par_tls = threading.local()
@@ -576,10 +581,11 @@ def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mo
             if plain:                         # the never-split grid (mavlm_attention; the fused step's last layer when
                 ns, tps = 1, 0                # it carries the frame scores): one sweep over the keys for every row
             elif kv_tile == KV_TILE:          # attention3.hip (head_dim <= 128)
-                ns, tps = split_plan(plan_rows or R, Lk, heads)
-                sk_qb, sk_all = streamk_split_tiles(plan_rows or R, Lk, heads)
-                sk_cuts = {qb: a for (hh_, qb), a in sk_all.items() if hh_ == h}
-                if streamk_wgs(plan_rows or R, Lk, heads):
+                vb, nb = ROW_BATCH
+                ns, tps = split_plan(plan_rows or R, Lk, heads) if nb == 1 else (1, 0)
+                sk_qb, sk_all = streamk_split_tiles(plan_rows or R, Lk, heads * nb)
+                sk_cuts = {qb: a for (hh_, qb), a in sk_all.items() if hh_ == vb * heads + h}
+                if streamk_wgs(plan_rows or R, Lk, heads * nb):
                     ns, tps = 1, 0
             elif kv_tile == 32:               # attention_hd.hip
                 ns, tps = split_plan_wide(plan_rows or R, Lk, heads)
@@ -660,10 +666,9 @@ def mha(Xq: np.ndarray, Xkv: np.ndarray, w: Dict[str, np.ndarray], prefix: str, 
         V = r(linear(Xkv, w[f"{prefix}.v_proj.weight"], w[f"{prefix}.v_proj.bias"]))
     else:
         K, V = kv_cached
-    # the fused step computes the frame scores inside this attention when it can (mavlm_frame_scores_fused): that launch
-    # is the plain, never-split grid
-    plain = bool(want_colsum and frame_scores_fused(Q.shape[0], K.shape[0], cfg.heads, cfg.patches, Q.shape[1] // cfg.heads))
-    ctx, _, colsum_h, probs = attention_heads(Q, K, V, cfg.heads, mode, want_colsum, want_probs, plain=plain)
+    # (the fused step computes the frame scores inside this attention when it can, on the schedule every attention of the
+    # shape runs: asking for the scores does not change the context)
+    ctx, _, colsum_h, probs = attention_heads(Q, K, V, cfg.heads, mode, want_colsum, want_probs)
     colsum = colsum_h.astype(np.float64).sum(axis=0).astype(F32) if want_colsum else None   # :135 sum over heads
     ctx = r(ctx)
     pre = linear(ctx, w[f"{prefix}.residual.dense.weight"], w[f"{prefix}.residual.dense.bias"]) + Xq

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Diagnostic (run in the build container, then tests/diag_ablate.sh gemm on the GPU box): builds of the library with
 # parts of the 256x256x64 GEMM main loop removed (results wrong, timing only) into lib/exp/ - where does the in-loop
-# time go?   usage: tests/diag_gemm_ablate.sh
+# time go?  The instrumented kernel is a diagnostic COPY (tests/diag_src/gemm256_ablate.hip: the round-2 kernel with
+# its MAVLM_GEMM_ABLATE_* blocks); the product kernel carries none.   usage: tests/diag_gemm_ablate.sh
 set -e
 cd "$(dirname "$0")/.."
 SRC=memory-augmented-vlm_amd/csrc
@@ -10,7 +11,7 @@ mkdir -p $OUT /tmp/gab
 VARIANTS=${VARIANTS:-"base READS DMA MFMA BAR"}
 for v in $VARIANTS; do
   D=""; [ $v != base ] && D="-DMAVLM_GEMM_ABLATE_$v"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $D -c -o /tmp/gab/gemm256_$v.o $SRC/gemm256.hip &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $D -I$SRC -c -o /tmp/gab/gemm256_$v.o tests/diag_src/gemm256_ablate.hip &
 done
 wait
 for v in $VARIANTS; do

@@ -51,12 +51,16 @@ constexpr int STAGE2 = 4 * HALF;             // A0 A1 B0 B1
 constexpr int GEMM256_LDS = 2 * STAGE2;      // 128 KiB
 
 // raw workgroup barrier fenced against compiler motion of memory operations (s_barrier itself is IntrNoMem)
+#ifdef MAVLM_GEMM_ABLATE_BAR
+#define MAVLM_BAR() do { asm volatile("" ::: "memory"); } while (0)
+#else
 #define MAVLM_BAR()                          \
   do {                                       \
     asm volatile("" ::: "memory");           \
     __builtin_amdgcn_s_barrier();            \
     asm volatile("" ::: "memory");           \
   } while (0)
+#endif
 // all LDS reads of this phase retired before its MFMAs (WAR rule above); sched_barrier: hipcc may hoist a
 // register-only MFMA above an inline-asm wait (cdna_hip_programming.md rule 18)
 #define MAVLM_LGKM0()                                          \
@@ -80,8 +84,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
                                                          const uint16_t* __restrict__ W, int ldw,
                                                          const float* __restrict__ bias,
                                                          const uint16_t* __restrict__ res, int ldr,
-                                                         void* __restrict__ Cout, int ldc, int M, int N, int K,
-                                                         int c_rpb, int c_nb, long long c_bs) {
+                                                         void* __restrict__ Cout, int ldc, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -124,6 +127,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   const unsigned lds_wave = (unsigned)(uintptr_t)(MAVLM_LDS char*)smem + wave * 2048;
   // half-tile ids: 0 = A0, 1 = A1, 2 = B0, 3 = B1
   auto dma = [&](int stage, int half_id, int kt) {
+#ifdef MAVLM_GEMM_ABLATE_DMA
+    if (kt > 1) return;                       // (diagnostic build: results are wrong, timing only)
+#endif
     unsigned base = lds_wave;
     asm volatile("" : "+s"(base));            // M0 = base + constant stays a one-instruction recompute (no SGPR hoisting)
     const unsigned dst = base + stage * STAGE2 + half_id * HALF;
@@ -147,6 +153,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifdef MAVLM_GEMM_ABLATE_READS
+  int ablate_kt = 0;
+#endif
   typename T::vec8 af[4][2];      // [m-tile of the current 64-row slice][k-step]
   typename T::vec8 bf[4][2];      // [n-tile of the wave's 64 columns][k-step]
 
@@ -164,6 +173,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   MAVLM_BAR();
 
   auto read_a = [&](const char* st, int mh) {
+#ifdef MAVLM_GEMM_ABLATE_READS
+    if (ablate_kt > 0) return;
+#endif
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       if (mh == 1 && mt >= MT1) continue;     // (mh is a literal at every call site)
@@ -171,7 +183,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
       af[mt][1] = *(const typename T::vec8*)(st + offA + mh * 8192 + mt * 2048 + ck1);
     }
   };
+#ifdef MAVLM_GEMM_ABLATE_MFMA
+#define MAVLM_QUADRANT(MH, NH) { asm volatile("" : "+v"(af[0][0]), "+v"(bf[0][0])); }
+#else
   auto read_b_half = [&](const char* st, int nh) {
+#ifdef MAVLM_GEMM_ABLATE_READS
+    if (ablate_kt > 0) return;
+#endif
 #pragma unroll
     for (int nt = 2 * nh; nt < 2 * nh + 2; ++nt) {
       bf[nt][0] = *(const typename T::vec8*)(st + offB + nt * 2048 + ck0);
@@ -187,6 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
       acc[MH * 4 + mt][NH * 2 + nt] = T::mfma16(bf[NH * 2 + nt][ks], af[mt][ks], acc[MH * 4 + mt][NH * 2 + nt]); \
     __builtin_amdgcn_s_setprio(0);                                                          \
   }
+#endif
 
 
   if (trailing) MAVLM_BAR();           // ping-pong skew: pairs with the leading group's first in-loop barrier
@@ -194,6 +213,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   for (int kt = 0; kt < nk; ++kt) {
     const int s = kt & 1;
     const char* st = smem + s * STAGE2;
+#ifdef MAVLM_GEMM_ABLATE_READS
+    ablate_kt = kt;
+#endif
     // -------- phase 1
     read_a(st, 0);
     read_b_half(st, 0);
@@ -238,20 +260,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
     if (EPI == MAVLM_EPI_GELU) return gelu_erf_fast(v);
     return v;
   };
-  // element offset of output row m.  Row-batched outputs (mavlm_gemm_args::c_rpb): block q = m / c_rpb of c_rpb rows goes
-  // to batch element q % c_nb, as its (q / c_nb)-th block
-  auto crow = [&](int m) -> size_t {
-    if (c_rpb <= 0) return (size_t)m * ldc;
-    const int q = m / c_rpb, r = m - q * c_rpb;
-    return (size_t)(q % c_nb) * (size_t)c_bs + ((size_t)(q / c_nb) * c_rpb + r) * ldc;
-  };
   f32x4 bv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(bias + n0 + wn * 64 + j * 16 + fq * 4);
 #pragma unroll
   for (int i = 0; i < 4 + MT1; ++i) {
     const int m = m0 + wm * MHALF + i * 16 + fr;
-    const size_t co = crow(m < M ? m : M - 1);
     if (EPI == MAVLM_EPI_RES_F32 || EPI == MAVLM_EPI_F32) {
       if (m >= M) continue;
 #pragma unroll
@@ -262,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
           const u16x4 rv = *(const u16x4*)(res + (size_t)m * ldr + n);
           o[0] += T::to_f32(rv[0]); o[1] += T::to_f32(rv[1]); o[2] += T::to_f32(rv[2]); o[3] += T::to_f32(rv[3]);
         }
-        *(f32x4*)((float*)Cout + co + n) = o;
+        *(f32x4*)((float*)Cout + (size_t)m * ldc + n) = o;
       }
     } else {
 #pragma unroll
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
         const u32x4 w = widen_pair(pack4<T>(act(x[0]), act(x[1]), act(x[2]), act(x[3])),
                                    pack4<T>(act(y[0]), act(y[1]), act(y[2]), act(y[3])));
         const int n = n0 + wn * 64 + 16 * (j + (fq & 1)) + 8 * (fq >> 1);
-        if (m < M) *(u32x4*)((uint16_t*)Cout + co + n) = w;
+        if (m < M) *(u32x4*)((uint16_t*)Cout + (size_t)m * ldc + n) = w;
       }
     }
   }
@@ -288,8 +302,7 @@ hipError_t launch256h(const mavlm_gemm_args& g, hipStream_t s) {
   }
   const int ntm = (g.M + BMT - 1) / BMT, ntn = g.N / BN2;
   hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(512), GEMM256_LDS, s, (const uint16_t*)g.A, g.lda, (const uint16_t*)g.W,
-                     g.ldw, g.bias, (const uint16_t*)g.res, g.ldr, g.C, g.ldc, g.M, g.N, g.K, g.c_rpb, g.c_nb > 0 ? g.c_nb : 1,
-                     (long long)g.c_bstride);
+                     g.ldw, g.bias, (const uint16_t*)g.res, g.ldr, g.C, g.ldc, g.M, g.N, g.K);
   return hipGetLastError();
 }
 

@@ -1,0 +1,236 @@
+"""Round 3: the row batch (several videos stepped together, `mavlm_config.batch`) and the frame masses on the scheduled
+(stream-K) attention forward - HIP kernels through the C ABI against the oracle / against the single-video engine."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import memory_augmented_vlm_amd  # noqa: F401
+from memory_augmented_vlm_amd import _capi as capi
+from memory_augmented_vlm_amd import _ops as ops
+from memory_augmented_vlm_amd.model.memory_module.MemoryController import BatchedProjector
+from memory_augmented_vlm_amd.model import llava_arch as arch
+from oracle import memory_path as O
+from gpu_util import to_dev, to_np, load_oracle_weights, DT
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(autouse=True)
+def _inference_path():
+    with torch.no_grad():
+        yield
+
+
+def _host(cfg: O.PathConfig, w, mode="bf16", cap=10, vocab=48900):
+    class Base(torch.nn.Module):
+        def __init__(self, config):
+            super().__init__()
+            self.embed_tokens = torch.nn.Embedding(vocab, config.hidden_size)
+
+    class Model(arch.LlavaMetaModel, Base):
+        pass
+
+    hf = types.SimpleNamespace(hidden_size=cfg.hidden, num_memory_tokens=cfg.mem_tokens, memory_cache_cap=cap)
+    model = Model(hf).eval()
+    # LlavaMetaModel hard-codes 8 heads (llava_arch.py:122); the small test shapes use fewer
+    if cfg.heads != 8:
+        c = model.recurrent_memory_transformer.config
+        c.mm_num_attention_heads = cfg.heads
+        from memory_augmented_vlm_amd.model.memory_module.MemoryController import TransformerProjector
+        model.recurrent_memory_transformer = TransformerProjector(c)
+        model.recurrent_memory_transformer.bind_fuser(model.memory_fuser, model.token_type_embedding)
+    model.image_newline = torch.nn.Parameter(torch.zeros(cfg.hidden))
+    load_oracle_weights(model, w)
+    return model.to("cuda").to(DT[mode])
+
+
+def _prompts(D, mode="bf16"):
+    g = torch.Generator(device="cpu").manual_seed(5)
+    mp = torch.randn((10, D), generator=g).to("cuda").to(DT[mode])
+    fp = torch.randn((9, D), generator=g).to("cuda").to(DT[mode])
+    return mp, fp
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_row_batch_bit_identical_when_the_schedules_coincide(mode):
+    """Three videos stepped as one row batch == three single-video runs, bit for bit, on a shape where both take the same
+    attention schedule (few key tiles: the plain grid; nothing is split).  Everything the batch adds is exercised: the
+    stacked [B*R, D] GEMM / LayerNorm operands, the slot-major memory ring, the scattered outputs of the evolution K/V
+    projection and of the fuser's second GEMM, per-video K/V strides in the attention, the frame masses per video, a
+    FIFO that wraps (cap 2, 4 chunks), a ragged last chunk."""
+    cfg = O.PathConfig(hidden=256, heads=2, mem_tokens=2, depth=2)
+    w = O.make_weights(cfg, seed=61)
+    model = _host(cfg, w, mode, cap=2)
+    rm = model.recurrent_memory_transformer
+    B, T = 3, 14
+    r = O.rounder(mode)
+    vids = [to_dev(r(O.hash_normal_like((T, 196, 256), 6100 + b)), mode) for b in range(B)]
+    idx = torch.arange(T) * 2
+    mp, fp = _prompts(256, mode)
+    singles, sscores = [], []
+    for b in range(B):
+        n0 = len(rm.frame_attn_scores)
+        singles.append(arch.video_memory_tokens(model, vids[b], idx, mp, fp, model.image_newline, chunk=4)[0].clone())
+        sscores.append([s.clone() for s in rm.frame_attn_scores[n0:]])
+    bp = BatchedProjector(rm, B)
+    toks, info = arch.video_memory_tokens_batched(model, bp, vids, idx, mp, fp, model.image_newline, chunk=4)
+    torch.cuda.synchronize()
+    assert toks.shape == (B,) + tuple(singles[0].shape) and info["num_memories"] == 2
+    for b in range(B):
+        assert torch.equal(toks[b], singles[b]), f"video {b}"
+        for c, sc in enumerate(info["frame_scores"]):
+            assert torch.equal(sc[b], sscores[b][c]), f"video {b} chunk {c}"
+        for got, ref in zip(bp.memory_cache(b), rm.memory_cache if b == B - 1 else []):
+            assert torch.equal(got, ref)
+    # the frame-dropout branch and a second batch through the same state (reset)
+    toks2, _ = arch.video_memory_tokens_batched(model, bp, vids[::-1], idx, mp, fp, model.image_newline, with_frames=False,
+                                                chunk=4)
+    a, b_ = info["memory_rows"]
+    assert toks2.shape[1] == b_ + 1
+    for b in range(B):
+        assert torch.equal(toks2[b], singles[B - 1 - b][:b_ + 1])
+
+
+def test_row_batch_checkpoint_shape_vs_oracle():
+    """The reference-default shape (8 memory tokens, D = 1024, 8 heads), five videos in one row batch, 2 chunks of 32 frames:
+    40 (video, head) pairs x 7 query blocks = 280 eight-wave units on 256 workgroups - the levelled stream-K schedule with
+    the frame masses riding on it, cut units in the last video.  Video 0 (whole units) and video 4 (cut units, entries per
+    piece merged in the combine kernel) against the oracle with the batch's plan mirrored; every video against the
+    single-video engine within the 16-bit rounding of two schedules."""
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=62)
+    model = _host(cfg, w)
+    rm = model.recurrent_memory_transformer
+    B, T = 5, 64
+    info_ = (capi.i32 * 4)()
+    capi.check(capi.lib().mavlm_attention_plan(1568, 6272, 8 * B, info_), "plan")
+    assert info_[1] == 256 and info_[0] == 8 and info_[2] == 2          # 8-wave stream-K, two levels (16 + 8 cut units)
+    xs = [O.bf16_round(O.hash_normal_like((T, 196, 1024), 6200 + b)) for b in range(B)]
+    vids = [to_dev(x) for x in xs]
+    idx = torch.arange(T)
+    mp, fp = _prompts(1024)
+    bp = BatchedProjector(rm, B)
+    toks, info = arch.video_memory_tokens_batched(model, bp, vids, idx, mp, fp, model.image_newline)
+    torch.cuda.synchronize()
+    a, b_ = info["memory_rows"]
+    emb = np.zeros((48900, 1024), np.float32)
+    emb[list(O.MEM_PROMPT_IDS)] = to_np(mp)
+    emb[list(O.FRAME_PROMPT_IDS)] = to_np(fp)
+    for b in (0, B - 1):
+        O.ROW_BATCH = (b, B)
+        try:
+            ref, parts = O.video_tokens(xs[b], idx.numpy(), cfg, w, emb, "bf16", return_parts=True)
+            with O.accumulate_in(np.float64):
+                ref64 = O.video_tokens(xs[b], idx.numpy(), cfg, w, emb, "bf16")
+        finally:
+            O.ROW_BATCH = (0, 1)
+        floor = O.rel_l2(ref64[a:b_], ref[a:b_])
+        err = O.rel_l2(to_np(toks[b])[a:b_], ref[a:b_])
+        print(f"row batch, video {b}: fused memory tokens HIP vs oracle {err:.2e} (floor {floor:.2e})")
+        assert err < max(TOL, 2.0 * floor)
+        for c, sc in enumerate(info["frame_scores"]):
+            assert O.rel_l2(to_np(sc[b]), parts["frame_scores"][c]) < 5e-3
+    for b in range(B):
+        single = arch.video_memory_tokens(model, vids[b], idx, mp, fp, model.image_newline)[0]
+        assert O.rel_l2(to_np(toks[b]), to_np(single)) < 6e-3
+        assert torch.equal(toks[b][:a], single[:a]) and torch.equal(toks[b][b_:], single[b_:])     # copies / gathers
+
+
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("mode,R,F,P,H", [("bf16", 8320, 10, 64, 8), ("fp16", 8330, 3, 196, 8), ("bf16", 1100, 6, 100, 64)])
+def test_attention_frames_on_the_stream_k_schedule(mode, R, F, P, H, waves, monkeypatch, request):
+    """The frame-score variant of the forward on the levelled stream-K schedule: the pieces of a cut unit leave (a, m)
+    entries for the parts of the frames they saw, the combine kernel - which knows the merged log-sum-exp - turns them into
+    partial frame sums.  Context and log-sum-exp are BIT-identical to the plain forward of the same schedule (asking for
+    the scores has no side effect), the scores match the oracle's column sums; frame boundaries inside pieces, pieces
+    inside frames, fewer key tiles than pieces (empty pieces), ragged query blocks; 4- and 8-wave workgroups."""
+    lib = capi.lib()
+    capi.check(lib.mavlm_set_attention_streamk_min_tiles(2), "min tiles")
+    capi.check(lib.mavlm_set_attention_streamk_waves(waves), "waves")
+    request.addfinalizer(lambda: (lib.mavlm_set_attention_streamk_min_tiles(64), lib.mavlm_set_attention_streamk_waves(0)))
+    monkeypatch.setattr(O, "STREAMK_MIN_TILES", 2)
+    monkeypatch.setattr(O, "STREAMK_WAVES", waves)
+    S = F * P
+    info = (capi.i32 * 4)()
+    capi.check(lib.mavlm_attention_plan(R, S, H, info), "plan")
+    assert info[1] > 0 and info[0] == waves, "the shape must take the stream-K schedule"
+    r = O.rounder(mode)
+    q = r(O.hash_normal_like((R, H * 128), 71)) * 2.0
+    k = r(O.hash_normal_like((S, H * 128), 72))
+    v = r(O.hash_normal_like((S, H * 128), 73))
+    q[R - 7] *= 8.0                                    # a row of the last (cut) units whose maximum jumps: rescale of the mass
+    dq, dk, dv = to_dev(q, mode), to_dev(k, mode), to_dev(v, mode)
+    got, lse, scores = ops.attention_frames(dq, dk, dv, H, P, want_lse=True)
+    plain, lse_p = ops.attention(dq, dk, dv, H, want_lse=True)
+    assert torch.equal(got, plain) and torch.equal(lse, lse_p)
+    ctx, lse2, col, _ = O.attention_heads(q, k, v, H, mode, want_colsum=True)
+    assert O.rel_l2(to_np(got), r(ctx)) < TOL
+    ref = col.astype(np.float64).sum(0).reshape(F, P).mean(1)
+    assert O.rel_l2(to_np(scores), ref) < TOL and abs(float(scores.sum()) * P - H * R) < 1e-3 * H * R
+    for _ in range(2):
+        assert torch.equal(ops.attention_frames(dq, dk, dv, H, P)[2], scores)
+
+
+@pytest.mark.parametrize("R", [1568, 300, 4100 + 64])
+def test_frame_entries_have_one_writer(R):
+    """Query rows past R are clamped duplicates of row R-1.  When R % 128 leaves whole waves past R, those waves must not
+    store frame entries: a duplicate wave can take a rescale the owning wave does not (a row of wave 0 - not row R-1 -
+    whose maximum jumps by more than 2^8 in a late tile) and would race with it.  Their stores go to an offset behind the
+    buffer descriptor's end.  Scores equal the oracle's and repeat bit for bit."""
+    H, P, F = 8, 196, 6
+    S = F * P
+    assert 0 < R % 128 <= 96
+    r = O.rounder("bf16")
+    q = r(O.hash_normal_like((R, H * 128), 91))
+    k = r(O.hash_normal_like((S, H * 128), 92))
+    v = r(O.hash_normal_like((S, H * 128), 93))
+    row = (R // 128) * 128 + 5                        # wave 0 of the last block, not the last row
+    assert row < R - 1
+    # its score against the keys of a late tile exceeds everything before by far more than 2^8 (log2 domain)
+    k[S - 100:S - 90] = r(q[row][None, :] * 6.0)
+    dq, dk, dv = to_dev(q), to_dev(k), to_dev(v)
+    got, lse, scores = ops.attention_frames(dq, dk, dv, H, P, want_lse=True)
+    _, _, col, _ = O.attention_heads(q, k, v, H, "bf16", want_colsum=True, plain=True)
+    ref = col.astype(np.float64).sum(0).reshape(F, P).mean(1)
+    assert O.rel_l2(to_np(scores), ref) < TOL
+    for _ in range(20):
+        assert torch.equal(ops.attention_frames(dq, dk, dv, H, P)[2], scores)
+
+
+def test_pool_row_batches():
+    """MemoryPathPool(batch=B): consecutive videos of one length run as row batches on the pool's streams, the rest through
+    the single-video slots; every video's block equals the single-video result within the rounding of two attention
+    schedules, and identical videos in different batch positions give identical tokens."""
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=63)
+    model = _host(cfg, w)
+    mp, fp = _prompts(1024)
+    x40 = [to_dev(O.bf16_round(O.hash_normal_like((40, 196, 1024), 6300 + i))) for i in range(4)]
+    x33 = to_dev(O.bf16_round(O.hash_normal_like((33, 196, 1024), 6310)))
+    vids = [(x40[0], torch.arange(40)), (x40[1], torch.arange(40)), (x33, torch.arange(33)),
+            (x40[2], torch.arange(40)), (x40[0], torch.arange(40)), (x40[3], torch.arange(40))]
+    serial = [arch.video_memory_tokens(model, v, i, mp, fp, model.image_newline)[0].clone() for v, i in vids]
+    pool = arch.MemoryPathPool(model, 2, batch=2)
+    outs = pool.run(vids, mp, fp, model.image_newline)
+    torch.cuda.synchronize()
+    for a, b in zip(serial, outs):
+        assert a.shape == b.shape and O.rel_l2(to_np(b), to_np(a)) < 6e-3
+    assert torch.equal(outs[2], serial[2])                  # the odd one out ran through a single-video slot
+
+
+def test_row_batch_refusals():
+    """Loud errors: wide heads have no row batch; the single-video entry points refuse a batched context and vice versa."""
+    c = capi.Config(hidden=3584, heads=8, patches=196, mem_tokens=8, depth=2, inter=4 * 3584, cache_cap=10,
+                    max_chunk_frames=32, dtype=0, eps=1e-12, batch=2)
+    h = capi.vp()
+    assert capi.lib().mavlm_create(c, h) == capi.E_SHAPE
+    c.hidden, c.inter, c.batch = 1024, 4096, 65
+    assert capi.lib().mavlm_create(c, h) == capi.E_ARG
+    c.batch = 2
+    assert capi.lib().mavlm_create(c, h) == 0 and capi.lib().mavlm_batch(h) == 2
+    x = torch.zeros(8, device="cuda")
+    assert capi.lib().mavlm_step(h, x.data_ptr(), 1, 0, 0, 0) == capi.E_STATE
+    capi.lib().mavlm_destroy(h)

@@ -199,9 +199,11 @@ def test_attention_split_kv_small_grids(mode, R, S, H):
 @pytest.mark.parametrize("R,F,P,H", [(1568, 3, 196, 8), (300, 5, 196, 2), (129, 64, 64, 1), (8330, 2, 100, 8), (4100, 7, 68, 3)])
 def test_attention_frames_vs_oracle(mode, R, F, P, H):
     """Forward + frame scores in one pass (what the fused step runs for the last formation layer): the context and the
-    log-sum-exp are BIT-identical to the plain-grid forward (the frame bookkeeping does not touch them), the scores match
+    log-sum-exp are BIT-identical to the forward without scores on the same schedule (the frame bookkeeping does not touch
+    them; the small grids that `ops.attention` would split over the keys run the plain grid here), the scores match
     the oracle's column sums averaged per frame; frame boundaries inside a 64-key tile (P = 196, 100, 68) and at tile ends
-    (P = 64, the smallest frame: one boundary per tile, 64 frames), ragged last tiles and query blocks."""
+    (P = 64, the smallest frame: one boundary per tile, 64 frames), ragged last tiles and query blocks.  (The stream-K
+    schedule: tests/test_gpu_batch.py.)"""
     S = F * P
     r = O.rounder(mode)
     q = r(O.hash_normal_like((R, H * 128), 51)) * 2.0
@@ -211,7 +213,9 @@ def test_attention_frames_vs_oracle(mode, R, F, P, H):
     dq, dk, dv = to_dev(q, mode), to_dev(k, mode), to_dev(v, mode)
     assert capi.lib().mavlm_attention_frames_ws_floats(R, S, H, P) > 0 and capi.lib().mavlm_attention_frames_ws_floats(R, 32 * 60, H, 60) == 0
     got, lse, scores = ops.attention_frames(dq, dk, dv, H, P, want_lse=True)
-    plain, lse_p = ops.attention(dq, dk, dv, H, want_lse=True, plain=True)
+    info = (capi.i32 * 4)()
+    capi.check(capi.lib().mavlm_attention_plan(R, S, H, info), "plan")
+    plain, lse_p = ops.attention(dq, dk, dv, H, want_lse=True, plain=info[3] > 1)
     assert torch.equal(got, plain) and torch.equal(lse, lse_p)
     _, _, col = _attn_oracle(q, k, v, H, mode)        # (plan-independent up to rounding: column sums of the probabilities)
     ref = col.astype(np.float64).sum(0).reshape(F, P).mean(1)
