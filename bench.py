@@ -59,14 +59,17 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=("replica", "shard-video"), default="replica")
     ap.add_argument("--repeats", type=int, default=5, help="minimum number of timed K-step blocks")
-    ap.add_argument("--min-seconds", type=float, default=2.0, help="keep repeating blocks until this much timed work")
+    ap.add_argument("--min-seconds", type=float, default=8.0,
+                    help="keep repeating blocks until this much timed work (>= 8 s: a utilisation sampler sees the GPU busy)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="functional rehearsal: ranks may share GPUs and talk over gloo (never a measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frame-scores", action="store_true", help="skip the column-sum pass (not the headline)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of the final memory state")
     ap.add_argument("--videos-in-flight", type=int, default=2,
-                    help="independent videos per step per GPU, each on its own HIP stream (fills partial-wave tails)")
+                    help="HIP streams per GPU, each stepping its own video(s) (fills partial-wave tails)")
+    ap.add_argument("--batch", type=int, default=2,
+                    help="videos stepped TOGETHER per stream as a row batch (stacked memory rows in every weight-shared GEMM)")
     ap.add_argument("--shard-frames", type=int, default=1024, help="shard-video: frames of the one long video")
     ap.add_argument("--shard-hidden", type=int, default=3584, help="shard-video: hidden width (3584 = OV-7B)")
     ap.add_argument("--shard-mem-tokens", type=int, default=8)
@@ -353,13 +356,18 @@ def run_replica(args, rank, world, local, device, dist_info):
     rm = model.recurrent_memory_transformer
     rm.compute_frame_scores = not args.no_frame_scores
     g = torch.Generator(device="cpu").manual_seed(100 + rank)
-    B = max(1, args.videos_in_flight)
+    NS, NB = max(1, args.videos_in_flight), max(1, args.batch)      # streams, videos per row batch
+    B = NS * NB                                                      # videos per step per GPU
     xs = [torch.randn((FRAMES, PATCHES, HIDDEN), generator=g).to(device).to(torch.bfloat16) for _ in range(B)]  # in HBM
     x = xs[0]
     idx_cpu = torch.arange(FRAMES)
-    pool = arch.MemoryPathPool(model, B)
-    for slot in pool.slots:
-        slot.recurrent_memory_transformer.compute_frame_scores = not args.no_frame_scores
+    pool = arch.MemoryPathPool(model, NS, batch=NB)
+    pool1 = arch.MemoryPathPool(model, 1, batch=NB) if NS > 1 else pool     # instrumented pass: ONE stream
+    for pl in (pool, pool1):
+        for slot in pl.slots:
+            slot.recurrent_memory_transformer.compute_frame_scores = not args.no_frame_scores
+        for bs in pl.bslots:
+            bs.compute_frame_scores = not args.no_frame_scores
     mem_ids = torch.tensor(arch.MEMORY_PROMPT_IDS, device=device)
     frame_ids = torch.tensor(arch.FRAME_PROMPT_IDS, device=device)
     gathered = torch.empty((world, MEM_TOKENS, PATCHES, HIDDEN), device=device, dtype=torch.bfloat16) if world > 1 else None
@@ -369,17 +377,25 @@ def run_replica(args, rank, world, local, device, dist_info):
     do_gather = world > 1 and not args.no_gather
     last = [None]
 
-    def step(single=False):
+    def final_memory():
+        """newest memory of this rank's first video (what the north-star's all-gather ships)"""
+        if NB > 1:
+            return pool.bslots[0].memory_cache(0)[-1]
+        return rm.memory_cache[-1]
+
+    def step(single=False, one_video=False):
         mp = torch.nn.functional.embedding(mem_ids, model.embed_tokens.weight)
         fp = torch.nn.functional.embedding(frame_ids, model.embed_tokens.weight)
-        if single or B == 1:
+        if one_video:
             toks, _ = arch.video_memory_tokens(model, x, idx_cpu, mp, fp, model.image_newline)
+        elif single:
+            toks = pool1.run([(xi, idx_cpu) for xi in xs[:NB]], mp, fp, model.image_newline)[0]
         else:
             toks = pool.run([(xi, idx_cpu) for xi in xs], mp, fp, model.image_newline)[0]
-        if do_gather:
+        if do_gather and not single and not one_video:
             if pending[0] is not None:
                 pending[0].wait()                       # previous gather (overlapped with this step) is done with `send`
-            send.copy_(rm.memory_cache[-1])             # final memory state of this rank's (first) video
+            send.copy_(final_memory())                  # final memory state of this rank's (first) video
             _, pending[0] = D.all_gather_memory_state(send, out=gathered, async_op=True)
         last[0] = toks
         return toks
@@ -401,8 +417,8 @@ def run_replica(args, rank, world, local, device, dist_info):
         mine = gathered[rank].float()
         assert bool(torch.isfinite(gathered.float()).all()) and torch.equal(mine, send.float())
 
-    # ---- instrumented pass: the same K steps with a HIP-event pair around every kernel launch (ONE video in flight:
-    # kernel durations are not smeared by the other stream)
+    # ---- instrumented pass: the same K steps with a HIP-event pair around every kernel launch, ONE stream (one row batch of
+    # NB videos in flight: kernel durations are not smeared by the other stream)
     lib = capi.lib()
     with torch.no_grad():
         lib.mavlm_prof_enable(1)
@@ -411,35 +427,53 @@ def run_replica(args, rank, world, local, device, dist_info):
         sync()
         kernels, ms, ln, fl, by = kernel_table(lib, capi, args.steps)
         lib.mavlm_prof_enable(0)
+        # single-video latency (one video, one stream, no row batch): what a request waits for
+        for _ in range(3):
+            step(one_video=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step(one_video=True)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t0) / 10 * 1e3
     dom = "attention_fwd"
     di = capi.KERNEL_KINDS.index(dom)
     info = (ctypes.c_int32 * 4)()       # which instantiation the plan picks at the formation shape (S = one chunk's keys)
-    capi.check(lib.mavlm_attention_plan(MEM_TOKENS * PATCHES, 32 * PATCHES, HEADS, info), "mavlm_attention_plan")
+    capi.check(lib.mavlm_attention_plan(MEM_TOKENS * PATCHES, 32 * PATCHES, HEADS * NB, info), "mavlm_attention_plan")
     kname = f"attn_fwd3_kernel<BF16, {info[0]}, 0>"
     mi = capi.KERNEL_KINDS.index("attention_merge")
     fi = capi.KERNEL_KINDS.index("attention_fwd_frames")
     knote = ("HIP-event bracket around this kernel only (all its launches of a step: formation and evolution shapes; the last "
-             "formation layer of a step runs the frame-score variant attn_fwd3_kernel<BF16, 4, 1> on the plain grid instead - "
+             f"formation layer of a step runs the frame-score variant attn_fwd3_kernel<BF16, {info[0]}, 1> on the SAME schedule - "
              f"{ms[fi] / max(ln[fi], 1) * 1e3:.1f} us per launch, kernels.attention_fwd_frames - which replaces the "
-             "column-sum pass); "
+             f"column-sum pass); a launch serves the {NB} video(s) of a row batch ({HEADS * NB} (video, head) pairs); "
              + (f"schedule: levelled stream-K, {info[1]} workgroups of {info[0]} waves, {info[2]} level(s); its merge kernel "
                 f"attn_combine_sk_kernel<BF16> is bracketed separately: {ms[mi] / max(ln[mi], 1) * 1e3:.1f} us per launch "
                 "(kernels.attention_merge)" if info[1] else "plain grid"))
     achieved = fl[di] / (ms[di] * 1e-3) / 1e12
+    # every attention-forward launch of a step, weighted by time (plain + frame-score variant + merges)
+    att_ms = ms[di] + ms[fi] + ms[mi]
+    att_weighted = (fl[di] + fl[fi]) / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0
     traffic, tnote = None, None
-    for tp in ("r02_attn_fwd_hbm_traffic.json", "r01_attn_fwd3_hbm_traffic.json"):
+    for tp in ("r03_attn_fwd_hbm_traffic.json",):
         tpath = os.path.join(ROOT, "profiles", tp)
         if os.path.exists(tpath):      # PMC summary committed from a separate rocprofv3 --pmc run (tests/pmc_traffic.sh)
-            traffic = json.load(open(tpath)).get("bench_avg_bytes_per_launch")
-            tnote = (f"NOT measured in this run: constant from profiles/{tp} (separate rocprofv3 --pmc passes, FETCH_SIZE x2 "
-                     "gfx950 correction + WRITE_SIZE, per launch); algorithmic bytes per launch in alg_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("bench_avg_bytes_per_launch")
+            tnote = (f"NOT measured in this run: constant from profiles/{tp} (separate rocprofv3 --pmc passes over the same "
+                     "command, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, averaged over this kernel's launches of a step = "
+                     f"its real launch mix: {tj.get('launch_mix', 'see file')}); algorithmic bytes per launch in alg_bytes_per_launch")
             break
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": tnote,
                 "kernel": kname, "kernel_note": knote,
                 "avg_launch_ms": round(ms[di] / ln[di], 5), "launches_per_step": ln[di] / args.steps,
                 "alg_flops_per_launch": fl[di] / ln[di], "alg_bytes_per_launch": by[di] / ln[di],
-                "hbm_gbs_algorithmic": round(by[di] / (ms[di] * 1e-3) / 1e9, 1)}
+                "hbm_gbs_algorithmic": round(by[di] / (ms[di] * 1e-3) / 1e9, 1),
+                "attention_fwd_all_launches_tflops": round(att_weighted, 1),
+                "attention_fwd_all_launches_frac": round(att_weighted / MFMA_PEAK_TFLOPS, 4),
+                "clock_note": "frac is against the nominal 2.5 PFLOP/s (2.4 GHz); sclk of THIS box while the blocks ran: "
+                              "timing.clock; the box profiles/r03_* were taken on: profiles/README.md"}
 
     extras = {}
     if args.m8_extra or (world == 1 and os.environ.get("MAVLM_BENCH_M8", "1") != "0"):
@@ -459,9 +493,10 @@ def run_replica(args, rank, world, local, device, dist_info):
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "configs[1]: 64-frame video, 2 recurrent chunks of 32 frames, 64 memory tokens, "
                                "196 tokens/frame, D=1024, H=8, depth 2, frame scores on; "
-                               f"a step = {B} independent video(s) per GPU, each on its own HIP stream",
+                               f"a step = {B} independent videos per GPU: {NS} HIP stream(s) x a row batch of {NB} (the memory "
+                               "rows of a batch are stacked into every weight-shared GEMM / LayerNorm launch)",
                    "frames": FRAMES, "mem_tokens": MEM_TOKENS, "hidden": HIDDEN, "parallelism": f"replica x{world}",
-                   "videos_per_step_per_gpu": B, "allgather_final_memory": bool(do_gather),
+                   "videos_per_step_per_gpu": B, "streams": NS, "row_batch": NB, "allgather_final_memory": bool(do_gather),
                    "frame_scores": not args.no_frame_scores, "mode": "replica"},
         "timing": {"blocks": len(times), "steps_per_block": args.steps, "statistic": "median block",
                    "ms_per_step_min": round(times_sorted[0] / args.steps * 1e3, 4),
@@ -472,7 +507,8 @@ def run_replica(args, rank, world, local, device, dist_info):
         "roofline": roofline,
         "alg_tflop_per_video": round(flops / 1e12, 3),
         "path_mfma_frac": round(B * flops / (med / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-        "kernel_timing_note": "per-kernel numbers from an instrumented pass with ONE video in flight",
+        "single_video_latency_ms": round(single_ms, 3),
+        "kernel_timing_note": f"per-kernel numbers from an instrumented pass with ONE stream (a row batch of {NB} video(s)) in flight",
         "kernels": kernels,
     }
     out.update(extras)
@@ -483,11 +519,12 @@ def run_m8_extra(args, device, arch):
     """Extras: the reference-default (checkpoint-compatible) shape M = 8, D = 1024, 64 frames, same path."""
     import torch
     model, _ = build_model(device, mem_tokens=8, seed=4321)
-    B = max(1, args.videos_in_flight)
+    NS, NB = max(1, args.videos_in_flight), 8          # 8 videos per row batch: 8 x 1568 = the 12 544 rows of the headline shape
+    B = NS * NB
     g = torch.Generator(device="cpu").manual_seed(55)
     xs = [torch.randn((FRAMES, PATCHES, HIDDEN), generator=g).to(device).to(torch.bfloat16) for _ in range(B)]
     idx_cpu = torch.arange(FRAMES)
-    pool = arch.MemoryPathPool(model, B)
+    pool = arch.MemoryPathPool(model, NS, batch=NB)
     mem_ids = torch.tensor(arch.MEMORY_PROMPT_IDS, device=device)
     frame_ids = torch.tensor(arch.FRAME_PROMPT_IDS, device=device)
 
@@ -511,7 +548,7 @@ def run_m8_extra(args, device, arch):
     med = ts[len(ts) // 2]
     fl = algorithmic_flops(M=8)
     return {"frames_per_s": round(args.steps * B * FRAMES / med, 1), "ms_per_step": round(med / args.steps * 1e3, 4),
-            "videos_per_step": B, "mem_tokens": 8, "alg_tflop_per_video": round(fl / 1e12, 4),
+            "videos_per_step": B, "streams": NS, "row_batch": NB, "mem_tokens": 8, "alg_tflop_per_video": round(fl / 1e12, 4),
             "path_mfma_frac": round(B * fl / (med / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4), "this_rank_only": True}
 
 
@@ -535,7 +572,8 @@ def run_shard_video(args, rank, world, local, device, dist_info):
         xp = model.positional_encoding(x, idx, indices_checked=True)
         sh.reset()
         for i in range(0, T, 32):
-            cache, _ = sh.step(xp[i:i + 32])
+            # the next chunk's K/V projection overlaps the all-gather of this step's memory rows
+            cache, _ = sh.step(xp[i:i + 32], prefetch=xp[i + 32:i + 64] if i + 32 < T else None)
         last[0] = cache
         return cache
 

@@ -51,6 +51,13 @@ typedef struct mavlm_config {
                              * weight-shared GEMM / LayerNorm launch ([B*M*P, D]); the attention serves B*heads (video, head)
                              * pairs, each video over its own keys.  head_dim <= 128 only.  Buffers: see mavlm_buffers,
                              * mavlm_weights.mem0; protocol: mavlm_step_batch / mavlm_fuse_emit_batch. */
+  int32_t q_token0;         /* Row shard of ONE video over the ranks of a process group (SURVEY.md section 8e option 2): this */
+  int32_t q_tokens;         /* context computes the memory tokens [q_token0, q_token0 + q_tokens) of every step - q projection,
+                             * attention rows, dense, LayerNorm and MLP are row-independent - and writes them into its rows
+                             * of the FIFO slot; the host all-gathers the other ranks' rows into the slot before the next
+                             * mavlm_step (the evolution reads ALL rows of every cached memory as keys).  mem0 = the owned
+                             * rows [q_tokens*P, D]; frame scores = this shard's partial sums (all-reduce them).
+                             * q_tokens = 0: all tokens (no shard).  Not combined with batch > 1. */
 } mavlm_config;
 
 /* One `Attention` block (MemoryController.py:31-57) minus its K/V projections.  Weights [out,in] 16-bit
@@ -127,6 +134,10 @@ int mavlm_step(mavlm_ctx* ctx, const void* seg, int32_t F, void* frame_scores, i
  * contexts where the attention schedule differs (fp32 summation order of the cut units); same rounding points. */
 int mavlm_step_batch(mavlm_ctx* ctx, const void* const* segs, int32_t F, void* frame_scores, int32_t scores_f32, void* stream);
 int mavlm_batch(const mavlm_ctx* ctx);      /* B = max(config.batch, 1) */
+/* K/V projection of a chunk ahead of its mavlm_step (the one GEMM of a step that does not read the memory): lets a host
+ * overlap it with an exchange the step has to wait for - the all-gather of the previous memory's rows in the row-sharded
+ * mode.  The next mavlm_step with the same (seg, F) skips the projection; any other call discards it. */
+int mavlm_project_chunk(mavlm_ctx* ctx, const void* seg, int32_t F, void* stream);
 
 /* replaces memory_fuser(cat(memory_cache)) + token_type add + fine-frame gather/add + prompt/newline concat
  * (llava_arch.py:513-524,545-554,620-629,708-731).  Writes

@@ -20,7 +20,7 @@ i32 = C.c_int32
 class Config(C.Structure):
     _fields_ = [("hidden", i32), ("heads", i32), ("patches", i32), ("mem_tokens", i32), ("depth", i32),
                 ("inter", i32), ("cache_cap", i32), ("max_chunk_frames", i32), ("dtype", i32), ("eps", C.c_float),
-                ("batch", i32)]
+                ("batch", i32), ("q_token0", i32), ("q_tokens", i32)]
 
 
 class AttnWeights(C.Structure):
@@ -58,6 +58,7 @@ SIGNATURES = {
     "mavlm_step": (C.c_int, [vp, vp, i32, vp, i32, vp]),
     "mavlm_step_batch": (C.c_int, [vp, C.POINTER(vp), i32, vp, i32, vp]),
     "mavlm_batch": (C.c_int, [vp]),
+    "mavlm_project_chunk": (C.c_int, [vp, vp, i32, vp]),
     "mavlm_fuse_emit_batch": (C.c_int, [vp, C.POINTER(vp), vp, i32, vp, i32, vp, i32, vp, i32, vp, C.c_int64,
                                         C.POINTER(C.c_int64), vp]),
     "mavlm_fuse_emit": (C.c_int, [vp, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, C.c_int64,

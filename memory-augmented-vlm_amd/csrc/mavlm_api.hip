@@ -18,6 +18,8 @@ struct mavlm_ctx {
   size_t o_kv, o_q, o_ctx, o_a, o_h, o_pre, o_mA, o_mB, o_lse, o_part, o_split, o_gsplit, gsplit_floats, total;
   size_t o_fscr = 0, o_fout = 0;   // frame-score variant of the last layer's forward (0 = not available for this config)
   size_t split_floats = 0;         // floats carved at o_split (attention partials: split-KV / stream-K)
+  const void* pre_seg = nullptr;   // mavlm_project_chunk: the chunk whose K/V already sit in the workspace (0 = none)
+  int pre_F = 0;
   int fuse_mems = 1;   // cached memories the Memory-Fuser MLP takes per GEMM launch (mavlm_fuse_emit)
 };
 
@@ -32,9 +34,15 @@ bool cfg_ok(const mavlm_config* c) {
     return false;
   if (c->dtype != 0 && c->dtype != 1) return false;
   if (c->batch < 0 || c->batch > MAVLM_MAX_BATCH) return false;
+  if (c->q_tokens < 0 || c->q_token0 < 0 || c->q_token0 + c->q_tokens > c->mem_tokens || (c->q_tokens == 0 && c->q_token0 != 0))
+    return false;
+  if (c->q_tokens > 0 && c->batch > 1) return false;           // a row shard of ONE video, or a row batch of whole videos
   return true;
 }
 inline int nbatch(const mavlm_config& c) { return c.batch > 1 ? c.batch : 1; }
+// row shard (mavlm_config.q_tokens): memory tokens this context computes per step, and the first of them
+inline int q_tokens(const mavlm_config& c) { return c.q_tokens > 0 ? c.q_tokens : c.mem_tokens; }
+inline int q_row0(const mavlm_config& c) { return c.q_tokens > 0 ? c.q_token0 * c.patches : 0; }
 
 // shapes the gfx950 kernels implement (DESIGN.md "Supported shapes"): head_dim <= 128 (heads are zero-padded to
 // 128 columns in the Q/K/V/ctx buffers and in the packed weights), D and I multiples of 128
@@ -62,8 +70,9 @@ inline int fuse_mems_per_launch(const mavlm_config& c) {
 void carve(mavlm_ctx* x) {
   const mavlm_config& c = x->cfg;
   const size_t B = (size_t)nbatch(c);
-  const size_t R1 = (size_t)c.mem_tokens * c.patches;          // memory rows of ONE video
-  const size_t R = R1 * B;                                     // rows of every row-wise operator (all videos stacked)
+  const size_t Rf = (size_t)c.mem_tokens * c.patches;          // memory rows of ONE video (row buffers: sized for all of them)
+  const size_t R1 = (size_t)q_tokens(c) * c.patches;           // query rows of one video this context computes (row shard)
+  const size_t R = Rf * B;                                     // rows of every row-wise operator (all videos stacked)
   const size_t S = (size_t)c.max_chunk_frames * c.patches, D = c.hidden, I = c.inter, L = c.depth, H = c.heads,
                Dp = (size_t)padded_width(c);
   size_t o = 0;
@@ -112,15 +121,18 @@ void carve(mavlm_ctx* x) {
   // projections (MLP down, fuser second layer) at small R
   x->o_gsplit = o;
   {
-    const int r = (int)R, sk = (int)S, d = (int)D, dp = (int)Dp, in = (int)I, l2 = (int)(2 * L * Dp);
-    const size_t need[] = {mavlm_gemm_split_ws_floats(r, dp, d, MAVLM_EPI_BIAS, dp),      // q projection
-                           mavlm_gemm_split_ws_floats(r, d, dp, MAVLM_EPI_F32, d),        // attention out dense
-                           mavlm_gemm_split_ws_floats(r, in, d, MAVLM_EPI_RELU, in),      // MLP up / fuser first
-                           mavlm_gemm_split_ws_floats(r, d, in, MAVLM_EPI_F32, d),        // MLP down / fuser second
-                           mavlm_gemm_split_ws_floats(sk, l2, d, MAVLM_EPI_BIAS, l2),     // chunk K/V
-                           mavlm_gemm_split_ws_floats(r, 2 * dp, d, MAVLM_EPI_BIAS, 2 * dp)};   // evolution K/V
     x->gsplit_floats = 0;
-    for (size_t n : need) x->gsplit_floats = n > x->gsplit_floats ? n : x->gsplit_floats;
+    const int rows_[2] = {(int)R, (int)(R1 * B)};              // every row of the memory / the rows of a row shard
+    for (int r : rows_) {
+      const int sk = (int)S, d = (int)D, dp = (int)Dp, in = (int)I, l2 = (int)(2 * L * Dp);
+      const size_t need[] = {mavlm_gemm_split_ws_floats(r, dp, d, MAVLM_EPI_BIAS, dp),      // q projection
+                             mavlm_gemm_split_ws_floats(r, d, dp, MAVLM_EPI_F32, d),        // attention out dense
+                             mavlm_gemm_split_ws_floats(r, in, d, MAVLM_EPI_RELU, in),      // MLP up / fuser first
+                             mavlm_gemm_split_ws_floats(r, d, in, MAVLM_EPI_F32, d),        // MLP down / fuser second
+                             mavlm_gemm_split_ws_floats(sk, l2, d, MAVLM_EPI_BIAS, l2),     // chunk K/V
+                             mavlm_gemm_split_ws_floats(r, 2 * dp, d, MAVLM_EPI_BIAS, 2 * dp)};   // evolution K/V
+      for (size_t n : need) x->gsplit_floats = n > x->gsplit_floats ? n : x->gsplit_floats;
+    }
   }
   o += al(x->gsplit_floats * 4);
   // scratch of the frame-score variant of the last formation layer's forward (attention3.hip): (a, m) per (head, memory
@@ -170,7 +182,7 @@ int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const 
                const void* V, int ldv, long long kv_bs, int S, void* out, float* lse2, bool frames = false,
                int* frame_rows = nullptr) {
   const mavlm_config& c = x->cfg;
-  const int B = nbatch(c), R1 = c.mem_tokens * c.patches, R = R1 * B, D = c.hidden, H = c.heads, dt = c.dtype,
+  const int B = nbatch(c), R1 = q_tokens(c) * c.patches, R = R1 * B, D = c.hidden, H = c.heads, dt = c.dtype,
             Dp = padded_width(c);
   MAVLM_TRY(gemm_x(x, s, xq, D, aw.wq, D, aw.bq, ws(x, x->o_q), Dp, R, Dp, D, MAVLM_EPI_BIAS));
   mavlm_attn_args a;
@@ -206,7 +218,7 @@ int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const 
 // that split their keys - mavlm_frame_scores_fused; a row batch never splits)
 bool step_frames_fused(const mavlm_ctx* x, int S) {
   const mavlm_config& c = x->cfg;
-  const int B = nbatch(c), R1 = c.mem_tokens * c.patches;
+  const int B = nbatch(c), R1 = q_tokens(c) * c.patches;
   if (wide_heads(c) || x->o_fscr == 0) return false;
   if (B == 1) return mavlm_frame_scores_fused(R1, S, c.heads, c.patches) != 0;
   return g_mavlm_frame_score_mode == 1 && g_mavlm_attn_impl != 2 && mavlm_attention_frames_supported(R1, S, c.heads * B, c.patches);
@@ -214,11 +226,13 @@ bool step_frames_fused(const mavlm_ctx* x, int S) {
 
 int step_impl(mavlm_ctx* x, const void* const* segs, int32_t F, void* frame_scores, int32_t scores_f32, hipStream_t s) {
   const mavlm_config& c = x->cfg;
-  const int B = nbatch(c), R1 = c.mem_tokens * c.patches, R = R1 * B, D = c.hidden, I = c.inter, L = c.depth, H = c.heads,
-            dt = c.dtype;
+  // R1: memory rows of one video (keys of the evolution, ring strides); Rq1: the rows of them this context computes (row
+  // shard: q_tokens memory tokens from row r0 on; else all); R: rows of the row-wise operators
+  const int B = nbatch(c), R1 = c.mem_tokens * c.patches, Rq1 = q_tokens(c) * c.patches, r0 = q_row0(c), R = Rq1 * B,
+            D = c.hidden, I = c.inter, L = c.depth, H = c.heads, dt = c.dtype;
   const int Dp = padded_width(c);
   const int S = F * c.patches;
-  const size_t slot_bytes = (size_t)R * D * 2;                // one FIFO slot: the newest memory of every video, [B, R1, D]
+  const size_t slot_bytes = (size_t)R1 * B * D * 2;           // one FIFO slot: the newest memory of every video, [B, R1, D]
   const int cap = c.cache_cap;
   const int n = x->steps < cap ? x->steps : cap;
   // evolution K/V ring: [B][cap][R1][2 Dp] - the keys of ONE video are contiguous over its slots
@@ -228,21 +242,22 @@ int step_impl(mavlm_ctx* x, const void* const* segs, int32_t F, void* frame_scor
   if (x->steps > 0) {
     // ---- memory evolution (MemoryController.py:89-97): q = newest memory, kv = every cached memory.
     const int newest = (x->steps - 1) % cap;
-    const char* mem_new = (const char*)x->b.mem_ring + (size_t)newest * slot_bytes;
+    const char* mem_new = (const char*)x->b.mem_ring + (size_t)newest * slot_bytes;     // ALL rows (row shard: gathered)
     char* kv_new = (char*)x->b.evo_kv_ring + (size_t)newest * R1 * 2 * Dp * 2;
     // K/V of a cached memory are row-independent -> project each memory once, when it becomes the newest.  Row batch: ONE
     // GEMM over the stacked rows, block b of R1 rows lands in video b's ring
     {
       mavlm_gemm_args g;
       g.A = mem_new; g.lda = D; g.W = x->w.w_kv_evo; g.ldw = D; g.bias = x->w.b_kv_evo; g.res = nullptr; g.ldr = 0;
-      g.C = kv_new; g.ldc = 2 * Dp; g.M = R; g.N = 2 * Dp; g.K = D; g.epilogue = MAVLM_EPI_BIAS;
+      g.C = kv_new; g.ldc = 2 * Dp; g.M = R1 * B; g.N = 2 * Dp; g.K = D; g.epilogue = MAVLM_EPI_BIAS;
       if (B > 1) { g.c_rpb = R1; g.c_nb = B; g.c_bstride = evo_bs; }
-      else if (x->gsplit_floats && mavlm_gemm_split_ws_floats(R, 2 * Dp, D, MAVLM_EPI_BIAS, 2 * Dp) <= x->gsplit_floats)
+      else if (x->gsplit_floats && mavlm_gemm_split_ws_floats(R1, 2 * Dp, D, MAVLM_EPI_BIAS, 2 * Dp) <= x->gsplit_floats)
         g.splitk_ws = (float*)ws(x, x->o_gsplit);
       MAVLM_TRY(mavlm_launch_gemm(g, dt, s));
     }
     const char* kv = (const char*)x->b.evo_kv_ring;
-    int rc = attn_block(x, s, x->w.evo, mem_new, kv, 2 * Dp, kv + (size_t)Dp * 2, 2 * Dp, evo_bs, n * R1, ws(x, x->o_mA), nullptr);
+    int rc = attn_block(x, s, x->w.evo, mem_new + (size_t)r0 * D * 2, kv, 2 * Dp, kv + (size_t)Dp * 2, 2 * Dp, evo_bs, n * R1,
+                        ws(x, x->o_mA), nullptr);
     if (rc) return rc;
     cur = ws(x, x->o_mA);
   }
@@ -251,7 +266,10 @@ int step_impl(mavlm_ctx* x, const void* const* segs, int32_t F, void* frame_scor
   // does not depend on the memory rows: nothing to gain from stacking, and the videos' frames stay where they are)
   char* kvs = ws(x, x->o_kv);
   const int ldkv = 2 * L * Dp;
-  for (int b = 0; b < B; ++b)
+  const bool pre = B == 1 && x->pre_seg == segs[0] && x->pre_F == F;       // mavlm_project_chunk ran for exactly this chunk
+  x->pre_seg = nullptr;
+  x->pre_F = 0;
+  for (int b = 0; b < B && !pre; ++b)
     MAVLM_TRY(gemm_x(x, s, segs[b], D, x->w.w_kv_seg, D, x->w.b_kv_seg, kvs + (size_t)b * S * ldkv * 2, ldkv, S, ldkv, D,
                      MAVLM_EPI_BIAS));
   for (int l = 0; l < L; ++l) {
@@ -271,15 +289,15 @@ int step_impl(mavlm_ctx* x, const void* const* segs, int32_t F, void* frame_scor
     } else if (want_scores) {
       for (int b = 0; b < B; ++b) {          // (one pass per video: the column-sum kernels know nothing of the row batch)
         mavlm_colsum_args ca;
-        ca.Q = ws(x, x->o_q) + (size_t)b * R1 * Dp * 2; ca.ldq = Dp; ca.K = Kl + (size_t)b * S * ldkv * 2; ca.ldk = ldkv;
-        ca.lse2 = lse + (size_t)b * H * R1; ca.part = (float*)ws(x, x->o_part);
-        ca.R = R1; ca.S = S; ca.H = H; ca.scale = attn_scale(c);
+        ca.Q = ws(x, x->o_q) + (size_t)b * Rq1 * Dp * 2; ca.ldq = Dp; ca.K = Kl + (size_t)b * S * ldkv * 2; ca.ldk = ldkv;
+        ca.lse2 = lse + (size_t)b * H * Rq1; ca.part = (float*)ws(x, x->o_part);
+        ca.R = Rq1; ca.S = S; ca.H = H; ca.scale = attn_scale(c);
         int planes = 1;
         if (wide_heads(c)) {
           MAVLM_TRY(mavlm_launch_colsum_hd(ca, c.hidden / c.heads, dt, s));
         } else {
           ca.keep_planes = 1;                   // frame_scores_kernel adds the planes (same order as the reduce kernel)
-          planes = mavlm_colsum_planes(R1, S, H);
+          planes = mavlm_colsum_planes(Rq1, S, H);
           MAVLM_TRY(mavlm_launch_colsum(ca, dt, s));
         }
         void* fs = scores_f32 ? (void*)((float*)frame_scores + (size_t)b * F) : (void*)((uint16_t*)frame_scores + (size_t)b * F);
@@ -290,7 +308,8 @@ int step_impl(mavlm_ctx* x, const void* const* segs, int32_t F, void* frame_scor
     MAVLM_TRY(gemm_x(x, s, ws(x, x->o_a), D, x->w.w_up[l], D, x->w.b_up[l], ws(x, x->o_h), I, R, I, D, MAVLM_EPI_RELU));
     MAVLM_TRY(gemm_x(x, s, ws(x, x->o_h), I, x->w.w_down[l], I, x->w.b_down[l], ws(x, x->o_pre), D, R, D, I,
                      MAVLM_EPI_F32));
-    void* dst = last ? (void*)((char*)x->b.mem_ring + (size_t)(x->steps % cap) * slot_bytes)
+    // (row shard: this context's rows of the slot; the host all-gathers the other ranks' rows into it before the next step)
+    void* dst = last ? (void*)((char*)x->b.mem_ring + (size_t)(x->steps % cap) * slot_bytes + (size_t)r0 * D * 2)
                      : (void*)ws(x, (l & 1) ? x->o_mA : x->o_mB);
     MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), ws(x, x->o_a), D, x->w.ln2_g[l], x->w.ln2_b[l], dst, R, D,
                                      c.eps, dt, s));
@@ -421,6 +440,8 @@ int mavlm_bind_buffers(mavlm_ctx* x, const mavlm_buffers* b) {
 int mavlm_reset(mavlm_ctx* x) {
   if (!x) return MAVLM_E_ARG;
   x->steps = 0;
+  x->pre_seg = nullptr;
+  x->pre_F = 0;
   return 0;
 }
 
@@ -452,6 +473,18 @@ int mavlm_step_batch(mavlm_ctx* x, const void* const* segs, int32_t F, void* fra
 }
 
 int mavlm_batch(const mavlm_ctx* x) { return x ? nbatch(x->cfg) : MAVLM_E_ARG; }
+
+int mavlm_project_chunk(mavlm_ctx* x, const void* seg, int32_t F, void* stream) {
+  if (!x || !seg) return MAVLM_E_ARG;
+  if (!x->has_w || !x->has_b || nbatch(x->cfg) != 1) return MAVLM_E_STATE;
+  const mavlm_config& c = x->cfg;
+  if (F <= 0 || F > c.max_chunk_frames) return MAVLM_E_SHAPE;
+  const int D = c.hidden, Dp = padded_width(c), ldkv = 2 * c.depth * Dp, S = F * c.patches;
+  MAVLM_TRY(gemm_x(x, (hipStream_t)stream, seg, D, x->w.w_kv_seg, D, x->w.b_kv_seg, ws(x, x->o_kv), ldkv, S, ldkv, D, MAVLM_EPI_BIAS));
+  x->pre_seg = seg;
+  x->pre_F = F;
+  return 0;
+}
 
 namespace {
 int fuse_emit_impl(mavlm_ctx* x, const void* const* x_pe, const int64_t* fine_idx, int32_t n_fine, const void* mem_prompt,

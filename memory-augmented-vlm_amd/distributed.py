@@ -59,13 +59,18 @@ class RowShardedMemory:
 
     The chunks of a video cannot be sharded (step t reads the FIFO of steps < t), but inside a step every operation on
     the memory side is row-independent: q projection, attention rows, out dense, LayerNorm, MLP.  Rank g owns the rows
-    of memory tokens [g*M/W, (g+1)*M/W); per step it
-      * projects the chunk's K/V itself (redundant on every rank: 6 % of a step's flops at M = 64, no communication),
-      * runs evolution + formation for its own rows only (the small-grid paths of the kernels - split-KV attention,
-        split-K GEMMs - keep the chip busy at 1/W of the rows),
-      * all-gathers the new memory rows (M*P*D*2 bytes in total: 25.7 MB at M = 64) so that every rank holds the full
-        FIFO entry, and all-reduces the per-frame attention scores (F floats).
-    Exact: same values as the single-GPU path up to fp32 summation order (the kernel plan depends on the row count).
+    of memory tokens [g*M/W, (g+1)*M/W) and runs the FUSED engine on them (`mavlm_config.q_tokens`: one `mavlm_step` per
+    chunk - the same launch sequence, kernels and device-resident K/V ring as the single-GPU path; round 3).  Per step:
+      * the chunk's K/V projection and the K/V projection of the newest (gathered) memory are computed on every rank
+        (redundant: 6 % + 3 % of a step's flops at M = 64, no communication),
+      * evolution + formation run for the rank's own rows only (the small-grid plans of the kernels - split-KV attention,
+        split-K GEMMs - keep the chip busy at 1/W of the rows); the last LayerNorm writes them into the rank's rows of the
+        FIFO slot,
+      * ONE all-gather, in place over the slot (M*P*D*2 bytes in total: 25.7 MB at M = 64), issued `async_op=True`, gives
+        every rank the full entry for the next step's evolution; it overlaps the NEXT chunk's K/V projection
+        (`step(seg, prefetch=next_seg)` -> `mavlm_project_chunk`), the one GEMM of a step that does not read the memory;
+      * the per-frame attention scores are partial sums over the rank's query rows: all-reduced (F floats, fp32).
+    Exact: same values as the single-GPU path up to fp32 summation order (the kernel plans depend on the row count).
     Inference only.  `projector` is a TransformerProjector whose parameters are replicated on every rank."""
 
     def __init__(self, projector, group=None):
@@ -76,59 +81,78 @@ class RowShardedMemory:
         M = projector.num_memory_tokens
         if M % self.world:
             raise ValueError(f"num_memory_tokens ({M}) must be a multiple of the group size ({self.world})")
-        self.rows = (M // self.world) * projector.patch_size
-        self.r0 = self.rank * self.rows
-        self.reset()
+        self.tokens = M // self.world
+        self.token0 = self.rank * self.tokens
+        self._engine = None
+        self._pending = None
+        self._n = 0
+
+    # -- engine (a row shard of the projector's fused engine) ------------------------------------------------
+    def _eng(self, device, dtype, frames):
+        from .model.memory_module.MemoryController import _Engine
+        p = self.p
+        need = max(int(getattr(p.config, "max_chunk_frames", 32)), int(frames or 0))
+        e = self._engine
+        if e is None or e.device != device or e.dtype != dtype or e.c.max_chunk_frames < need:
+            if e is not None and e.steps:
+                raise RuntimeError("device / dtype / chunk size changed in the middle of a video")
+            e = self._engine = _Engine(p, device, dtype, need, shard=(self.token0, self.tokens) if self.world > 1 else None)
+        v = p._param_version()
+        if e.version != v:
+            fuser, temb = p._fuser_refs if p._fuser_refs is not None else (None, None)
+            e.pack(p, fuser, temb)
+            e.version = v
+        return e
 
     def reset(self):
-        self.cache, self._kv, self._steps = [], [], 0
+        from . import _capi as capi
+        self.wait()
+        self._n = 0
+        if self._engine is not None:
+            capi.check(capi.lib().mavlm_reset(self._engine.ctx), "mavlm_reset")
+            if self.p._weights_maybe_stale():
+                self._engine.version = None
+
+    def wait(self):
+        """the all-gather of the newest memory is complete (the compute stream is ordered behind it)"""
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None
+
+    @property
+    def cache(self):
+        e = self._engine
+        if e is None:
+            return []
+        cap = e.c.cache_cap
+        n = min(self._n, cap)
+        return [e.mem_ring[(self._n - n + i) % cap] for i in range(n)]
 
     @torch.no_grad()
-    def step(self, image_features: torch.Tensor):
-        """One chunk [F,P,D] (already PE-added).  Returns (memory_cache: list of full [M,P,D] memories, scores [F])."""
-        from . import _autograd as ag
+    def step(self, image_features: torch.Tensor, prefetch: Optional[torch.Tensor] = None):
+        """One chunk [F,P,D] (already PE-added).  `prefetch`: the NEXT chunk (the tensor the next `step` will be given): its
+        K/V projection is enqueued while the all-gather of this step's memory is in flight.
+        Returns (memory_cache: list of full [M,P,D] memories, oldest first; scores [F])."""
+        from . import _capi as capi
         from . import _ops as ops
         p = self.p
         F, P, D = image_features.shape
-        M = p.num_memory_tokens
-        R, dt = M * P, image_features.dtype
-        cap = int(getattr(p.config, "cache_cap", 10))
-        frames = image_features.reshape(F * P, D)
-        sl = slice(self.r0, self.r0 + self.rows)
-        if self.cache:
-            evo = p.memory_update_attention
-            while len(self._kv) < len(self.cache):                       # K/V of a cached memory: once, on every rank
-                self._kv.append(ag.project_kv([evo], self.cache[len(self._kv)].reshape(R, D))[0])
-            first = self._steps - len(self._kv)
-            order = sorted(range(len(self._kv)), key=lambda i: (first + i) % cap)   # ring order, as the fused step
-            k = torch.cat([self._kv[i][0] for i in order], dim=0)
-            v = torch.cat([self._kv[i][1] for i in order], dim=0)
-            m, _ = ag.attention_block(evo, self.cache[-1].reshape(R, D)[sl].contiguous(), k, v)
-        else:
-            m = (p.initial_memory + p.memory_pos_embed).to(dt).reshape(R, D)[sl].contiguous()
-        atts = [layer.memory_segment_fusion_attention for layer in p.layers]
-        kvs = ag.project_kv(atts, frames)
-        stats = None
-        for li, layer in enumerate(p.layers):
-            a, stats = ag.attention_block(atts[li], m, kvs[li][0], kvs[li][1], want_stats=li == len(p.layers) - 1,
-                                          patches_per_frame=P)
-            m = ag.mlp_block(layer, a)
-        full = torch.empty((R, D), device=m.device, dtype=dt)
+        x = image_features.contiguous()
+        e = self._eng(x.device, x.dtype, F)
+        lib = capi.lib()
+        self.wait()                                               # (normally already complete: see below)
+        scores = torch.empty(F, device=x.device, dtype=torch.float32)
+        capi.check(lib.mavlm_step(e.ctx, x.data_ptr(), F, scores.data_ptr(), 1, ops.stream_ptr()), "mavlm_step")
+        self._n += 1
+        slot = e.mem_ring[lib.mavlm_newest_slot(e.ctx)]            # [M,P,D]: this rank's rows are written, the others stale
         if self.world > 1:
-            dist.all_gather_into_tensor(full.view(-1), m.contiguous().view(-1), group=self.group)
-        else:
-            full.copy_(m)
-        q, kk, lse = stats
-        att = atts[-1]
-        hdw = 128 if att.attention_head_size <= 128 else att.attention_head_size
-        part = ops.attention_colsum(q, kk, lse, att.num_attention_heads, head_dim=hdw,
-                                    scale=ops.attn_scale(att.attention_head_size)).sum(dim=0)     # [S], local queries
-        if self.world > 1:
-            dist.all_reduce(part, group=self.group)
-        scores = part.view(F, P).mean(dim=1).to(dt)
-        self.cache.append(full.view(M, P, D))
-        self._steps += 1
-        if len(self.cache) > cap:
-            drop = len(self.cache) - cap
-            self.cache, self._kv = self.cache[drop:], self._kv[drop:]
-        return self.cache, scores
+            own = slot[self.token0:self.token0 + self.tokens]
+            send = own if dist.get_backend(self.group) == "nccl" else own.clone()    # (in place over the slot: NCCL only)
+            self._pending = dist.all_gather_into_tensor(slot.view(-1), send.reshape(-1), group=self.group, async_op=True)
+            swork = dist.all_reduce(scores, group=self.group, async_op=True)
+            if prefetch is not None:                              # overlaps the all-gather: needs nothing of the memory
+                nx = prefetch.contiguous()
+                capi.check(lib.mavlm_project_chunk(e.ctx, nx.data_ptr(), nx.shape[0], ops.stream_ptr()), "mavlm_project_chunk")
+            swork.wait()
+            self.wait()
+        return self.cache, scores.to(x.dtype)

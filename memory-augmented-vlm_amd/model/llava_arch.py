@@ -12,8 +12,10 @@ Mirrors the memory-specific parts of the reference's llava/model/llava_arch.py s
                             PE add -> chunk loop (mavlm_step) -> fuser MLP + type add + prompts/newlines concat
                             (mavlm_fuse_emit) written straight into one token block.
 
-Out of scope here (stay with the backbone / next rows of SURVEY.md §8f): building the vision tower and projector,
-the image (non-video) merge modes, anyres unpadding.  Those branches raise NotImplementedError.
+Non-video inputs behave as in the reference (round 3): a plain image batch takes the reference's tensor branch (:703,
+backbone ops, restated in torch); a list without a video fails as the reference's memory loop does (IndexError); images
+beside the video are dropped as the reference drops them.  The anyres / multi-patch merge modes (:630-697) are unreachable
+in the reference's memory branch (its feature list only ever holds the memory and the fine frames) and are not restated.
 """
 import math
 import random
@@ -471,15 +473,37 @@ class LlavaMetaForCausalLM:
             return input_ids, position_ids, attention_mask, past_key_values, None, labels        # :392-394
         if isinstance(modalities, str):
             modalities = [modalities]
+        model = self.get_model()
         if not (type(images) is list or images.ndim == 5):
-            raise NotImplementedError("plain image batches bypass the memory path (llava_arch.py:703): backbone-only")
+            # A plain [N,3,H,W] image batch (llava_arch.py:703): the reference encodes it and then - its prompt insertion is
+            # unconditional (:705-731) - uses the features of image 0 as "memory" and of image 1 as "frames" (an IndexError
+            # for a single image).  Backbone ops only; restated as it behaves.
+            feats = self.encode_images(images)                                                       # :703
+            dev = feats.device
+            mem_prompt = model.embed_tokens(torch.tensor([MEMORY_PROMPT_IDS], device=dev)).squeeze(0)
+            frame_prompt = model.embed_tokens(torch.tensor([FRAME_PROMPT_IDS], device=dev)).squeeze(0)
+            drop = self.get_synced_dropout_decision(prob=0.5) and bool(getattr(self, "training", False)) and \
+                bool(getattr(self.config, "dropout_frames", False))                                  # :719-720
+            if drop:
+                tokens = torch.cat((mem_prompt, feats[0]), dim=0)                                    # :722-725
+            else:
+                tokens = torch.cat((mem_prompt, feats[0], frame_prompt, feats[1]), dim=0)            # :729-731
+            return splice_into_text(self, model, [tokens], input_ids, position_ids, attention_mask, past_key_values, labels)
         images = [x.unsqueeze(0) if x.ndim == 3 else x for x in images] if type(images) is list else list(images)
-        if len(images) != 1 or modalities[0] != "video":
-            raise NotImplementedError("the memory path supports one video per forward (llava_arch.py:436)")
+        vids = [i for i in range(min(len(modalities), len(images))) if modalities[i] == "video"]     # :403-406
+        if not vids:
+            # the reference: every non-video entry is skipped by the memory loop (:487-490), `image_features` ends up empty
+            # and the prompt insertion indexes it (:722 / :730)
+            raise IndexError("list index out of range (no video among `images`: the reference's memory branch skips "
+                             "non-video entries, llava_arch.py:487-490, and then indexes an empty feature list, :730)")
+        if len(vids) != 1:
+            raise NotImplementedError("the memory path supports one video per forward (llava_arch.py:436: 'Now support "
+                                      "only batch size of 1'; a second video fails the reference's patch-grid assert, :636)")
+        # non-video entries beside the video are encoded and then DROPPED by the reference (:487-490, 556): dropped here too
+        images = [images[vids[0]]]
         if getattr(self.config, "mm_newline_position", "one_token") != "one_token" or \
                 "unpad" not in getattr(self.config, "mm_patch_merge_type", "flat"):
             raise NotImplementedError("memory path: mm_newline_position='one_token' with an *_unpad merge type only")
-        model = self.get_model()
         video = images[0]
         idx_cpu = sample_frame_indices(video.shape[0])                                          # :437-451
         feats = self.encode_images(video[idx_cpu.to(video.device)])                             # :457-481

@@ -154,14 +154,16 @@ class TransformerLayer(nn.Module):
 class _Engine:
     """Owns the C handle, the packed parameter views and the device buffers of one TransformerProjector."""
 
-    def __init__(self, proj: "TransformerProjector", device, dtype, max_chunk_frames, batch: int = 1):
+    def __init__(self, proj: "TransformerProjector", device, dtype, max_chunk_frames, batch: int = 1, shard=None):
         cfg = proj.config
         self.device, self.dtype = device, dtype
         self.batch = int(batch)
+        self.shard = tuple(shard) if shard else None      # (first memory token, tokens) this engine computes: row shard
         self.c = capi.Config(hidden=cfg.mm_hidden_size, heads=cfg.mm_num_attention_heads, patches=cfg.patch_size,
                              mem_tokens=cfg.num_memory_tokens, depth=cfg.depth, inter=cfg.mm_intermediate_size,
                              cache_cap=getattr(cfg, "cache_cap", 10), max_chunk_frames=max_chunk_frames,
-                             dtype=ops.dtype_code(dtype), eps=cfg.mm_layer_norm_eps, batch=self.batch)
+                             dtype=ops.dtype_code(dtype), eps=cfg.mm_layer_norm_eps, batch=self.batch,
+                             q_token0=self.shard[0] if self.shard else 0, q_tokens=self.shard[1] if self.shard else 0)
         lib = capi.lib()
         h = capi.vp()
         capi.check(lib.mavlm_create(self.c, h), "mavlm_create")
@@ -238,6 +240,8 @@ class _Engine:
         R, D = self.c.mem_tokens * self.c.patches, self.c.hidden
         # initial_memory + memory_pos_embed in the parameter dtype, then cast (MemoryController.py:123-124)
         mem0 = (proj.initial_memory + proj.memory_pos_embed).reshape(R, D)
+        if self.shard:                                          # row shard: the owned rows only
+            mem0 = mem0[self.shard[0] * self.c.patches:(self.shard[0] + self.shard[1]) * self.c.patches]
         W.mem0 = w16("mem0", mem0.repeat(self.batch, 1) if self.batch > 1 else mem0)     # [B*R, D]: every video starts from it
         ats = [l.memory_segment_fusion_attention for l in proj.layers]
         W.w_kv_seg = w16("wkv", torch.cat([pad_out(t) for a in ats for t in (a.k_proj.weight, a.v_proj.weight)], dim=0))

@@ -1,7 +1,9 @@
 #!/bin/bash
 # builds lib/exp/libmavlm_stamps.so from the CURRENT csrc with s_memtime stamps in the attn_fwd3 tile loop
 set -e
-rm -rf /tmp/stamp && mkdir -p /tmp/stamp && cp -r /root/repo/memory-augmented-vlm_amd/csrc /tmp/stamp/csrc && mkdir -p /tmp/stamp/include && cp /root/repo/include/mavlm.h /tmp/stamp/include/
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+[ -d "$ROOT/memory-augmented-vlm_amd/csrc" ] || { echo "repository root not found: $ROOT" >&2; exit 1; }
+rm -rf /tmp/stamp && mkdir -p /tmp/stamp && cp -r "$ROOT/memory-augmented-vlm_amd/csrc" /tmp/stamp/csrc && mkdir -p /tmp/stamp/include && cp "$ROOT/include/mavlm.h" /tmp/stamp/include/
 cd /tmp/stamp/csrc && sed -i 's#"../../include/mavlm.h"#"../include/mavlm.h"#' *.hip *.h
 python - <<'EOF'
 p='/tmp/stamp/csrc/attention3.hip'
@@ -72,5 +74,7 @@ rep('''  // ---- epilogue: O[q][h*128 + 32db + 8g + 4hh + 0..3] = O^T / l''','''
   // ---- epilogue: O[q][h*128 + 32db + 8g + 4hh + 0..3] = O^T / l''')
 open(p,'w').write(s)
 EOF
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o /root/repo/memory-augmented-vlm_amd/lib/exp/libmavlm_stamps.so gemm.hip gemm256.hip gemm256p.hip attention.hip attention3.hip attention_hd.hip attention_bwd.hip backward.hip variants.hip elementwise.hip mavlm_api.hip prof.hip 2>&1 | grep -E "error" | head || true
-ls -la /root/repo/memory-augmented-vlm_amd/lib/exp/libmavlm_stamps.so
+mkdir -p "$ROOT/memory-augmented-vlm_amd/lib/exp"
+# (a failed build fails the script: no pipe that swallows hipcc's status)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o "$ROOT/memory-augmented-vlm_amd/lib/exp/libmavlm_stamps.so" gemm.hip gemm256.hip gemm256p.hip attention.hip attention3.hip attention_hd.hip attention_bwd.hip backward.hip variants.hip elementwise.hip mavlm_api.hip prof.hip
+ls -la "$ROOT/memory-augmented-vlm_amd/lib/exp/libmavlm_stamps.so"

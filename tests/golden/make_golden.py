@@ -333,6 +333,36 @@ def g7():
     save("g7_fullsize.npz", meta=meta(hidden=1024, wseed=71, segseed0=700, stride=997), **res)
 
 
+G7_FIFO_FRAMES = (2, 1, 2, 2, 1, 2, 1, 1, 2, 2, 1, 2, 2)      # 13 steps: the FIFO (cap 10) is full after 10, evicts 3 times
+
+
+def g7_fifo():
+    """A FIFO-wrapping chain at FULL width the HIP path can run (round 3): the checkpoint shape (8 memory tokens, D = 1024,
+    8 heads, depth 2), 13 steps of 1-2 frames - from step 10 on every append evicts the oldest memory
+    (MemoryController.py:152-154) and the evolution attends over all 10 cached memories.  Per step: strided samples + norm +
+    sum of the new memory and the frame scores of the reference's fp32 run, and the samples of its bf16 run."""
+    res = {}
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=72)
+    for dtype, sfx in ((torch.float32, ""), (torch.bfloat16, "_refbf16")):
+        m = ref_projector(cfg, w, dtype)
+        m.memory_cache = []
+        m.frame_attn_scores = []
+        for t, F in enumerate(G7_FIFO_FRAMES):
+            seg = O.bf16_round(O.hash_normal_like((F, 196, 1024), 7200 + t))
+            cache, scores = m(T(seg).to(dtype))
+            assert len(cache) == min(t + 1, 10)
+            mem = cache[-1].float().numpy().reshape(-1)
+            res[f"s{t}_sample{sfx}"] = mem[::499].copy()
+            if not sfx:
+                res[f"s{t}_norm"] = np.array(np.linalg.norm(mem.astype(np.float64)))
+                res[f"s{t}_sum"] = np.array(mem.astype(np.float64).sum())
+                res[f"s{t}_scores"] = scores[-1].numpy().copy()
+                if t == len(G7_FIFO_FRAMES) - 1:          # the whole FIFO after the last step: oldest entry = step 3's memory
+                    res["final_cache_samples"] = np.stack([c.numpy().reshape(-1)[::499] for c in cache])
+    save("g7_fifo_fullsize.npz", meta=meta(hidden=1024, wseed=72, segseed0=7200, stride=499, frames=list(G7_FIFO_FRAMES)), **res)
+
+
 # --------------------------------------------------------------------------- G8 (gradients, SURVEY.md §8f rank 3)
 G8_CASES = {"d256": (256, 7), "d1024": (1024, 61)}      # hidden (8 heads: the reference's dead reshape needs H = M = 8), stride
 
@@ -439,7 +469,7 @@ def g9():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g56", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g56", "g7", "g7fifo", "g8", "g9"]
     if "g9" in which:
         g9()
     if "g8" in which:
@@ -454,3 +484,5 @@ if __name__ == "__main__":
         g5_g6()
     if "g7" in which:
         g7()
+    if "g7fifo" in which:
+        g7_fifo()

@@ -75,7 +75,45 @@ def test_row_sharded_memory_argument_checks():
     from memory_augmented_vlm_amd import distributed as D
     proj = types.SimpleNamespace(num_memory_tokens=8, patch_size=196)
     s = D.RowShardedMemory(proj)
-    assert (s.world, s.rank, s.rows, s.r0) == (1, 0, 8 * 196, 0) and s.cache == []
+    assert (s.world, s.rank, s.tokens, s.token0) == (1, 0, 8, 0) and s.cache == []
+
+
+def _shard_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import types
+    D.init_from_env("gloo")
+    s = D.RowShardedMemory(types.SimpleNamespace(num_memory_tokens=8, patch_size=196))
+    try:
+        D.RowShardedMemory(types.SimpleNamespace(num_memory_tokens=7, patch_size=196))
+        bad = False
+    except ValueError:
+        bad = True
+    # the in-place all-gather the sharded step issues: every rank contributes its token rows of a [M, P, D] slot
+    slot = torch.zeros(8, 2, 3)
+    slot[s.token0:s.token0 + s.tokens] = rank + 1.0
+    own = slot[s.token0:s.token0 + s.tokens].clone()
+    dist.all_gather_into_tensor(slot.view(-1), own.reshape(-1))
+    q.put((rank, s.tokens, s.token0, bad, slot[:, 0, 0].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_memory_world2_partition_and_gather():
+    """world 2 over gloo: rank g owns memory tokens [4g, 4g+4); the per-step exchange (all-gather of the owned rows into the
+    FIFO slot) leaves every rank with the full entry; a token count that does not divide is refused."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[:4] for g in got] == [(0, 4, 0, True), (1, 4, 4, True)]
+    assert got[0][4] == got[1][4] == [1.0] * 4 + [2.0] * 4
 
 
 def _dropout_worker(rank, world, port, q):

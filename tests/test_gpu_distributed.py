@@ -42,8 +42,10 @@ def _worker(rank, world, port, out_dir, hidden=1024):
         for s_ in segs:
             cache, scores = proj(s_)
             ref.append((cache[-1].clone(), scores[-1].clone(), len(cache)))
+        sharded.reset()
         for t, s_ in enumerate(segs):
-            cache, scores = sharded.step(s_)
+            # (odd steps hand the next chunk over: its K/V projection runs under the all-gather, mavlm_project_chunk)
+            cache, scores = sharded.step(s_, prefetch=segs[t + 1] if t % 2 == 1 and t + 1 < len(segs) else None)
             assert len(cache) == ref[t][2]
             err = float((cache[-1].float() - ref[t][0].float()).norm() / ref[t][0].float().norm())
             serr = float((scores.float() - ref[t][1].float()).norm() / ref[t][1].float().norm())
@@ -81,13 +83,13 @@ def _oracle_chain(hidden, out_dir):
     return _ORACLE[hidden][1]
 
 
-@pytest.mark.parametrize("world,hidden,with_oracle", [(2, 1024, True), (4, 1024, True), (2, 3584, False)])
+@pytest.mark.parametrize("world,hidden,with_oracle", [(2, 1024, True), (4, 1024, True), (2, 3584, True)])
 def test_row_sharded_video_matches_single_gpu(world, hidden, with_oracle, tmp_path):
     """FIFO cap 3 over 4-5 chunks (wraps): the sharded recurrence tracks the single-GPU engine within the 16-bit chain
     noise (different kernel plans at 1/W of the rows -> different fp32 summation order; no systematic drift), and
     - independent of the engine - the CPU oracle within the calibrated chain tolerance (D = 1024).  hidden = 3584 is the
-    LLaVA-OneVision-7B width of BASELINE.json configs[3] (wide-head kernels; the single-GPU engine it is compared
-    with is itself checked against the oracle at this width in test_gpu_configs_fullsize.py)."""
+    LLaVA-OneVision-7B width of BASELINE.json configs[3] (wide-head kernels), against the oracle as well (round 3).  The
+    ranks run the FUSED engine on their row shard (mavlm_config.q_tokens), one in-place all-gather per step."""
     tols = _oracle_chain(hidden, str(tmp_path)) if with_oracle else None
     port = 29600 + world + (hidden // 1024)
     mp.spawn(_worker, args=(world, port, str(tmp_path), hidden), nprocs=world, join=True)
@@ -97,3 +99,32 @@ def test_row_sharded_video_matches_single_gpu(world, hidden, with_oracle, tmp_pa
             assert err < 6e-3 and serr < 5e-3, (rank, t, err, serr)
             if with_oracle:
                 assert 0 <= oerr < tols[t], (rank, t, oerr, tols[t])
+
+
+@pytest.mark.parametrize("mode", ["replica", "shard-video"])
+def test_bench_two_rank_rehearsal(mode, tmp_path):
+    """`bench.py --gpus 2` end to end, both modes: self-launch of the two ranks, process group, the timed loop with its
+    collectives (all-gather of the final memory state / per-step all-gather + all-reduce of the row shards), rank 0's JSON
+    line with ranks_seen == 2.  The ranks share this box's GPU and talk over gloo (`--rehearse-gloo`; the line says so)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-gloo", "--steps", "2", "--warmup", "1",
+           "--repeats", "1", "--min-seconds", "0", "--no-cpu-baseline", "--mode", mode]
+    if mode == "shard-video":
+        cmd += ["--shard-frames", "96", "--shard-hidden", "1024", "--shard-mem-tokens", "8"]
+    env = dict(os.environ, MAVLM_BENCH_M8="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"]["ranks_seen"] == 2 and out["ranks"]["rehearsal_shared_gpus"] is True
+    assert out["ranks"]["backend"] == "gloo" and out["value"] > 0 and out["config"]["mode"] == mode
+    if mode == "replica":
+        assert out["config"]["allgather_final_memory"] is True and out["scaling"] == "weak"
+    else:
+        assert out["scaling"] == "strong"

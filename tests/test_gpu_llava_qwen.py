@@ -74,10 +74,13 @@ def standalone_embeds(m, video, ids, p):
     return torch.cat([model.embed_tokens(row[:p]), toks, model.embed_tokens(row[p + 1:])])[None]
 
 
-@pytest.mark.parametrize("name,hidden,layers,heads,kv,inter", [("qwen2-0.5b-shape", 896, 2, 14, 2, 4864),
-                                                                ("ov-7b-shape", 3584, 1, 28, 4, 18944)])
-def test_forward_and_generate_through_real_qwen2_backbone(name, hidden, layers, heads, kv, inter):
-    m = build(hidden, layers, heads, kv, inter)
+@pytest.mark.parametrize("name,hidden,layers,heads,kv,inter,M", [("qwen2-0.5b-shape", 896, 2, 14, 2, 4864, 8),
+                                                                  ("ov-7b-shape", 3584, 1, 28, 4, 18944, 8),
+                                                                  ("configs1-literal-64-memory-tokens", 896, 2, 14, 2, 4864, 64)])
+def test_forward_and_generate_through_real_qwen2_backbone(name, hidden, layers, heads, kv, inter, M):
+    """(third case = BASELINE.json configs[1] as literally stated: 64 memory tokens feeding a Qwen2-0.5B-shape backbone - a
+    31 381-token prefill)"""
+    m = build(hidden, layers, heads, kv, inter, mem_tokens=M)
     torch.manual_seed(11)
     video = torch.randn(64, 3, 54, 54, device="cuda", dtype=torch.bfloat16)
     ids, p = prompt()
@@ -94,7 +97,7 @@ def test_forward_and_generate_through_real_qwen2_backbone(name, hidden, layers, 
         ref = standalone_embeds(m, video, ids, p)
         out = m(input_ids=ids, labels=labels, images=[video], modalities=["video"],
                 attention_mask=torch.ones_like(ids), position_ids=torch.arange(ids.shape[1], device="cuda")[None])
-    rows = arch.video_token_rows(64, 8)
+    rows = arch.video_token_rows(64, M)
     L = ids.shape[1] - 1 + rows
     assert m.multimodal_prefills == 1
     assert seen["emb"].shape == (1, L, hidden) and torch.equal(seen["emb"], ref)         # bit for bit
@@ -152,8 +155,10 @@ def test_training_step_through_the_backbone_reaches_the_memory_parameters():
     assert torch.equal(seen["emb"][0, :a], ref[0, :a]) and torch.equal(seen["emb"][0, b:], ref[0, b:])
     d = (seen["emb"][0, a:b].float() - ref[0, a:b].float()).norm() / ref[0, a:b].float().norm()
     # (a freshly initialised fuser - N(0, 0.02) weights - has small pre-activations, where rounding them to 16 bits costs
-    # the GELU output up to ~2 ulp: 4e-3 measured; the golden-weight case of test_full_token_block_gradients sits at 2e-3)
-    assert float(d) < 1e-2
+    # the GELU output up to ~2 ulp: 3.9e-3 measured, gate = 1.5 x that; the golden-weight case of
+    # test_full_token_block_gradients sits at 2e-3)
+    print(f"training-mode vs inference-mode fused rows: {float(d):.2e}")
+    assert float(d) < 6e-3
     got = {n_: p_.grad for n_, p_ in m.named_parameters() if p_.requires_grad}
     assert got and all(g is not None and torch.isfinite(g.float()).all() for g in got.values())
     nz = [n_ for n_, g in got.items() if float(g.float().abs().max()) > 0]

@@ -82,6 +82,34 @@ def test_gemm_tile_height_is_a_pure_speed_choice():
         assert torch.equal(o, outs[1])
 
 
+def test_gemm_256_tile_kernels_with_l2_resident_weights():
+    """The 256-column-tile kernels re-stage a B half-tile (LDS-DMA) in the barrier interval in which the other wave group
+    retires its last reads of it; the margin is the DMA's latency (gemm256.hip, hazard table: WAR).  The shortest latency
+    is a weight matrix that stays in L2 (small N*K) streamed over many K-tiles: integer data, exact against numpy, for both
+    kernels and both tile heights, repeated - and bit-identical to the 128-tile kernel (which has no such interval)."""
+    lib = capi.lib()
+    M, N, K = 7168, 256, 4096                                   # W = 2 MiB: L2-resident; 64 K-tiles
+    A = _int_mat((M, K), 21)
+    W = _int_mat((N, K), 22)
+    b = _int_mat((N,), 23).astype(np.float32)
+    ref = A @ W.T + b
+    a_, w_, b_ = to_dev(A), to_dev(W), f32_dev(b)
+    ar = to_dev(O.bf16_round(O.hash_normal_like((M, K), 24)))
+    try:
+        lib.mavlm_set_gemm_tile(128)
+        base = ops.linear(ar, w_, b_, capi.EPI_F32).clone()
+        for tile in (256, 257):
+            for rows in (256, 224):
+                lib.mavlm_set_gemm_tile(tile)
+                lib.mavlm_set_gemm_rows(rows)
+                for _ in range(10):
+                    np.testing.assert_array_equal(to_np(ops.linear(a_, w_, b_, capi.EPI_F32)), ref)
+                    assert torch.equal(ops.linear(ar, w_, b_, capi.EPI_F32), base)
+    finally:
+        lib.mavlm_set_gemm_tile(0)
+        lib.mavlm_set_gemm_rows(0)
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(1568, 1024, 1024, "bias"), (588, 4096, 1024, "bias"), (777, 512, 4096, "gelu"),
                                        (300, 4096, 1024, "relu")])
 def test_linear_random_vs_oracle(M, N, K, epi, gemm_tile):

@@ -245,6 +245,44 @@ def test_golden_g7_reference_fullsize(tag, M, F, steps):
         assert errs[t] / errs[t - 1] <= 1.25 * ref_errs[t] / ref_errs[t - 1] + 0.05, (errs, ref_errs)
 
 
+def test_golden_g7_fifo_wrap_fullsize():
+    """The reference-pinned chain PAST the FIFO's capacity at full width (round 3): checkpoint shape (8 memory tokens,
+    D = 1024), 13 steps of 1-2 frames, cap 10 - eviction at steps 10-12 (MemoryController.py:152-154), the evolution attends
+    over all 10 cached memories.  HIP bf16 against the REFERENCE's fp32 run with the gates of the G7 test (no oracle
+    involved): at least as close as the reference's own bf16 run, unbiased, no faster drift; plus the surviving FIFO
+    entries after the last step (ring order -> FIFO order)."""
+    z, m = load_golden("g7_fifo_fullsize.npz")
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=m["wseed"])
+    proj = make_projector(cfg, w)
+    proj.memory_cache = []
+    errs, ref_errs = [], []
+    for t, F in enumerate(m["frames"]):
+        seg = O.bf16_round(O.hash_normal_like((F, 196, 1024), m["segseed0"] + t))
+        cache, scores = proj(to_dev(seg))
+        assert len(cache) == min(t + 1, 10)
+        mem = to_np(cache[-1]).reshape(-1)
+        ref = z[f"s{t}_sample"]
+        got = mem[::m["stride"]]
+        err, err_refbf16 = O.rel_l2(got, ref), O.rel_l2(z[f"s{t}_sample_refbf16"], ref)
+        d = (got - ref).astype(np.float64)
+        bias, sem = d.mean(), d.std() / math.sqrt(d.size)
+        print(f"fifo step {t} ({F} frames): HIP-bf16 vs ref-fp32 {err:.2e}; reference-bf16 vs ref-fp32 {err_refbf16:.2e}; "
+              f"mean signed error {bias:+.2e} (standard error {sem:.1e})")
+        assert err < TOL_REF_FP32 and err <= err_refbf16
+        assert abs(bias) < 4.0 * sem + 1e-6
+        assert abs(np.linalg.norm(mem.astype(np.float64)) / float(z[f"s{t}_norm"]) - 1) < 5e-3
+        assert O.rel_l2(to_np(scores[-1]), z[f"s{t}_scores"]) < 1e-2
+        errs.append(err)
+        ref_errs.append(err_refbf16)
+    for t in range(1, len(errs)):
+        assert errs[t] / errs[t - 1] <= 1.25 * ref_errs[t] / ref_errs[t - 1] + 0.05, (errs, ref_errs)
+    final = np.stack([to_np(c).reshape(-1)[::m["stride"]] for c in cache])
+    assert final.shape == z["final_cache_samples"].shape
+    for i in range(final.shape[0]):                           # oldest first: steps 3..12
+        assert O.rel_l2(final[i], z["final_cache_samples"][i]) < TOL_REF_FP32, i
+
+
 def _tiny_host(cfg: O.PathConfig, w, mode="bf16", vocab=48900):
     # LlavaMetaModel calls super().__init__(config): give it a base that accepts it
     class Base(torch.nn.Module):

@@ -210,3 +210,67 @@ def test_vision_projector_state_dict_keys_per_type():
     assert sorted(build_vision_projector(cfg).state_dict()) == ["0.bias", "0.weight", "2.bias", "2.weight"]
     cfg.mm_projector_type = "identity"
     assert not build_vision_projector(cfg).state_dict()
+
+
+def test_non_video_inputs_behave_as_the_reference_does():
+    """Non-video batches through the drop-in mixin (llava_arch.py:562-703 as the reference's memory branch actually
+    behaves; backbone ops, CPU): a plain [N,3,H,W] image batch takes the tensor branch (:703) - features of image 0 as
+    "memory", of image 1 as "frames", with the two fixed prompts around them; a list without a video fails like the
+    reference's memory loop (IndexError); two videos are refused; an image beside the video is dropped (checked on the GPU)."""
+    import types
+    import torch
+    from memory_augmented_vlm_amd.model import llava_arch as arch
+
+    D, NP = 32, 9
+
+    class Tower(torch.nn.Module):
+        num_patches_per_side = 3
+
+        def forward(self, images):
+            return images.flatten(1)[:, :NP * D].reshape(images.shape[0], NP, D)
+
+    class Base(torch.nn.Module):
+        def __init__(self, config):
+            super().__init__()
+            self.embed_tokens = torch.nn.Embedding(49000, D)
+
+    class Inner(arch.LlavaMetaModel, Base):
+        pass
+
+    class LM(arch.LlavaMetaForCausalLM, torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.config = types.SimpleNamespace(hidden_size=D, mm_patch_merge_type="spatial_unpad", mm_newline_position="one_token",
+                                                mm_spatial_pool_mode="bilinear", tokenizer_model_max_length=4096,
+                                                tokenizer_padding_side="right")
+            self.model = Inner(self.config)
+            self.model.vision_tower = Tower()
+            self.model.mm_projector = torch.nn.Identity()
+            self.model.image_newline = torch.nn.Parameter(torch.zeros(D))
+
+        def get_model(self):
+            return self.model
+
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+    torch.manual_seed(0)
+    lm = LM().eval()
+    images = torch.randn(2, 3, 10, 10)
+    ids = torch.tensor([[5, 6, arch.IMAGE_TOKEN_INDEX, 7]])
+    with torch.no_grad():
+        out = lm.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, images, modalities=["image"])
+        feats = lm.model.vision_tower(images)
+        emb = lm.model.embed_tokens
+        want = torch.cat([emb(torch.tensor([5, 6])), emb(torch.tensor(arch.MEMORY_PROMPT_IDS)), feats[0],
+                          emb(torch.tensor(arch.FRAME_PROMPT_IDS)), feats[1], emb(torch.tensor([7]))])[None]
+    assert out[0] is None and torch.equal(out[4], want)
+    with pytest.raises(IndexError):                                  # a single image: feats[1] does not exist (as the reference)
+        lm.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, images[:1], modalities=["image"])
+    with pytest.raises(IndexError, match="no video"):
+        lm.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [images[0], images[1]], modalities=["image", "image"])
+    with pytest.raises(NotImplementedError, match="one video"):
+        lm.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [images, images], modalities=["video", "video"])
+    # decode steps / no images: the early exit (:392-394)
+    assert lm.prepare_inputs_labels_for_multimodal(ids[:, :1], None, None, None, None, images)[4] is None

@@ -142,6 +142,27 @@ def test_g7_fullsize_samples(tag, M, F, steps):
         assert O.rel_l2(scores[-1], z[f"{tag}_s{t}_scores"]) < 2 * TOL
 
 
+def test_g7_fifo_wrap_fullsize_samples():
+    """The FIFO-wrapping chain at full width (checkpoint shape: 8 memory tokens, D = 1024; 13 steps of 1-2 frames, cap 10:
+    three evictions, MemoryController.py:152-154) - the oracle's fp32 mode against the reference's own fp32 run, every step,
+    and the whole FIFO after the last one (the oldest surviving entry is step 3's memory)."""
+    z, m = load_golden("g7_fifo_fullsize.npz")
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=m["wseed"])
+    rm = O.RecurrentMemory(cfg, w, "fp32")
+    rm.reset()
+    for t, F in enumerate(m["frames"]):
+        seg = O.bf16_round(O.hash_normal_like((F, 196, 1024), m["segseed0"] + t))
+        cache, scores = rm.step(seg)
+        assert len(cache) == min(t + 1, 10)
+        mem = cache[-1].reshape(-1)
+        assert O.rel_l2(mem[::m["stride"]], z[f"s{t}_sample"]) < 2 * TOL, t
+        assert abs(np.linalg.norm(mem.astype(np.float64)) / float(z[f"s{t}_norm"]) - 1) < 1e-5
+        assert O.rel_l2(scores[-1], z[f"s{t}_scores"]) < 2 * TOL
+    got = np.stack([c.reshape(-1)[::m["stride"]] for c in cache])
+    assert got.shape == z["final_cache_samples"].shape and O.rel_l2(got, z["final_cache_samples"]) < 2 * TOL
+
+
 def test_g9_transformer_fuser_variant_matches_reference():
     """Inactive MemoryFuser variant (MemoryFuser.py:4-30): oracle/variants.py against the imported reference class."""
     from oracle import variants as V
