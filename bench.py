@@ -436,6 +436,17 @@ def run_replica(args, rank, world, local, device, dist_info):
             step(one_video=True)
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t0) / 10 * 1e3
+    # the fused dense + residual + LayerNorm epilogue exchanges row statistics between workgroups with a bounded spin: a
+    # timeout (never seen) would mean a wrong result - fail loudly rather than print a number
+    ln_status = {}
+    engines = [bs._engine for bs in pool.bslots + pool1.bslots if bs._engine is not None] + \
+              [sl.recurrent_memory_transformer._engine for sl in pool.slots if sl.recurrent_memory_transformer._engine is not None]
+    for e in engines:
+        st = e.ln_exchange_status()
+        if st is not None:
+            ln_status["launches"] = ln_status.get("launches", 0) + st[0]
+            ln_status["timeouts"] = ln_status.get("timeouts", 0) + st[1]
+    assert ln_status.get("timeouts", 0) == 0, ln_status
     dom = "attention_fwd"
     di = capi.KERNEL_KINDS.index(dom)
     info = (ctypes.c_int32 * 4)()       # which instantiation the plan picks at the formation shape (S = one chunk's keys)
@@ -510,6 +521,7 @@ def run_replica(args, rank, world, local, device, dist_info):
         "single_video_latency_ms": round(single_ms, 3),
         "kernel_timing_note": f"per-kernel numbers from an instrumented pass with ONE stream (a row batch of {NB} video(s)) in flight",
         "kernels": kernels,
+        "fused_layernorm_exchange": ln_status or None,
     }
     out.update(extras)
     return out

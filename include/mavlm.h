@@ -93,7 +93,8 @@ typedef struct mavlm_buffers {
                          * holds the memory of every video of the row batch - one contiguous [B*M*P, D] GEMM operand) */
   void* evo_kv_ring;    /* [B, cache_cap, M*P, 2Dp] 16-bit K|V projections of each cached memory (projected once); the keys
                          * of ONE video are contiguous over its slots */
-  void* workspace;      /* mavlm_workspace_bytes() bytes, 256-B aligned */
+  void* workspace;      /* mavlm_workspace_bytes() bytes, 256-B aligned, ZERO-FILLED when bound (it holds the launch counter and
+                         * the exchange granules of the fused dense + residual + LayerNorm epilogue, mavlm_linear_ln) */
   size_t workspace_bytes;
 } mavlm_buffers;
 
@@ -170,6 +171,27 @@ int64_t mavlm_attention_frames_ws_floats(int32_t R, int32_t S, int32_t H, int32_
 int mavlm_attention_frames(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                            int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, int32_t patches,
                            float* ws, int64_t ws_floats, float* frame_scores, int32_t dtype, void* stream);
+/* The whole Residual block (MemoryController.py:20-29) in ONE kernel: out = LayerNorm(A . W^T + bias + res) * gamma + beta,
+ * 16-bit out [M, ldo]; res 16-bit [M, ldr]; N % 256 == 0, N <= 4096, and a grid that fills the chip
+ * (mavlm_linear_ln_ws_bytes > 0; 0 = this shape takes mavlm_linear(epilogue 4) + mavlm_layernorm).  The N / 256 workgroups
+ * of a 224/256-row block exchange their per-row (mean, centred sum of squares) through `ws` and merge them in a fixed order;
+ * the fp32 dense output never goes through HBM.  pre_out: null, or [M, N] fp32 = A . W^T + bias (what the backward needs).
+ * ws: mavlm_linear_ln_ws_bytes(M,N,K) bytes, 16-B aligned, zero-filled ONCE before its first use and then left to the
+ * launches of one stream (it carries a launch counter: nothing is re-zeroed per call, hipGraph replays are fine).
+ * mavlm_step uses the same kernel wherever it applies (mavlm_set_fused_layernorm(0): the two-kernel form). */
+int64_t mavlm_linear_ln_ws_bytes(int32_t M, int32_t N, int32_t K);
+int mavlm_linear_ln(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const void* res, int32_t ldr,
+                    const float* gamma, const float* beta, float eps, void* out, int32_t ldo, float* pre_out, int32_t M,
+                    int32_t N, int32_t K, void* ws, int64_t ws_bytes, int32_t dtype, void* stream);
+/* tuning hook: 1 (default) = the Residual blocks whose GEMM fills the chip run as one kernel (mavlm_linear_ln), 0 = GEMM with
+ * fp32 epilogue + row LayerNorm kernel everywhere.  Same fp32 inputs to the normalisation; the row statistics are added in
+ * a different order (part of the result, like the attention schedule). */
+int mavlm_set_fused_layernorm(int32_t on);
+/* byte offset, inside the workspace of a context with this config, of the 4 control words {arrivals, launch counter, timeout
+ * flag, -} of the fused epilogue's exchange, or -1 when the config never takes the fused form.  The timeout flag is set when a
+ * workgroup gave up waiting for a partner's statistics (bounded spin; the output of that launch is then wrong): 0 after any
+ * correct run - the tests and bench.py read it. */
+int64_t mavlm_workspace_ln_ctl_offset(const mavlm_config* cfg);
 /* ctx[R,H*128] = softmax(Q K^T / sqrt(128)) V per head; lse2 [H,R] fp32 optional.  MemoryController.py:51-54 */
 int mavlm_attention(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                     int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream);
@@ -329,9 +351,10 @@ int mavlm_frame_scores_fused(int32_t R, int32_t S, int32_t H, int32_t patches);
 /* When enabled, every kernel launch is bracketed by HIP events on its own stream.  Kinds: 0 GEMM, 1 attention
  * forward, 2 attention column-sum, 3 LayerNorm (forward and backward), 4 row-add, 5 misc, 6 attention backward,
  * 7 split-K GEMM, 8 transpose, 9 attention merge (split-KV / stream-K partials), 10 attention forward carrying the frame
- * masses (last formation layer).  Not re-entrant, not graph-capturable. */
+ * masses (last formation layer), 11 GEMM with the fused residual + LayerNorm epilogue (mavlm_linear_ln: the Residual blocks;
+ * its time contains what kinds 0 + 3 spend on the two-kernel form).  Not re-entrant, not graph-capturable. */
 int mavlm_prof_enable(int32_t on);
-/* host arrays of length nkinds >= 11: total milliseconds, launches, algorithmic flops, algorithmic bytes per kind */
+/* host arrays of length nkinds >= 12: total milliseconds, launches, algorithmic flops, algorithmic bytes per kind */
 int mavlm_prof_read(double* ms, int64_t* launches, double* flops, double* bytes, int32_t nkinds);
 
 #ifdef __cplusplus

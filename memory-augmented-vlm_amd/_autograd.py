@@ -79,8 +79,9 @@ class DenseResidualNormFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, res, gamma, beta, eps):
         x, res, w = _c(x.detach()), _c(res.detach()), weight.detach()
         g32 = gamma.detach().float()
-        z = ops.linear(x, w, bias.detach().float(), capi.EPI_F32)
-        y = ops.layernorm(z, g32, beta.detach().float(), eps, x.dtype, residual=res)
+        # the form the fused inference step takes for this shape (one kernel where the GEMM fills the chip, else GEMM + row
+        # LayerNorm): bit-identical activations; z = x W^T + b in fp32 is what the backward recomputes the statistics from
+        y, z = ops.linear_residual_layernorm(x, w, bias.detach().float(), res, g32, beta.detach().float(), eps, want_pre=True)
         ctx.save_for_backward(x, w, z, res, g32)
         ctx.eps = eps
         ctx.dtypes = (bias.dtype, gamma.dtype, beta.dtype)

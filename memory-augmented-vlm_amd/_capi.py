@@ -66,6 +66,11 @@ SIGNATURES = {
     "mavlm_linear": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mavlm_attention": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.c_float, i32, vp]),
     "mavlm_attention_hd": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, C.c_float, i32, vp]),
+    "mavlm_linear_ln_ws_bytes": (C.c_int64, [i32, i32, i32]),
+    "mavlm_linear_ln": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, vp, vp, C.c_float, vp, i32, vp, i32, i32, i32, vp, C.c_int64,
+                                  i32, vp]),
+    "mavlm_set_fused_layernorm": (C.c_int, [i32]),
+    "mavlm_workspace_ln_ctl_offset": (C.c_int64, [C.POINTER(Config)]),
     "mavlm_linear_ws_floats": (C.c_int64, [i32, i32, i32, i32, i32]),
     "mavlm_linear_ws": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, C.c_int64, i32, vp]),
     "mavlm_attention_ws_floats": (C.c_int64, [i32, i32, i32]),
@@ -113,7 +118,7 @@ SIGNATURES = {
 }
 
 KERNEL_KINDS = ("gemm", "attention_fwd", "attention_colsum", "layernorm", "row_add", "misc", "attention_bwd",
-                "gemm_splitk", "transpose", "attention_merge", "attention_fwd_frames")
+                "gemm_splitk", "transpose", "attention_merge", "attention_fwd_frames", "gemm_layernorm")
 
 _lib = None
 

@@ -175,6 +175,44 @@ def layernorm(x_f32, gamma_f32, beta_f32, eps, out_dtype, out=None, residual=Non
     return out
 
 
+_LN_WS = {}
+
+
+def linear_residual_layernorm(x, weight, bias_f32, residual, gamma_f32, beta_f32, eps, want_pre=False, out=None):
+    """The Residual block, out = LayerNorm(x @ weight.T + bias + residual) * gamma + beta (MemoryController.py:20-29), the
+    way the fused step runs it for this shape: ONE kernel (`mavlm_linear_ln`) where the GEMM fills the chip, else the GEMM
+    with fp32 epilogue + the row LayerNorm kernel.  Returns (out 16-bit [M,N], pre fp32 [M,N] = x W^T + bias | None)."""
+    _need_gpu(x, weight, bias_f32, residual, gamma_f32, beta_f32)
+    M, K, lda = _rows(x)
+    N, K2, ldw = _rows(weight)
+    _, _, ldr = _rows(residual)
+    if K2 != K or weight.dtype != x.dtype or residual.dtype != x.dtype or residual.shape != (M, N):
+        raise capi.MavlmError("linear_residual_layernorm: operand mismatch")
+    lib = capi.lib()
+    nws = int(lib.mavlm_linear_ln_ws_bytes(M, N, K))
+    if nws == 0:
+        pre = linear(x, weight, bias_f32, capi.EPI_F32)
+        return layernorm(pre, gamma_f32, beta_f32, eps, x.dtype, out=out, residual=residual), (pre if want_pre else None)
+    # scratch with a launch counter: zero-filled ONCE per device and then reused (operator-level calls are single-stream:
+    # the training path, the tests; the fused engine has its own scratch in its workspace).  Never (re-)created inside a
+    # hipGraph capture: a replayed memset would reset the launch counter under the granules of the previous replay.
+    key = x.device.index
+    ws = _LN_WS.get(key)
+    if ws is None or ws.numel() < nws:
+        if torch.cuda.is_current_stream_capturing():
+            raise capi.MavlmError("linear_residual_layernorm: first use inside a graph capture - warm the operator up "
+                                  "outside the capture (its scratch carries a launch counter)")
+        ws = _LN_WS[key] = torch.zeros(max(nws, 1 << 22), device=x.device, dtype=torch.uint8)
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=x.dtype)
+    pre = torch.empty((M, N), device=x.device, dtype=torch.float32) if want_pre else None
+    capi.check(lib.mavlm_linear_ln(x.data_ptr(), lda, weight.data_ptr(), ldw, bias_f32.data_ptr(), residual.data_ptr(), ldr,
+                                   gamma_f32.data_ptr(), beta_f32.data_ptr(), float(eps), out.data_ptr(), out.stride(0),
+                                   pre.data_ptr() if want_pre else 0, M, N, K, ws.data_ptr(), ws.numel(),
+                                   dtype_code(x.dtype), stream_ptr()), "mavlm_linear_ln")
+    return out, pre
+
+
 def row_add(x, table, idx=None, src=None, out=None):
     """out[t,p,:] = x[src[t],p,:] + table[idx[t],:]  (x [T0,P,D]; idx/src int64 device tensors or None)."""
     _need_gpu(x, table, idx, src, out)

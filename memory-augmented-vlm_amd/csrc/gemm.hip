@@ -281,6 +281,16 @@ size_t mavlm_gemm_split_ws_floats(int M, int N, int K, int epilogue, int ldc) {
 
 hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s) {
   if (g.M <= 0) return hipSuccess;
+  if (g.epilogue == MAVLM_EPI_LN) {
+    // dense + residual + LayerNorm in one kernel: the non-persistent 256-column-tile kernel only (its row-block exchange
+    // needs the N / 256 workgroups of a row block in flight together)
+    if (!mavlm_gemm_ln_supported(g.M, g.N, g.K) || !mavlm_gemm256_supported(g) || g.c_rpb > 0 || !g.res || (g.ldr & 3) ||
+        !g.ln.gamma || !g.ln.beta || !g.ln.gran || !g.ln.ctl || ((uintptr_t)g.C & 15) || (g.ldc & 7) || (g.lda & 7) || (g.ldw & 7))
+      return hipErrorInvalidValue;
+    mavlm_prof_scope prof(MAVLM_K_GEMM_LN, 2.0 * g.M * (double)g.N * g.K,
+                          2.0 * ((double)g.M * g.K + (double)g.N * g.K) + 4.0 * g.M * (double)g.N, s);
+    return mavlm_launch_gemm256(g, dtype, s);
+  }
   if (g.c_rpb > 0) {
     // row-batched output: only the 256-column-tile kernels scatter their rows (the stacked rows of several videos fill
     // the chip - there is no small-grid case to serve)

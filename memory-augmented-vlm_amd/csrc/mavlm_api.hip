@@ -18,6 +18,7 @@ struct mavlm_ctx {
   size_t o_kv, o_q, o_ctx, o_a, o_h, o_pre, o_mA, o_mB, o_lse, o_part, o_split, o_gsplit, gsplit_floats, total;
   size_t o_fscr = 0, o_fout = 0;   // frame-score variant of the last layer's forward (0 = not available for this config)
   size_t split_floats = 0;         // floats carved at o_split (attention partials: split-KV / stream-K)
+  size_t o_lnx = 0, lnx_bytes = 0; // scratch of the fused dense + residual + LayerNorm GEMM epilogue (0 = not used for this config)
   const void* pre_seg = nullptr;   // mavlm_project_chunk: the chunk whose K/V already sit in the workspace (0 = none)
   int pre_F = 0;
   int fuse_mems = 1;   // cached memories the Memory-Fuser MLP takes per GEMM launch (mavlm_fuse_emit)
@@ -145,6 +146,19 @@ void carve(mavlm_ctx* x) {
       x->o_fout = o; o += al(mavlm_attention_frames_out_floats((int)R1, fc * c.patches, (int)(H * B), c.patches) * 4);
     }
   }
+  // scratch of the fused dense + residual + LayerNorm epilogue (gemm256.hip EPI_LN): {epoch, value} granules of the row
+  // blocks + control words.  MUST be zero when the workspace is bound (mavlm_buffers.workspace).
+  x->o_lnx = 0;
+  x->lnx_bytes = 0;
+  {
+    const int rows_[2] = {(int)R, (int)(R1 * B)};
+    for (int r : rows_)
+      if (mavlm_gemm_ln_supported(r, (int)D, (int)Dp) || mavlm_gemm_ln_supported(r, (int)D, (int)I)) {
+        const size_t b = mavlm_gemm_ln_ws_bytes(r, (int)D);
+        if (b > x->lnx_bytes) x->lnx_bytes = b;
+      }
+    if (x->lnx_bytes) { x->o_lnx = o; o += al(x->lnx_bytes); }
+  }
   x->total = o;
 }
 
@@ -173,6 +187,30 @@ inline hipError_t gemm_x(mavlm_ctx* x, hipStream_t s, const void* A, int lda, co
                          int ldc, int M, int N, int K, int epi) {
   return gemm(x->cfg.dtype, s, A, lda, W, ldw, bias, C, ldc, M, N, K, epi, nullptr, 0,
               x->gsplit_floats ? (float*)ws(x, x->o_gsplit) : nullptr, x->gsplit_floats);
+}
+
+// Residual block (MemoryController.py:26-29): out = LayerNorm(A . W^T + bias + res) * gamma + beta.  One kernel where the
+// 256-column-tile GEMM fills the chip (EPI_LN: the fp32 dense output never goes through HBM), else the GEMM with its
+// fp32 epilogue + the row LayerNorm kernel.  Same fp32 values into the normalisation either way; the two forms add the
+// row statistics in different orders (a pure function of the shape which one runs: mavlm_linear_ln_fused).
+int g_mavlm_fused_ln = 1;
+int dense_ln(mavlm_ctx* x, hipStream_t s, const void* A, int lda, const void* W, int ldw, const float* bias, const void* res,
+             const float* gamma, const float* beta, void* out, int rows, int N, int K) {
+  const mavlm_config& c = x->cfg;
+  if (g_mavlm_fused_ln && x->lnx_bytes && mavlm_gemm_ln_supported(rows, N, K) && mavlm_gemm_ln_ws_bytes(rows, N) <= x->lnx_bytes) {
+    mavlm_gemm_args g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.res = res; g.ldr = N; g.C = out; g.ldc = N;
+    g.M = rows; g.N = N; g.K = K; g.epilogue = MAVLM_EPI_LN;
+    g.ln.gamma = gamma; g.ln.beta = beta; g.ln.eps = c.eps;
+    // (control words FIRST: their place must not depend on the shape - the launch counter is what keeps epochs unique)
+    g.ln.ctl = (unsigned*)ws(x, x->o_lnx);
+    g.ln.gran = (unsigned long long*)(ws(x, x->o_lnx) + 64);
+    MAVLM_TRY(mavlm_launch_gemm(g, c.dtype, s));
+    return 0;
+  }
+  MAVLM_TRY(gemm_x(x, s, A, lda, W, ldw, bias, ws(x, x->o_pre), N, rows, N, K, MAVLM_EPI_F32));
+  MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), res, N, gamma, beta, out, rows, N, c.eps, c.dtype, s));
+  return 0;
 }
 
 // One `Attention` block given projected K/V:  out = LN(dense(attn(q_proj(xq), K, V)) + xq).  All videos of the row batch
@@ -208,10 +246,8 @@ int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const 
       MAVLM_TRY(mavlm_launch_attention(a, dt, s));
     }
   }
-  // Residual: dense + bias in fp32 (GEMM epilogue), + residual and LayerNorm in the row kernel (MemoryController.py:26-29)
-  MAVLM_TRY(gemm_x(x, s, ws(x, x->o_ctx), Dp, aw.wo, Dp, aw.bo, ws(x, x->o_pre), D, R, D, Dp, MAVLM_EPI_F32));
-  MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), xq, D, aw.ln_g, aw.ln_b, out, R, D, c.eps, dt, s));
-  return 0;
+  // Residual: dense + bias + residual in fp32, LayerNorm (MemoryController.py:26-29)
+  return dense_ln(x, s, ws(x, x->o_ctx), Dp, aw.wo, Dp, aw.bo, xq, aw.ln_g, aw.ln_b, out, R, D, Dp);
 }
 
 // does the step take the fused frame scores for a last-layer attention over S keys?  (single videos: not the small grids
@@ -306,13 +342,14 @@ int step_impl(mavlm_ctx* x, const void* const* segs, int32_t F, void* frame_scor
     }
     // MLP: Linear(D,I)+ReLU -> Residual(I->D)  (MemoryController.py:63-67,71)
     MAVLM_TRY(gemm_x(x, s, ws(x, x->o_a), D, x->w.w_up[l], D, x->w.b_up[l], ws(x, x->o_h), I, R, I, D, MAVLM_EPI_RELU));
-    MAVLM_TRY(gemm_x(x, s, ws(x, x->o_h), I, x->w.w_down[l], I, x->w.b_down[l], ws(x, x->o_pre), D, R, D, I,
-                     MAVLM_EPI_F32));
     // (row shard: this context's rows of the slot; the host all-gathers the other ranks' rows into it before the next step)
     void* dst = last ? (void*)((char*)x->b.mem_ring + (size_t)(x->steps % cap) * slot_bytes + (size_t)r0 * D * 2)
                      : (void*)ws(x, (l & 1) ? x->o_mA : x->o_mB);
-    MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), ws(x, x->o_a), D, x->w.ln2_g[l], x->w.ln2_b[l], dst, R, D,
-                                     c.eps, dt, s));
+    {
+      int rc2 = dense_ln(x, s, ws(x, x->o_h), I, x->w.w_down[l], I, x->w.b_down[l], ws(x, x->o_a), x->w.ln2_g[l], x->w.ln2_b[l],
+                         dst, R, D, I);
+      if (rc2) return rc2;
+    }
     cur = dst;
   }
   x->steps += 1;   // append; the slot written above evicts the oldest entry once the ring is full (:152-154)
@@ -374,6 +411,32 @@ int mavlm_set_frame_score_mode(int32_t mode) {
   return 0;
 }
 
+int mavlm_set_fused_layernorm(int32_t on) {
+  g_mavlm_fused_ln = on ? 1 : 0;
+  return 0;
+}
+
+int64_t mavlm_linear_ln_ws_bytes(int32_t M, int32_t N, int32_t K) {
+  return (g_mavlm_fused_ln && mavlm_gemm_ln_supported(M, N, K)) ? (int64_t)mavlm_gemm_ln_ws_bytes(M, N) : 0;
+}
+
+int mavlm_linear_ln(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const void* res, int32_t ldr,
+                    const float* gamma, const float* beta, float eps, void* out, int32_t ldo, float* pre_out, int32_t M,
+                    int32_t N, int32_t K, void* ws_, int64_t ws_bytes, int32_t dtype, void* stream) {
+  if (!A || !W || !bias || !res || !gamma || !beta || !out || M < 0) return MAVLM_E_ARG;
+  const int64_t need = mavlm_linear_ln_ws_bytes(M, N, K);
+  if (need == 0) return MAVLM_E_SHAPE;
+  if (!ws_ || ws_bytes < need || ((uintptr_t)ws_ & 15)) return MAVLM_E_ARG;
+  mavlm_gemm_args g;
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.res = res; g.ldr = ldr; g.C = out; g.ldc = ldo;
+  g.M = M; g.N = N; g.K = K; g.epilogue = MAVLM_EPI_LN;
+  g.ln.gamma = gamma; g.ln.beta = beta; g.ln.eps = eps; g.ln.pre_out = pre_out;
+  g.ln.ctl = (unsigned*)ws_;                               // control words first: a fixed place for every shape
+  g.ln.gran = (unsigned long long*)((char*)ws_ + 64);
+  hipError_t e = mavlm_launch_gemm(g, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
 int mavlm_set_gemm_rows(int32_t rows) {
   if (rows != 0 && rows != 224 && rows != 256) return MAVLM_E_ARG;
   g_mavlm_gemm_rows = rows;
@@ -386,6 +449,14 @@ size_t mavlm_workspace_bytes(const mavlm_config* cfg) {
   t.cfg = *cfg;
   carve(&t);
   return t.total;
+}
+
+int64_t mavlm_workspace_ln_ctl_offset(const mavlm_config* cfg) {
+  if (!cfg_ok(cfg)) return -1;
+  mavlm_ctx t;
+  t.cfg = *cfg;
+  carve(&t);
+  return t.lnx_bytes ? (int64_t)t.o_lnx : -1;
 }
 
 int mavlm_workspace_layout(const mavlm_config* cfg, size_t* offsets, int32_t n) {

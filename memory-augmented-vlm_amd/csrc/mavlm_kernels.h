@@ -4,7 +4,18 @@
 #include <stddef.h>
 #include <stdint.h>
 
-enum { MAVLM_EPI_BIAS = 0, MAVLM_EPI_RELU = 1, MAVLM_EPI_GELU = 2, MAVLM_EPI_RES_F32 = 3, MAVLM_EPI_F32 = 4 };
+enum { MAVLM_EPI_BIAS = 0, MAVLM_EPI_RELU = 1, MAVLM_EPI_GELU = 2, MAVLM_EPI_RES_F32 = 3, MAVLM_EPI_F32 = 4, MAVLM_EPI_LN = 5 };
+
+// EPI_LN (gemm256.hip): C = LayerNorm(A.W^T + bias + res) * gamma + beta in 16 bits - the Residual block of the reference in
+// one kernel (the fp32 dense output never goes through HBM).  gran / ctl: mavlm_gemm_ln_ws_bytes() of scratch, see there.
+struct mavlm_ln_epilogue {
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  float eps = 0.f;
+  unsigned long long* gran = nullptr;   // [row blocks][N/256][256][2] {epoch, value} granules
+  unsigned* ctl = nullptr;              // {arrivals of this launch, launch counter, timeout flag, -}
+  float* pre_out = nullptr;             // optional [M, N] fp32: dense + bias (before the residual), for the training path
+};
 
 struct mavlm_gemm_args {
   const void* A; int lda;        // [M,K] 16-bit, row stride lda elements
@@ -21,7 +32,10 @@ struct mavlm_gemm_args {
   // (mavlm_config::batch) are written to per-video buffers: the evolution K/V ring, the fused-token blocks.
   int c_rpb = 0, c_nb = 1;
   long long c_bstride = 0;
+  mavlm_ln_epilogue ln;          // EPI_LN only
 };
+bool mavlm_gemm_ln_supported(int M, int N, int K);
+size_t mavlm_gemm_ln_ws_bytes(int M, int N);
 hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s);
 // split-K plan for GEMMs with few output tiles and a long contraction (small M, K >= 2048): 1 = none.  Pure function of
 // the shape: the fused step and the stand-alone operator take the same path.
@@ -171,7 +185,7 @@ hipError_t mavlm_launch_pool_bilinear(const void* x, void* out, const void* tabl
 
 // ---- optional per-kernel HIP-event profiling (bench.py roofline line); off by default, zero cost when off.
 enum { MAVLM_K_GEMM = 0, MAVLM_K_ATTN = 1, MAVLM_K_COLSUM = 2, MAVLM_K_LN = 3, MAVLM_K_ROWADD = 4, MAVLM_K_MISC = 5,
-       MAVLM_K_ATTN_BWD = 6, MAVLM_K_GEMM_SPLITK = 7, MAVLM_K_TRANSPOSE = 8, MAVLM_K_ATTN_MERGE = 9, MAVLM_K_ATTN_FRAMES = 10, MAVLM_K_COUNT = 11 };
+       MAVLM_K_ATTN_BWD = 6, MAVLM_K_GEMM_SPLITK = 7, MAVLM_K_TRANSPOSE = 8, MAVLM_K_ATTN_MERGE = 9, MAVLM_K_ATTN_FRAMES = 10, MAVLM_K_GEMM_LN = 11, MAVLM_K_COUNT = 12 };
 struct mavlm_prof_scope {
   int slot;
   hipStream_t s;

@@ -87,8 +87,8 @@ class Residual(nn.Module):
             from ... import _autograd as ag
             return ag.DenseResidualNormFn.apply(h2, self.dense.weight.to(h2.dtype), self.dense.bias, x2,
                                                 self.layernorm.weight, self.layernorm.bias, self.layernorm.eps).reshape(shp)
-        pre = ops.linear(h2, self.dense.weight, self.dense.bias.float(), capi.EPI_RES_F32, residual=x2)
-        out = ops.layernorm(pre, self.layernorm.weight.float(), self.layernorm.bias.float(), self.layernorm.eps, x2.dtype)
+        out, _ = ops.linear_residual_layernorm(h2, self.dense.weight, self.dense.bias.float(), x2.contiguous(),
+                                               self.layernorm.weight.float(), self.layernorm.bias.float(), self.layernorm.eps)
         return out.reshape(shp)
 
 
@@ -181,7 +181,8 @@ class _Engine:
             self.mem_ring = torch.empty((self.c.cache_cap, self.c.mem_tokens, self.c.patches, D), device=device, dtype=dtype)
             self.evo_kv = torch.empty((self.c.cache_cap, R, 2 * self.Dp), device=device, dtype=dtype)
         nbytes = lib.mavlm_workspace_bytes(self.c)
-        self.workspace = torch.empty(nbytes + 256, device=device, dtype=torch.uint8)
+        # zero-filled: the workspace carries the launch counter / exchange granules of the fused LayerNorm epilogue (mavlm.h)
+        self.workspace = torch.zeros(nbytes + 256, device=device, dtype=torch.uint8)
         base = (self.workspace.data_ptr() + 255) & ~255
         self.workspace_base_offset = base - self.workspace.data_ptr()
         b = capi.Buffers(mem_ring=self.mem_ring.data_ptr(), evo_kv_ring=self.evo_kv.data_ptr(), workspace=base,
@@ -273,6 +274,16 @@ class _Engine:
     @property
     def steps(self) -> int:
         return capi.lib().mavlm_steps(self.ctx)
+
+    def ln_exchange_status(self):
+        """(launches, timeouts) of the fused dense + residual + LayerNorm epilogue in this engine's workspace, or None when the
+        config never takes the fused form.  timeouts != 0: a workgroup gave up waiting for a partner (bounded spin) and the
+        result of that launch is wrong - never seen; the tests and bench.py assert 0.  Synchronises (a D2H read)."""
+        off = int(capi.lib().mavlm_workspace_ln_ctl_offset(self.c))
+        if off < 0:
+            return None
+        w = self.workspace[self.workspace_base_offset + off:self.workspace_base_offset + off + 16].view(torch.int32).cpu()
+        return int(w[1]), int(w[2])
 
     def workspace_views(self):
         """Typed views of the workspace regions (contents = intermediates of the most recent sub-layer).  For the

@@ -25,3 +25,27 @@ for (M, N, K, e) in CASES:
     f = 2.0 * M * N * K
     print(f"M{M:6d} N{N:5d} K{K:5d} {e:5s}: this library {t_mine*1e6:7.1f} us {f/t_mine/1e12:7.1f} TF | hipBLASLt(bias) "
           f"{t_lt*1e6:7.1f} us {f/t_lt/1e12:7.1f} TF | ratio {t_lt/t_mine:.2f}", flush=True)
+
+# the Residual block: one kernel (mavlm_linear_ln) against GEMM (fp32 epilogue) + row LayerNorm kernel
+lib = capi.lib()
+for (M, N, K) in [(12544, 1024, 1024), (12544, 1024, 4096), (25088, 1024, 1024), (25088, 1024, 4096)]:
+    a = torch.randn(M, K, device="cuda").bfloat16()
+    w = torch.randn(N, K, device="cuda").bfloat16() * 0.05
+    b32 = torch.randn(N, device="cuda")
+    res = torch.randn(M, N, device="cuda").bfloat16()
+    g = torch.rand(N, device="cuda") + 0.5
+    be = torch.randn(N, device="cuda")
+    out = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+
+    def fused():
+        lib.mavlm_set_fused_layernorm(1)
+        ops.linear_residual_layernorm(a, w, b32, res, g, be, 1e-12, out=out)
+
+    def two():
+        lib.mavlm_set_fused_layernorm(0)
+        ops.linear_residual_layernorm(a, w, b32, res, g, be, 1e-12, out=out)
+    t_f, t_2 = timeit_pair(fused, two)
+    lib.mavlm_set_fused_layernorm(1)
+    f = 2.0 * M * N * K
+    print(f"Residual block M{M:6d} N{N:5d} K{K:5d}: one kernel {t_f*1e6:7.1f} us ({f/t_f/1e12:7.1f} TF) | GEMM + LayerNorm kernels "
+          f"{t_2*1e6:7.1f} us | ratio {t_2/t_f:.2f}", flush=True)

@@ -234,3 +234,129 @@ def test_row_batch_refusals():
     x = torch.zeros(8, device="cuda")
     assert capi.lib().mavlm_step(h, x.data_ptr(), 1, 0, 0, 0) == capi.E_STATE
     capi.lib().mavlm_destroy(h)
+
+
+# ---- fused dense + residual + LayerNorm epilogue (mavlm_linear_ln) ----------------------------------------------------
+def _ln_case(M, N, K, mode, seed):
+    r = O.rounder(mode)
+    x = r(O.hash_normal_like((M, K), seed))
+    w = r(O.hash_uniform((N, K), seed + 1, -1 / np.sqrt(K), 1 / np.sqrt(K)))
+    b = O.hash_uniform((N,), seed + 2, -0.1, 0.1).astype(np.float32)
+    res = r(O.hash_normal_like((M, N), seed + 3))
+    g = (1.0 + O.hash_uniform((N,), seed + 4, -0.1, 0.1)).astype(np.float32)
+    be = O.hash_uniform((N,), seed + 5, -0.1, 0.1).astype(np.float32)
+    return x, w, b, res, g, be
+
+
+@pytest.mark.parametrize("mode,M,N,K", [("bf16", 12544, 1024, 1024), ("bf16", 25088 + 37, 1024, 4096), ("fp16", 12544, 1024, 1024),
+                                        ("bf16", 6272, 3584, 512), ("bf16", 13000, 1024, 64), ("bf16", 50000, 256, 128 * 3)])
+def test_fused_dense_residual_layernorm(mode, M, N, K, request):
+    """mavlm_linear_ln: the Residual block (MemoryController.py:20-29) as ONE kernel - the N / 256 workgroups of a row block
+    exchange their per-row (mean, centred sum of squares) through {epoch, value} granules - against the oracle's LayerNorm of
+    the oracle's dense output and against the two-kernel form (same fp32 inputs, statistics added in another order); the
+    optional fp32 dense output equals the plain GEMM's bit for bit; N = 1024 (4 tiles per row), 3584 (14: the OV-7B width)
+    and 256 (1: no partner), ragged M, a single K-tile; bit-reproducible."""
+    from gpu_util import f32_dev
+    lib = capi.lib()
+    assert lib.mavlm_linear_ln_ws_bytes(M, N, K) > 0 and lib.mavlm_linear_ln_ws_bytes(1568, N, K) == 0
+    x, w, b, res, g, be = _ln_case(M, N, K, mode, 300 + N)
+    dx, dw, dres = to_dev(x, mode), to_dev(w, mode), to_dev(res, mode)
+    db, dg, dbe = f32_dev(b), f32_dev(g), f32_dev(be)
+    out, pre = ops.linear_residual_layernorm(dx, dw, db, dres, dg, dbe, 1e-12, want_pre=True)
+    plain_pre = ops.linear(dx, dw, db, capi.EPI_F32)
+    assert torch.equal(pre, plain_pre)
+    capi.check(lib.mavlm_set_fused_layernorm(0), "hook")
+    request.addfinalizer(lambda: lib.mavlm_set_fused_layernorm(1))
+    two, _ = ops.linear_residual_layernorm(dx, dw, db, dres, dg, dbe, 1e-12)
+    capi.check(lib.mavlm_set_fused_layernorm(1), "hook")
+    r = O.rounder(mode)
+    ref = r(O.layernorm(O.linear(x, w, b) + res, g, be, 1e-12))
+    err, err2, d12 = O.rel_l2(to_np(out), ref), O.rel_l2(to_np(two), ref), O.rel_l2(to_np(out), to_np(two))
+    print(f"fused LN {mode} {M}x{N}x{K}: vs oracle {err:.2e} (two-kernel form {err2:.2e}), fused vs two-kernel {d12:.2e}")
+    assert err < TOL and err <= err2 * 1.2 + 1e-6 and d12 < 5e-4
+    for _ in range(5):
+        assert torch.equal(ops.linear_residual_layernorm(dx, dw, db, dres, dg, dbe, 1e-12)[0], out)
+
+
+def test_fused_layernorm_back_to_back_launches_and_graph_replay():
+    """The exchange granules carry an epoch from a launch counter in memory (nothing is re-zeroed between launches): many
+    launches back to back on alternating inputs each give their own result (a stale granule of the previous launch would
+    show as the other input's statistics), and a captured launch replays correctly - the counter lives in memory, not in
+    the kernel arguments."""
+    from gpu_util import f32_dev
+    M, N, K = 12544, 1024, 1024
+    cases = []
+    for sd in (700, 800):
+        x, w, b, res, g, be = _ln_case(M, N, K, "bf16", sd)
+        res = res * (3.0 if sd == 800 else 1.0) + (5.0 if sd == 800 else 0.0)       # very different row statistics
+        args = (to_dev(x), to_dev(w), f32_dev(b), to_dev(res), f32_dev(g), f32_dev(be), 1e-12)
+        cases.append((args, ops.linear_residual_layernorm(*args)[0].clone()))
+    assert not torch.equal(cases[0][1], cases[1][1])
+    outs = []
+    for i in range(40):
+        outs.append(ops.linear_residual_layernorm(*cases[i & 1][0])[0])
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert torch.equal(o, cases[i & 1][1]), i
+    # hipGraph: capture one launch, replay it on changing inputs (static buffers)
+    a0 = cases[0][0]
+    sx, sres = a0[0].clone(), a0[3].clone()
+    sout = torch.empty_like(cases[0][1])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.linear_residual_layernorm(sx, a0[1], a0[2], sres, a0[4], a0[5], 1e-12, out=sout)
+    torch.cuda.current_stream().wait_stream(side)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        ops.linear_residual_layernorm(sx, a0[1], a0[2], sres, a0[4], a0[5], 1e-12, out=sout)
+    for rep in range(6):
+        src = cases[rep & 1]
+        sx.copy_(src[0][0])
+        sres.copy_(src[0][3])
+        gr.replay()
+        torch.cuda.synchronize()
+        if rep & 1:      # (input x / res of case 1 through the weights of case 0: compare with an eager launch)
+            want = ops.linear_residual_layernorm(sx, a0[1], a0[2], sres, a0[4], a0[5], 1e-12)[0]
+        else:
+            want = cases[0][1]
+        assert torch.equal(sout, want), rep
+
+
+def test_fused_layernorm_in_the_step_training_equals_inference():
+    """64 memory tokens (R = 12 544: the Residual blocks of the step run as the fused kernel): the training path's forward
+    (autograd Functions over the same operators) is bit-identical to the inference step, the fused step matches the
+    two-kernel step within the rounding of a different summation order, and gradients flow."""
+    from test_gpu_path import make_projector
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=64, depth=2)
+    w = O.make_weights(cfg, seed=64)
+    proj = make_projector(cfg, w)
+    segs = [to_dev(O.bf16_round(O.hash_normal_like((f, 196, 1024), 6400 + t))) for t, f in enumerate((3, 2))]
+    proj.memory_cache = []
+    for s_ in segs:
+        cache, _ = proj(s_)
+    infer = [c.clone() for c in cache]
+    launches, timeouts = proj._engine.ln_exchange_status()
+    assert launches == 2 * (2 * 2) + 1 and timeouts == 0          # 2 Residual blocks per layer, 2 layers, 2 steps + 1 evolution
+    lib = capi.lib()
+    try:
+        capi.check(lib.mavlm_set_fused_layernorm(0), "hook")
+        proj.memory_cache = []
+        for s_ in segs:
+            cache, _ = proj(s_)
+        two = [c.clone() for c in cache]
+    finally:
+        lib.mavlm_set_fused_layernorm(1)
+    for a, b in zip(infer, two):
+        assert O.rel_l2(to_np(a), to_np(b)) < 3e-3
+    with torch.enable_grad():
+        for p_ in proj.parameters():
+            p_.requires_grad_(True)
+        proj.memory_cache = []
+        for s_ in segs:
+            cache, _ = proj(s_)
+        for a, b in zip(cache, infer):
+            assert torch.equal(a.detach(), b)
+        sum((c.float() ** 2).mean() for c in cache).backward()
+    assert all(p_.grad is not None and torch.isfinite(p_.grad.float()).all() for p_ in proj.parameters())
+    proj.memory_cache = []
