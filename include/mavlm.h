@@ -49,7 +49,7 @@ typedef struct mavlm_config {
   int32_t batch;            /* B: independent videos stepped together over ONE set of weights (0 / 1 = a single video, the
                              * reference's limit, llava_arch.py:436).  The memory rows of the B videos are stacked into every
                              * weight-shared GEMM / LayerNorm launch ([B*M*P, D]); the attention serves B*heads (video, head)
-                             * pairs, each video over its own keys.  head_dim <= 128 only.  Buffers: see mavlm_buffers,
+                             * pairs, each video over its own keys (wide heads, 448: one attention launch per video).  Buffers: see mavlm_buffers,
                              * mavlm_weights.mem0; protocol: mavlm_step_batch / mavlm_fuse_emit_batch. */
   int32_t q_token0;         /* Row shard of ONE video over the ranks of a process group (SURVEY.md section 8e option 2): this */
   int32_t q_tokens;         /* context computes the memory tokens [q_token0, q_token0 + q_tokens) of every step - q projection,
@@ -172,7 +172,8 @@ int mavlm_attention_frames(const void* Q, int32_t ldq, const void* K, int32_t ld
                            int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, int32_t patches,
                            float* ws, int64_t ws_floats, float* frame_scores, int32_t dtype, void* stream);
 /* The whole Residual block (MemoryController.py:20-29) in ONE kernel: out = LayerNorm(A . W^T + bias + res) * gamma + beta,
- * 16-bit out [M, ldo]; res 16-bit [M, ldr]; N % 256 == 0, N <= 4096, and a grid that fills the chip
+ * 16-bit out [M, ldo]; res 16-bit [M, ldr]; N % 256 == 0, N <= 1024 (wider rows: correct - hook value 2 - but slower than
+ * the two-kernel form), and a grid that fills the chip
  * (mavlm_linear_ln_ws_bytes > 0; 0 = this shape takes mavlm_linear(epilogue 4) + mavlm_layernorm).  The N / 256 workgroups
  * of a 224/256-row block exchange their per-row (mean, centred sum of squares) through `ws` and merge them in a fixed order;
  * the fp32 dense output never goes through HBM.  pre_out: null, or [M, N] fp32 = A . W^T + bias (what the backward needs).
@@ -184,7 +185,7 @@ int mavlm_linear_ln(const void* A, int32_t lda, const void* W, int32_t ldw, cons
                     const float* gamma, const float* beta, float eps, void* out, int32_t ldo, float* pre_out, int32_t M,
                     int32_t N, int32_t K, void* ws, int64_t ws_bytes, int32_t dtype, void* stream);
 /* tuning hook: 1 (default) = the Residual blocks whose GEMM fills the chip run as one kernel (mavlm_linear_ln), 0 = GEMM with
- * fp32 epilogue + row LayerNorm kernel everywhere.  Same fp32 inputs to the normalisation; the row statistics are added in
+ * fp32 epilogue + row LayerNorm kernel everywhere, 2 = as 1 and also for rows of up to 4096 columns (tests).  Same fp32 inputs to the normalisation; the row statistics are added in
  * a different order (part of the result, like the attention schedule). */
 int mavlm_set_fused_layernorm(int32_t on);
 /* byte offset, inside the workspace of a context with this config, of the 4 control words {arrivals, launch counter, timeout

@@ -53,7 +53,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd_kernel(const uint16_t* __r
                                                              const uint16_t* __restrict__ V, int ldv,
                                                              uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
                                                              int R, int S, int H, float c, float* __restrict__ Opart,
-                                                             float* __restrict__ lse_part, int tps) {
+                                                             float* __restrict__ lse_part, int tps, long long kv_bs) {
+  // row batch (mavlm_attn_args::nb): blockIdx.z = video; its queries / outputs are the rows [z R, (z+1) R), its keys start
+  // kv_bs elements after the previous video's, its log-sum-exp rows are [z H, (z+1) H)  (never combined with split-KV)
+  {
+    const size_t vb = blockIdx.z;
+    Q += vb * R * ldq;
+    O += vb * R * ldo;
+    K += vb * kv_bs;
+    V += vb * kv_bs;
+    if (lse2 != nullptr) lse2 += vb * H * R;
+  }
   // split-KV for small grids (as attn_fwd3_kernel): blockIdx.y owns the keys [y*tps*32, (y+1)*tps*32), writes a
   // normalised fp32 partial + its log-sum-exp; attn_combine_kernel (attention3.hip) merges them
   const int split = blockIdx.y;
@@ -358,14 +368,18 @@ hipError_t launch_fwd_hd(const mavlm_attn_args& a, hipStream_t s) {
     if (e != hipSuccess) return e;
   }
   const float c = a.scale * 1.44269504088896340736f;
+  const int nb = a.nb > 0 ? a.nb : 1;                     // row batch: a.H counts the heads of ALL videos
+  if (a.H % nb != 0) return hipErrorInvalidValue;
+  const int Hv = a.H / nb;
   int tps = 0;
-  int ns = a.split_ws != nullptr ? mavlm_attention_hd_splits(a.R, a.S, a.H, &tps) : 1;
+  int ns = (a.split_ws != nullptr && nb == 1) ? mavlm_attention_hd_splits(a.R, a.S, a.H, &tps) : 1;
   if (ns <= 1) { ns = 1; tps = 0; }
   float* opart = a.split_ws;
   float* lpart = ns > 1 ? a.split_ws + (size_t)ns * a.R * a.H * HD : nullptr;
-  hipLaunchKernelGGL(kern, dim3(((a.R + 127) / 128) * a.H, ns), dim3(512), LDS, s, (const uint16_t*)a.Q, a.ldq,
-                     (const uint16_t*)a.K, a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, a.H, c,
-                     opart, lpart, tps);
+  mavlm_prof_scope prof(MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD, 2.0 * HD * a.H * (2.0 * a.R + 2.0 * a.S), s);
+  hipLaunchKernelGGL(kern, dim3(((a.R + 127) / 128) * Hv, ns, nb), dim3(512), LDS, s, (const uint16_t*)a.Q, a.ldq,
+                     (const uint16_t*)a.K, a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, Hv, c,
+                     opart, lpart, tps, (long long)a.kv_bstride);
   if (ns > 1) return mavlm_launch_attention_combine(opart, lpart, a.O, a.ldo, a.lse2, a.R, a.H, HD, ns, std::is_same<T, F16>::value ? MAVLM_F16 : MAVLM_BF16, s);
   return hipGetLastError();
 }

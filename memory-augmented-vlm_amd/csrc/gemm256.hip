@@ -479,12 +479,17 @@ hipError_t launch256_epi(const mavlm_gemm_args& g, hipStream_t s) {
 
 }  // namespace
 
+int g_mavlm_gemm_ln_wide = 0;     // test hook (mavlm_set_fused_layernorm(2)): admit up to 16 partners per row block
 // Fused dense + residual + LayerNorm epilogue (EPI_LN): the N / 256 workgroups of a row block exchange 2 floats per row
 // through `gran`.  Scratch: 64 bytes of control words (arrivals, launch counter, timeout flag; FIRST, so that their place does
 // not depend on the shape: a scratch reused for another shape keeps counting epochs upward) + [ceil(M / rows)][N / 256][256][2]
 // 8-byte granules - zero-filled ONCE before the first launch, then owned by the launches of ONE stream.
 bool mavlm_gemm_ln_supported(int M, int N, int K) {
-  if (M <= 0 || N % BN2 != 0 || N / BN2 > 16 || N / BN2 < 1 || K % BK2 != 0 || K <= 0) return false;
+  // N <= 1024: up to 4 partners per row block.  The kernel is correct for up to 16 (N = 3584 is tested through
+  // mavlm_set_fused_layernorm(2)), but with 14 partners every thread polls 11 granules one after the other and the row
+  // blocks of a grid larger than the chip straddle its rounds (workgroups spin on CUs their partners are waiting for):
+  // measured 730 TFLOP/s against 1 290 for the plain GEMM at the OneVision-7B width - the two-kernel form wins there.
+  if (M <= 0 || N % BN2 != 0 || N / BN2 > (g_mavlm_gemm_ln_wide ? 16 : 4) || N / BN2 < 1 || K % BK2 != 0 || K <= 0) return false;
   // (the same "fills the chip" rule as the plain 256-column-tile kernels: below it the 128-tile / split-K kernels + the
   // row LayerNorm kernel are faster)
   return (long)((M + 255) / 256) * (N / BN2) >= 192;

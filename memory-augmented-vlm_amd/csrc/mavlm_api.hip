@@ -50,7 +50,6 @@ inline int q_row0(const mavlm_config& c) { return c.q_tokens > 0 ? c.q_token0 * 
 bool shape_ok(const mavlm_config* c) {
   if (c->hidden % 128 != 0 || c->hidden % c->heads != 0 || c->inter % 128 != 0) return false;
   const int hd = c->hidden / c->heads;
-  if (c->batch > 1 && hd > 128) return false;       // the row batch rides on the head_dim <= 128 kernels (attention3.hip)
   return hd <= 128 || hd == 448;      // 448: wide-head kernels (attention_hd.hip), no padding
 }
 inline bool wide_heads(const mavlm_config& c) { return c.hidden / c.heads > 128; }
@@ -227,7 +226,9 @@ int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const 
   a.Q = ws(x, x->o_q); a.ldq = Dp; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = ws(x, x->o_ctx); a.ldo = Dp;
   a.lse2 = lse2; a.R = R1; a.S = S; a.H = H * B; a.nb = B; a.kv_bstride = kv_bs; a.scale = attn_scale(c);
   if (wide_heads(c)) {
-    a.split_ws = x->split_floats ? (float*)ws(x, x->o_split) : nullptr;
+    // wide heads (448: the OneVision-7B width): the row batch is the grid's z dimension (never split over the keys: B videos
+    // fill the chip); a single video may take the kernel's split-KV form
+    a.split_ws = (B == 1 && x->split_floats) ? (float*)ws(x, x->o_split) : nullptr;
     MAVLM_TRY(mavlm_launch_attention_hd(a, c.hidden / c.heads, dt, s));
   } else {
     // the schedule is part of the result: take it only when the carved workspace covers this shape's plan under the
@@ -412,7 +413,9 @@ int mavlm_set_frame_score_mode(int32_t mode) {
 }
 
 int mavlm_set_fused_layernorm(int32_t on) {
+  if (on < 0 || on > 2) return MAVLM_E_ARG;
   g_mavlm_fused_ln = on ? 1 : 0;
+  g_mavlm_gemm_ln_wide = on == 2 ? 1 : 0;
   return 0;
 }
 

@@ -35,6 +35,7 @@ struct mavlm_gemm_args {
   mavlm_ln_epilogue ln;          // EPI_LN only
 };
 bool mavlm_gemm_ln_supported(int M, int N, int K);
+extern int g_mavlm_gemm_ln_wide;
 size_t mavlm_gemm_ln_ws_bytes(int M, int N);
 hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s);
 // split-K plan for GEMMs with few output tiles and a long contraction (small M, K >= 2048): 1 = none.  Pure function of

@@ -1,5 +1,6 @@
 """Diagnostic (GPU box): frames/s of the memory path for (streams, row batch) combinations, same process, interleaved
-blocks (rule 24).  usage: python tests/diag_batch_modes.py [M] [configs...]   e.g.  64 2x1 1x2 2x2    /    8 2x1 1x8 2x8 2x4"""
+blocks (rule 24).  usage: python tests/diag_batch_modes.py [M] [configs...]   e.g.  64 2x1 1x2 2x2    /    8 2x1 1x8 2x8 2x4
+env HIDDEN (1024) / FRAMES (64): e.g. HIDDEN=3584 FRAMES=256 ... 8 1x1 1x4 1x8 = BASELINE.json configs[2] (OV-7B width)"""
 import os
 import sys
 import time
@@ -15,7 +16,9 @@ def main():
     cfgs = [tuple(int(v) for v in c.split("x")) for c in (sys.argv[2:] or ["2x1", "1x2", "2x2"])]
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    model, arch = bench.build_model(dev, mem_tokens=M, seed=4321 if M == 8 else 1234)
+    bench.HIDDEN = int(os.environ.get("HIDDEN", bench.HIDDEN))
+    bench.FRAMES = int(os.environ.get("FRAMES", bench.FRAMES))
+    model, arch = bench.build_model(dev, hidden=bench.HIDDEN, mem_tokens=M, seed=4321 if M == 8 else 1234)
     idx = torch.arange(bench.FRAMES)
     g = torch.Generator(device="cpu").manual_seed(100)
     nmax = max(s * b for s, b in cfgs)
@@ -30,7 +33,7 @@ def main():
         n = c[0] * c[1]
         return pools[c].run([(x, idx) for x in xs[:n]], mp, fp, model.image_newline)
 
-    steps = int(os.environ.get("STEPS", "20"))
+    steps = int(os.environ.get("STEPS", "20" if bench.HIDDEN <= 1024 else "4"))
     res = {c: [] for c in cfgs}
     with torch.no_grad():
         for c in cfgs:
@@ -45,7 +48,7 @@ def main():
                     step(c)
                 torch.cuda.synchronize()
                 res[c].append((time.perf_counter() - t0) / steps)
-    fl = bench.algorithmic_flops(M=M)
+    fl = bench.algorithmic_flops(M=M, frames=bench.FRAMES, D=bench.HIDDEN)
     for c in cfgs:
         ts = sorted(res[c])
         med = ts[len(ts) // 2]

@@ -14,10 +14,10 @@ TAG=${1:-r03}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT" && mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp MAVLM_BENCH_M8=0
-B="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --repeats 2 --min-seconds 0"
+B="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-latency --repeats 2 --min-seconds 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -- $B --videos-in-flight 1 > $OUT/stats1.json 2> $OUT/stats1.err || echo "stats1 failed"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats2 -- $B > $OUT/stats2.json 2> $OUT/stats2.err || echo "stats2 failed"
-P="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --repeats 1 --min-seconds 0 --videos-in-flight 1"
+P="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency --repeats 1 --min-seconds 0 --videos-in-flight 1"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/mfma -- $P > $OUT/mfma.json 2> $OUT/mfma.err || echo "mfma failed"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $P > $OUT/fetch.json 2> $OUT/fetch.err || echo "fetch failed"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $P > $OUT/write.json 2> $OUT/write.err || echo "write failed"
