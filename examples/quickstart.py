@@ -60,6 +60,19 @@ def main():
         dt2 = (time.perf_counter() - t0) / 20
     print(f"2 in flight: {dt2 * 1e3:.2f} ms/video ({T / dt2:,.0f} frames/s)")
 
+    # ---- row batches: 8 videos stepped together per stream (their memory rows stacked into every weight-shared GEMM) ----
+    with torch.no_grad():
+        vids = [(torch.randn_like(frames) * 0.5, idx) for _ in range(16)]
+        pool8 = arch.MemoryPathPool(model, 2, batch=8)
+        pool8.run(vids, mp, fp, model.image_newline)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            pool8.run(vids, mp, fp, model.image_newline)
+        torch.cuda.synchronize()
+        dt8 = (time.perf_counter() - t0) / (5 * len(vids))
+    print(f"2 streams x row batch of 8: {dt8 * 1e3:.3f} ms/video ({T / dt8:,.0f} frames/s)")
+
     # ---- hipGraph: the whole per-video launch sequence as one graph ---------------------------------------------
     g = arch.GraphedVideoMemory(model, T, idx)
     out = g(frames, mp.detach(), fp.detach(), model.image_newline)
