@@ -10,13 +10,6 @@
 //     OLDEST operation of the tile's first K-tile, so the counted vmcnt(6) waits are unchanged) and are read from
 //     LDS; the residual add of the LN-fused epilogue is done by the LayerNorm kernel instead (EPI_F32 here).
 //   * Epilogue stores count in vmcnt too, but they are older than the three half-tiles that stay in flight.
-//   * DEFERRED STORES (round 3, 16-bit epilogues): all workgroups run in lock-step, so their epilogues used to hit HBM
-//     together - 28.7 MB per round of 256 tiles, 5-6 us during which nothing computes (a quarter of a K = 1024 tile).  The
-//     epilogue of every tile but a workgroup's last now only converts: the 16-bit tile (14-16 registers of 16 B per lane)
-//     stays in registers and is stored one 16-byte piece per phase during the first four K-tiles of the NEXT tile, so the
-//     writes of a round are spread over ~5 us of MFMA work.  The stores are VMEM operations in the same in-order queue as
-//     the DMAs: the counted wait of those K-tiles is vmcnt(8) instead of vmcnt(6) (the two stores of phases 3 and 4 are
-//     younger than the half-tile it must see landed).
 // Same contract as gemm_tn_kernel (gemm.hip): C[M,N] = epi(A[M,K] . W[N,K]^T + bias), nn.Linear layout.
 //
 // Structure (after cdna_hip_programming.md "The 256^2 8-phase template", re-derived for this layout):
@@ -44,12 +37,6 @@
 #include "mavlm_kernels.h"
 
 namespace {
-
-template <int V>
-struct pic { static constexpr int value = V; };
-#ifndef MAVLM_GEMM256P_NID
-#define MAVLM_GEMM256P_NID(MT1) ((MT1) == 3 ? 5 : 4)      // deferred 16-row groups of the wave's 7 / 8 (252 / 256 VGPRs, no spill)
-#endif
 
 constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
 constexpr int HALF = 128 * BK2 * 2;          // 16 KiB half-tile
@@ -212,58 +199,20 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
 
   if (trailing) MAVLM_BAR();           // ping-pong skew: pairs with the leading group's first in-loop barrier
 
-  // element offset of output row m; row-batched outputs: see gemm256_kernel / mavlm_gemm_args::c_rpb
-  auto crow = [&](int m) -> size_t {
-    if (c_rpb <= 0) return (size_t)m * ldc;
-    const int q = m / c_rpb, r = m - q * c_rpb;
-    return (size_t)(q % c_nb) * (size_t)c_bs + ((size_t)(q / c_nb) * c_rpb + r) * ldc;
-  };
-  // deferred stores of the previous tile (header): piece idx = (i, j pair) of the 16-bit tile, origin (pm0, pn0)
-  // (registers: the whole 16-bit tile would be 56-64 registers on top of 210-226 - it spills.  NID row groups are deferred,
-  // the rest of the tile is stored in the epilogue as before)
-  constexpr int NI = 4 + MT1, NID = MAVLM_GEMM256P_NID(MT1), NP = 2 * NID;
-  constexpr bool DEFER = EPI != MAVLM_EPI_F32;
-  const bool defer_ok = DEFER && nk >= 4;
-  u32x4 pend[NP];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) pend[i] = u32x4{0u, 0u, 0u, 0u};
-  int pm0 = 0, pn0 = 0;
-  bool has_pend = false;               // (wave-uniform)
-  auto pend_store = [&](auto ic) {
-    constexpr int idx = decltype(ic)::value;
-    if constexpr (idx < NP) {
-      constexpr int i = idx >> 1, j = (idx & 1) * 2;
-      const int m = pm0 + wm * MHALF + i * 16 + fr;
-      const int n = pn0 + wn * 64 + 16 * (j + (fq & 1)) + 8 * (fq >> 1);
-      if (m < M) *(u32x4*)((uint16_t*)Cout + crow(m) + n) = pend[idx];
-    }
-  };
-  // phase P (0..3) of K-tile kt (0..3) stores piece 4 kt + P
-#define MAVLM_PEND_PHASE(P)                                                       \
-  if (ps) {                                                                       \
-    if (kt == 0) pend_store(pic<P>{});                                            \
-    else if (kt == 1) pend_store(pic<4 + P>{});                                   \
-    else if (kt == 2) pend_store(pic<8 + P>{});                                   \
-    else pend_store(pic<12 + P>{});                                               \
-  }
-
   int v = 0;
   for (int it = 0; it < ntl; ++it) {
     for (int kt = 0; kt < nk; ++kt, ++v) {
       const char* st = smem + (v & 1) * STAGE2;
-      const bool ps = DEFER && has_pend && kt < 4;          // (wave-uniform) this K-tile carries stores of the previous tile
       // -------- phase 1
       read_a(st, 0);
       read_b_half(st, 0);
-      MAVLM_PEND_PHASE(0)
       MAVLM_BAR();
       MAVLM_LGKM0();
       MAVLM_QUADRANT(0, 0)
       MAVLM_BAR();
       // -------- phase 2
       read_b_half(st, 1);
-      MAVLM_PEND_PHASE(1)
-      if (kt == 0 && it > 0) dma_bias(it, n0c);              // older than every DMA of this K-tile
+      if (kt == 0 && it > 0) dma_bias(it, n0c);              // oldest VMEM operation of this K-tile
       if (v + 1 < VT) dma(1, v + 1, it);                     // A1 of the next virtual K-tile
       MAVLM_BAR();
       MAVLM_LGKM0();
@@ -271,29 +220,22 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
       MAVLM_BAR();
       // -------- phase 3   (B half-tiles of this stage are dead: everything is in registers)
       read_a(st, 1);
-      MAVLM_PEND_PHASE(2)
       if (v + 2 < VT) dma(2, v + 2, it);
       MAVLM_BAR();
       MAVLM_LGKM0();
       MAVLM_QUADRANT(1, 1)
       MAVLM_BAR();
       // -------- phase 4   (A half-tiles dead)
-      MAVLM_PEND_PHASE(3)
       if (v + 2 < VT) {
         dma(3, v + 2, it);
         dma(0, v + 2, it);
-        // K-tile v+1 landed; 3 half-tiles of v+2 stay in flight - and, in a K-tile that carries deferred stores, the stores
-        // of phases 3 and 4, which are younger than the last half-tile of v+1 (pieces 4 kt + 2 / + 3, where they exist)
-        if (ps && 4 * kt + 3 < NP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ps && 4 * kt + 2 < NP) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // K-tile v+1 landed; 3 half-tiles of v+2 stay in flight
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       MAVLM_BAR();
       MAVLM_QUADRANT(1, 0)
       MAVLM_BAR();
-      if (kt == 3) has_pend = false;
     }
 
     // ---- epilogue of tile `it` (no barriers, no VMEM loads): the next tile's first K-tiles are already in flight.
@@ -307,7 +249,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
       if (EPI == MAVLM_EPI_GELU) return gelu_erf_fast(v);
       return v;
     };
-    const bool defer = defer_ok && it + 1 < ntl;            // the next tile's K loop will carry this tile's stores
+    // element offset of output row m; row-batched outputs: see gemm256_kernel / mavlm_gemm_args::c_rpb
+    auto crow = [&](int m) -> size_t {
+      if (c_rpb <= 0) return (size_t)m * ldc;
+      const int q = m / c_rpb, r = m - q * c_rpb;
+      return (size_t)(q % c_nb) * (size_t)c_bs + ((size_t)(q / c_nb) * c_rpb + r) * ldc;
+    };
 #pragma unroll
     for (int i = 0; i < 4 + MT1; ++i) {
       const int m = m0c + wm * MHALF + i * 16 + fr;
@@ -329,14 +276,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
           const u32x4 w = widen_pair(pack4<T>(act(x[0]), act(x[1]), act(x[2]), act(x[3])),
                                      pack4<T>(act(y[0]), act(y[1]), act(y[2]), act(y[3])));
           const int n = n0c + wn * 64 + 16 * (j + (fq & 1)) + 8 * (fq >> 1);
-          if constexpr (DEFER) {
-            if (i < NID) pend[2 * i + (j >> 1)] = w;          // (i is a literal: the loop is unrolled)
-          }
-          if ((!defer || i >= NID) && m < M) *(u32x4*)((uint16_t*)Cout + co + n) = w;
+          if (m < M) *(u32x4*)((uint16_t*)Cout + co + n) = w;
         }
       }
     }
-    if (defer) { pm0 = m0c; pn0 = n0c; has_pend = true; }
     // ---- next tile becomes current; offsets of the one after it
     if (it + 1 < ntl) {
       tile_origin(it + 1, m0c, n0c);
@@ -353,7 +296,6 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
   }
   if (!trailing) MAVLM_BAR();          // matches the trailing group's last barrier
 #undef MAVLM_QUADRANT
-#undef MAVLM_PEND_PHASE
 }
 
 template <typename T, int EPI, int MT1>
