@@ -105,6 +105,7 @@ SIGNATURES = {
     "mavlm_set_attention_streamk_min_tiles": (C.c_int, [i32]),
     "mavlm_set_attention_streamk_waves": (C.c_int, [i32]),
     "mavlm_set_attention_colsum_wgs": (C.c_int, [i32]),
+    "mavlm_set_attention_wide_groups": (C.c_int, [i32]),
     "mavlm_set_frame_score_mode": (C.c_int, [i32]),
     "mavlm_frame_scores_fused": (C.c_int, [i32, i32, i32, i32]),
     "mavlm_attention_frames_ws_floats": (C.c_int64, [i32, i32, i32, i32]),

@@ -10,6 +10,11 @@
 //   * The S^T accumulators become the B operand of O^T = V^T.P^T without lane movement: k-slot j of group g is
 //     key 4g+j of block 0 (j < 4) or block 1 (j >= 4); the V^T fragment is read with two ds_read_b64_tr_b16 that
 //     follow the same key order.
+//   * QG = 2 (round 3, head_dim 448): a wave takes TWO groups of 16 queries and feeds every K / V^T fragment it reads from
+//     LDS to both (2 MFMAs per fragment read).  The 16-query form is LDS-read bound - every wave reads the whole 32-key K and
+//     V tiles, 16 flop per LDS byte = the MFMA peak at the full LDS rate - the 32-query form halves the LDS bytes per flop.
+//     Costs registers: O^T 2 x 112 (accumulator file) + Q fragments 2 x 56 -> 4 waves of 32 queries per workgroup, one wave
+//     per SIMD (512-register budget).
 //   * 8 waves (128 queries) per workgroup, 32-key K/V tiles by LDS-DMA into a 2-stage ring.  A tile row is padded to
 //     HDP = ceil(HD/128)*128 columns and stored as HDP/128 sub-images of [32 keys][256 B] with the swizzle of
 //     attention.hip (2-way conflicts for the 16x16x32 operand reads, as the guide documents for this image).
@@ -47,8 +52,8 @@ __device__ __forceinline__ float xgroup_sum(float v) {
   return a + b;
 }
 
-template <typename T, int HD>
-__global__ __launch_bounds__(512, 2) void attn_fwd_hd_kernel(const uint16_t* __restrict__ Q, int ldq,
+template <typename T, int HD, int QG>
+__global__ __launch_bounds__(512 / QG, 2 / QG) void attn_fwd_hd_kernel(const uint16_t* __restrict__ Q, int ldq,
                                                              const uint16_t* __restrict__ K, int ldk,
                                                              const uint16_t* __restrict__ V, int ldv,
                                                              uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
@@ -83,27 +88,29 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd_kernel(const uint16_t* __r
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NWV = 8 / QG;                             // waves per workgroup (128 queries either way)
   const int h = blockIdx.x % H;
-  const int q0 = (blockIdx.x / H) * 128 + wave * 16;
+  const int q0 = (blockIdx.x / H) * 128 + wave * 16 * QG;  // + 16 qg
   const int qi = lane & 15, g = lane >> 4;
   const int nt = (S + KTH - 1) / KTH;
 
-  // ---- Q fragments (B operand): lane holds Q[q0+qi][h*HD + 32ks + 8g + 0..7]
-  typename T::vec8 qf[KS];
-  {
-    int qrow = q0 + qi;
+  // ---- Q fragments (B operand): lane holds Q[q0 + 16 qg + qi][h*HD + 32ks + 8g + 0..7]
+  typename T::vec8 qf[QG][KS];
+#pragma unroll
+  for (int qg = 0; qg < QG; ++qg) {
+    int qrow = q0 + 16 * qg + qi;
     qrow = qrow < R ? qrow : R - 1;
     const uint16_t* qp = Q + (size_t)qrow * ldq + h * HD + 8 * g;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const typename T::vec8*)(qp + 32 * ks);
+    for (int ks = 0; ks < KS; ++ks) qf[qg][ks] = *(const typename T::vec8*)(qp + 32 * ks);
   }
 
   // ---- LDS-DMA: a tile is NSUB*8 instructions of 1 KiB (4 rows of one sub-image); wave w issues instruction ids
   // w, w+8, ...  Instruction id = sub*8 + rg writes rows 4rg..4rg+3 of sub-image `sub`.
   auto dma_tile = [&](const uint16_t* base, int ld, int t, char* dst) {
 #pragma unroll
-    for (int k = 0; k < NSUB; ++k) {
-      const int id = wave + 8 * k;                        // wave-uniform
+    for (int k = 0; k < NSUB * QG; ++k) {
+      const int id = wave + NWV * k;                      // wave-uniform
       const int sub = id >> 3, rg = id & 7;
       const int row = 4 * rg + (lane >> 4);
       int ch = (lane & 15) ^ imgh_x(row);                 // logical chunk of the sub-image stored at physical lane&15
@@ -127,15 +134,22 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd_kernel(const uint16_t* __r
   const int vx = imgh_x(vrow);                            // same for vrow + 16
   const unsigned vbase_off = 256 * vrow + 8 * (tp & 1);
 
-  f32x4 ot[DB];
+  f32x4 ot[QG][DB];
+  float m_run[QG], l_run[QG];
 #pragma unroll
-  for (int d = 0; d < DB; ++d) ot[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -1e30f, l_run = 0.f;
+  for (int qg = 0; qg < QG; ++qg) {
+#pragma unroll
+    for (int d = 0; d < DB; ++d) ot[qg][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m_run[qg] = -1e30f;
+    l_run[qg] = 0.f;
+  }
 
   dma_tile(K, ldk, 0, smem);
   dma_tile(V, ldv, 0, smem + TILE);
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+  for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[qg][ks]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -150,10 +164,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd_kernel(const uint16_t* __r
       dma_tile(V, ldv, t + 1, smem + (cur ^ 1) * 2 * TILE + TILE);
     }
 
-    // ---- S^T = K.Q^T : 2 key blocks x KS k-steps
-    f32x4 st[2];
-    st[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    st[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- S^T = K.Q^T : 2 key blocks x KS k-steps; every K fragment feeds the QG query groups of the wave
+    f32x4 st[QG][2];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+      st[qg][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      st[qg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int gch = 4 * ks;                             // + g ; sub-image = gch>>4 is compile-time, (gch&15)+g < 16
@@ -161,49 +178,62 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd_kernel(const uint16_t* __r
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const typename T::vec8 kf = *(const typename T::vec8*)(kb + off + 4096 * b);
-        st[b] = T::mfma16(kf, qf[ks], st[b]);
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) st[qg][b] = T::mfma16(kf, qf[qg][ks], st[qg][b]);
       }
     }
     if (t == nt - 1 && (S & (KTH - 1))) {                 // ragged tail: key = 32t + 16b + 4g + r
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int qg = 0; qg < QG; ++qg)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (t * KTH + 16 * b + 4 * g + r >= S) st[b][r] = -INFINITY;
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (t * KTH + 16 * b + 4 * g + r >= S) st[qg][b][r] = -INFINITY;
     }
 
-    // ---- online softmax with deferred rescale (same rule as attn_fwd3_kernel; wave-uniform decision)
-    float mx = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])),
-                     fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
-    mx = xgroup_max(mx);
-    const float m_new = fmaxf(m_run, mx);
-    if (__any((m_new - m_run) * c > RESCALE_H_LOG2)) {
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      m_run = m_new;
-      l_run *= alpha;
+    // ---- online softmax with deferred rescale (same rule as attn_fwd3_kernel; the decision is uniform per 16-query group:
+    // a group's queries sit on all 64 lanes, so `__any` per group - as the 16-query wave of the QG = 1 form decides)
+    typename T::vec8 pf[QG];
 #pragma unroll
-      for (int d = 0; d < DB; ++d) ot[d] *= alpha;
-    }
-    const float mc = m_run * c;
-    float psum = 0.f;
+    for (int qg = 0; qg < QG; ++qg) {
+      float mx = fmaxf(fmaxf(fmaxf(st[qg][0][0], st[qg][0][1]), fmaxf(st[qg][0][2], st[qg][0][3])),
+                       fmaxf(fmaxf(st[qg][1][0], st[qg][1][1]), fmaxf(st[qg][1][2], st[qg][1][3])));
+      mx = xgroup_max(mx);
+      const float m_new = fmaxf(m_run[qg], mx);
+      if (__any((m_new - m_run[qg]) * c > RESCALE_H_LOG2)) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qg] - m_new) * c);
+        m_run[qg] = m_new;
+        l_run[qg] *= alpha;
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        st[b][r] = __builtin_amdgcn_exp2f(st[b][r] * c - mc);
-        psum += st[b][r];
+        for (int d = 0; d < DB; ++d) {
+          f32x4 v = ot[qg][d];
+          if constexpr (QG > 1) asm volatile("" : "+a"(v));   // O^T lives in the accumulator file: without this pin hipcc
+          v *= alpha;                                         // hoists the 224 v_accvgpr_read out of this rare branch to
+          ot[qg][d] = v;                                      // the top of every tile (and spills the Q fragments for it)
+        }
       }
-    l_run += psum;                                        // per-lane partial; lane groups are summed at the end
-    u32x4 pw;
-    pw[0] = pack2<T>(st[0][0], st[0][1]); pw[1] = pack2<T>(st[0][2], st[0][3]);
-    pw[2] = pack2<T>(st[1][0], st[1][1]); pw[3] = pack2<T>(st[1][2], st[1][3]);
-    const typename T::vec8 pf = __builtin_bit_cast(typename T::vec8, pw);
+      const float mc = m_run[qg] * c;
+      float psum = 0.f;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          st[qg][b][r] = __builtin_amdgcn_exp2f(st[qg][b][r] * c - mc);
+          psum += st[qg][b][r];
+        }
+      l_run[qg] += psum;                                  // per-lane partial; lane groups are summed at the end
+      u32x4 pw;
+      pw[0] = pack2<T>(st[qg][0][0], st[qg][0][1]); pw[1] = pack2<T>(st[qg][0][2], st[qg][0][3]);
+      pw[2] = pack2<T>(st[qg][1][0], st[qg][1][1]); pw[3] = pack2<T>(st[qg][1][2], st[qg][1][3]);
+      pf[qg] = __builtin_bit_cast(typename T::vec8, pw);
+    }
 
     // ---- O^T += V^T.P^T : DB blocks of 16 columns, one 32-key k-step.  The transposed reads are inline asm with
     // hand-counted lgkmcnt waits (as attn_fwd3_kernel): through the builtin hipcc puts an s_waitcnt vmcnt(0) in front of
     // the first one (it cannot prove that the read does not alias the LDS-DMA in flight), which drained the next tile's
     // DMAs in the middle of this one.  Step db issues the two reads of step db + 2, then waits until only the younger
-    // reads are outstanding.
+    // reads are outstanding.  A V^T fragment feeds the QG query groups.
     const unsigned vbl = (unsigned)(uintptr_t)(MAVLM_LDS const char*)vb;
     {
       u32x2 vlo[DB], vhi[DB];
@@ -226,7 +256,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd_kernel(const uint16_t* __r
         __builtin_amdgcn_sched_barrier(0);                    // keep the MFMA below the wait
         u32x4 both;
         both[0] = vlo[db][0]; both[1] = vlo[db][1]; both[2] = vhi[db][0]; both[3] = vhi[db][1];
-        ot[db] = T::mfma16(__builtin_bit_cast(typename T::vec8, both), pf, ot[db]);
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) ot[qg][db] = T::mfma16(__builtin_bit_cast(typename T::vec8, both), pf[qg], ot[qg][db]);
         __builtin_amdgcn_sched_barrier(0);
       };
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // nothing older than the reads below is outstanding
@@ -243,22 +274,25 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd_kernel(const uint16_t* __r
   }
 
   // ---- epilogue: O[q][h*HD + 16 db + 4g + 0..3] = O^T / l
-  const float l_tot = xgroup_sum(l_run);
-  const float inv = 1.0f / l_tot;
-  const int q = q0 + qi;
-  if (q < R) {
-    if (tps > 0) {
-      float* pp = Opart + ((size_t)split * R + q) * (H * HD) + h * HD + 4 * g;
 #pragma unroll
-      for (int db = 0; db < DB; ++db)
-        *(f32x4*)(pp + 16 * db) = f32x4{ot[db][0] * inv, ot[db][1] * inv, ot[db][2] * inv, ot[db][3] * inv};
-      if (g == 0) lse_part[((size_t)split * H + h) * R + q] = m_run * c + log2f(l_tot);
-    } else {
-      uint16_t* op = O + (size_t)q * ldo + h * HD + 4 * g;
+  for (int qg = 0; qg < QG; ++qg) {
+    const float l_tot = xgroup_sum(l_run[qg]);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + 16 * qg + qi;
+    if (q < R) {
+      if (tps > 0) {
+        float* pp = Opart + ((size_t)split * R + q) * (H * HD) + h * HD + 4 * g;
 #pragma unroll
-      for (int db = 0; db < DB; ++db)
-        *(u32x2*)(op + 16 * db) = pack4<T>(ot[db][0] * inv, ot[db][1] * inv, ot[db][2] * inv, ot[db][3] * inv);
-      if (lse2 != nullptr && g == 0) lse2[(size_t)h * R + q] = m_run * c + log2f(l_tot);
+        for (int db = 0; db < DB; ++db)
+          *(f32x4*)(pp + 16 * db) = f32x4{ot[qg][db][0] * inv, ot[qg][db][1] * inv, ot[qg][db][2] * inv, ot[qg][db][3] * inv};
+        if (g == 0) lse_part[((size_t)split * H + h) * R + q] = m_run[qg] * c + log2f(l_tot);
+      } else {
+        uint16_t* op = O + (size_t)q * ldo + h * HD + 4 * g;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+          *(u32x2*)(op + 16 * db) = pack4<T>(ot[qg][db][0] * inv, ot[qg][db][1] * inv, ot[qg][db][2] * inv, ot[qg][db][3] * inv);
+        if (lse2 != nullptr && g == 0) lse2[(size_t)h * R + q] = m_run[qg] * c + log2f(l_tot);
+      }
     }
   }
 }
@@ -358,10 +392,10 @@ __global__ __launch_bounds__(256, 1) void attn_colsum_hd_kernel(const uint16_t* 
   }
 }
 
-template <typename T, int HD>
+template <typename T, int HD, int QG>
 hipError_t launch_fwd_hd(const mavlm_attn_args& a, hipStream_t s) {
   constexpr int LDS = 4 * ((HD + 127) / 128) * KTH * 256;
-  auto kern = attn_fwd_hd_kernel<T, HD>;
+  auto kern = attn_fwd_hd_kernel<T, HD, QG>;
   static mavlm_per_device_once once;
   {
     hipError_t e = once.dyn_lds((const void*)kern, LDS);
@@ -377,7 +411,7 @@ hipError_t launch_fwd_hd(const mavlm_attn_args& a, hipStream_t s) {
   float* opart = a.split_ws;
   float* lpart = ns > 1 ? a.split_ws + (size_t)ns * a.R * a.H * HD : nullptr;
   mavlm_prof_scope prof(MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD, 2.0 * HD * a.H * (2.0 * a.R + 2.0 * a.S), s);
-  hipLaunchKernelGGL(kern, dim3(((a.R + 127) / 128) * Hv, ns, nb), dim3(512), LDS, s, (const uint16_t*)a.Q, a.ldq,
+  hipLaunchKernelGGL(kern, dim3(((a.R + 127) / 128) * Hv, ns, nb), dim3(512 / QG), LDS, s, (const uint16_t*)a.Q, a.ldq,
                      (const uint16_t*)a.K, a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, Hv, c,
                      opart, lpart, tps, (long long)a.kv_bstride);
   if (ns > 1) return mavlm_launch_attention_combine(opart, lpart, a.O, a.ldo, a.lse2, a.R, a.H, HD, ns, std::is_same<T, F16>::value ? MAVLM_F16 : MAVLM_BF16, s);
@@ -423,13 +457,18 @@ size_t mavlm_attention_hd_split_ws_floats(int R, int S, int H, int head_dim) {
   return ns > 1 ? (size_t)ns * R * H * head_dim + (size_t)ns * H * R : 0;
 }
 
+int g_mavlm_attn_hd_qg = 0;      // tuning hook: 0 = automatic (two query groups per wave at head_dim 448), 1 / 2 = forced
 hipError_t mavlm_launch_attention_hd(const mavlm_attn_args& a, int head_dim, int dtype, hipStream_t s) {
   const bool f16 = dtype == MAVLM_F16;
-  if (head_dim == 448) return f16 ? launch_fwd_hd<F16, 448>(a, s) : launch_fwd_hd<BF16, 448>(a, s);
-  if (head_dim == 128) return f16 ? launch_fwd_hd<F16, 128>(a, s) : launch_fwd_hd<BF16, 128>(a, s);
+  if (head_dim == 448) {
+    // same arithmetic per query either way (a 16-query group decides its rescales alone): results are bit-identical
+    if (g_mavlm_attn_hd_qg != 1) return f16 ? launch_fwd_hd<F16, 448, 2>(a, s) : launch_fwd_hd<BF16, 448, 2>(a, s);
+    return f16 ? launch_fwd_hd<F16, 448, 1>(a, s) : launch_fwd_hd<BF16, 448, 1>(a, s);
+  }
+  if (head_dim == 128) return f16 ? launch_fwd_hd<F16, 128, 1>(a, s) : launch_fwd_hd<BF16, 128, 1>(a, s);
   // 4-head encoder of the inactive MemoryFuser variant (MemoryFuser.py:12-19): hidden 1024 / 896 over nhead = 4
-  if (head_dim == 256) return f16 ? launch_fwd_hd<F16, 256>(a, s) : launch_fwd_hd<BF16, 256>(a, s);
-  if (head_dim == 224) return f16 ? launch_fwd_hd<F16, 224>(a, s) : launch_fwd_hd<BF16, 224>(a, s);
+  if (head_dim == 256) return f16 ? launch_fwd_hd<F16, 256, 1>(a, s) : launch_fwd_hd<BF16, 256, 1>(a, s);
+  if (head_dim == 224) return f16 ? launch_fwd_hd<F16, 224, 1>(a, s) : launch_fwd_hd<BF16, 224, 1>(a, s);
   return hipErrorInvalidValue;
 }
 

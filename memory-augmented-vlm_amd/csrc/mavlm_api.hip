@@ -406,6 +406,12 @@ int mavlm_frame_scores_fused(int32_t R, int32_t S, int32_t H, int32_t patches) {
           mavlm_attention_frames_supported(R, S, H, patches) && mavlm_attention_splits(R, S, H, nullptr) <= 1) ? 1 : 0;
 }
 
+int mavlm_set_attention_wide_groups(int32_t groups) {
+  if (groups < 0 || groups > 2) return MAVLM_E_ARG;
+  g_mavlm_attn_hd_qg = groups;
+  return 0;
+}
+
 int mavlm_set_frame_score_mode(int32_t mode) {
   if (mode != 0 && mode != 1) return MAVLM_E_ARG;
   g_mavlm_frame_score_mode = mode;

@@ -100,6 +100,7 @@ hipError_t mavlm_launch_attention_combine(const float* opart, const float* lpart
                                           int hd, int ns, int dtype, hipStream_t s);
 // software-pipelined LDS-DMA variant (attention3.hip); mavlm_launch_attention dispatches to it
 hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStream_t s);
+extern int g_mavlm_attn_hd_qg;  // head_dim-448 forward: 0 = auto (2 query groups per wave), 1 / 2 = forced (tuning hook)
 extern int g_mavlm_attn_impl;   // 0 = auto, 2 = register-staged kernel, 3 = pipelined kernel (tuning hook)
 
 // backward of the head_dim-128 attention (attention_bwd.hip); any of dQ / dK / dV may be null (skipped)
