@@ -337,9 +337,9 @@ int mavlm_set_attention_streamk_waves(int32_t waves);
 /* workgroups of the column-sum pass's balanced schedule: 0 = automatic (512), or 64 .. 1024.  Changes the fp32 summation
  * order of the column sums (pieces per unit), nothing else. */
 int mavlm_set_attention_colsum_wgs(int32_t wgs);
-/* query groups per wave of the head_dim-448 forward: 0 = automatic (2: a wave of 32 queries feeds every K / V fragment it
- * reads to two 16-query groups), 1 = the 16-query wave of rounds 1-2.  Bit-identical results (each 16-query group keeps its
- * own running maximum and rescale decisions). */
+/* the head_dim-448 forward: 0 = automatic (2), 2 = 32-query waves (two 16-query groups share every K / V fragment read from
+ * LDS; software-pipelined tile loop), 1 = the 16-query waves of rounds 1-2.  Same rounding points; the fp32 row sums are added
+ * in a different order (results agree to fp32 rounding, not bit for bit). */
 int mavlm_set_attention_wide_groups(int32_t groups);
 /* how mavlm_step obtains the frame scores of the last formation layer (head_dim <= 128, patches % 4 == 0, <= 64 frames per
  * chunk): 1 (default) = fused into that layer's attention forward - every query row carries the probability mass of the

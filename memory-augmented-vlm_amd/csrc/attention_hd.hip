@@ -10,11 +10,6 @@
 //   * The S^T accumulators become the B operand of O^T = V^T.P^T without lane movement: k-slot j of group g is
 //     key 4g+j of block 0 (j < 4) or block 1 (j >= 4); the V^T fragment is read with two ds_read_b64_tr_b16 that
 //     follow the same key order.
-//   * QG = 2 (round 3, head_dim 448): a wave takes TWO groups of 16 queries and feeds every K / V^T fragment it reads from
-//     LDS to both (2 MFMAs per fragment read).  The 16-query form is LDS-read bound - every wave reads the whole 32-key K and
-//     V tiles, 16 flop per LDS byte = the MFMA peak at the full LDS rate - the 32-query form halves the LDS bytes per flop.
-//     Costs registers: O^T 2 x 112 (accumulator file) + Q fragments 2 x 56 -> 4 waves of 32 queries per workgroup, one wave
-//     per SIMD (512-register budget).
 //   * 8 waves (128 queries) per workgroup, 32-key K/V tiles by LDS-DMA into a 2-stage ring.  A tile row is padded to
 //     HDP = ceil(HD/128)*128 columns and stored as HDP/128 sub-images of [32 keys][256 B] with the swizzle of
 //     attention.hip (2-way conflicts for the 16x16x32 operand reads, as the guide documents for this image).
@@ -52,8 +47,8 @@ __device__ __forceinline__ float xgroup_sum(float v) {
   return a + b;
 }
 
-template <typename T, int HD, int QG>
-__global__ __launch_bounds__(512 / QG, 2 / QG) void attn_fwd_hd_kernel(const uint16_t* __restrict__ Q, int ldq,
+template <typename T, int HD>
+__global__ __launch_bounds__(512, 2) void attn_fwd_hd_kernel(const uint16_t* __restrict__ Q, int ldq,
                                                              const uint16_t* __restrict__ K, int ldk,
                                                              const uint16_t* __restrict__ V, int ldv,
                                                              uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
@@ -88,29 +83,27 @@ __global__ __launch_bounds__(512 / QG, 2 / QG) void attn_fwd_hd_kernel(const uin
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int NWV = 8 / QG;                             // waves per workgroup (128 queries either way)
   const int h = blockIdx.x % H;
-  const int q0 = (blockIdx.x / H) * 128 + wave * 16 * QG;  // + 16 qg
+  const int q0 = (blockIdx.x / H) * 128 + wave * 16;
   const int qi = lane & 15, g = lane >> 4;
   const int nt = (S + KTH - 1) / KTH;
 
-  // ---- Q fragments (B operand): lane holds Q[q0 + 16 qg + qi][h*HD + 32ks + 8g + 0..7]
-  typename T::vec8 qf[QG][KS];
-#pragma unroll
-  for (int qg = 0; qg < QG; ++qg) {
-    int qrow = q0 + 16 * qg + qi;
+  // ---- Q fragments (B operand): lane holds Q[q0+qi][h*HD + 32ks + 8g + 0..7]
+  typename T::vec8 qf[KS];
+  {
+    int qrow = q0 + qi;
     qrow = qrow < R ? qrow : R - 1;
     const uint16_t* qp = Q + (size_t)qrow * ldq + h * HD + 8 * g;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[qg][ks] = *(const typename T::vec8*)(qp + 32 * ks);
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const typename T::vec8*)(qp + 32 * ks);
   }
 
   // ---- LDS-DMA: a tile is NSUB*8 instructions of 1 KiB (4 rows of one sub-image); wave w issues instruction ids
   // w, w+8, ...  Instruction id = sub*8 + rg writes rows 4rg..4rg+3 of sub-image `sub`.
   auto dma_tile = [&](const uint16_t* base, int ld, int t, char* dst) {
 #pragma unroll
-    for (int k = 0; k < NSUB * QG; ++k) {
-      const int id = wave + NWV * k;                      // wave-uniform
+    for (int k = 0; k < NSUB; ++k) {
+      const int id = wave + 8 * k;                        // wave-uniform
       const int sub = id >> 3, rg = id & 7;
       const int row = 4 * rg + (lane >> 4);
       int ch = (lane & 15) ^ imgh_x(row);                 // logical chunk of the sub-image stored at physical lane&15
@@ -134,22 +127,15 @@ __global__ __launch_bounds__(512 / QG, 2 / QG) void attn_fwd_hd_kernel(const uin
   const int vx = imgh_x(vrow);                            // same for vrow + 16
   const unsigned vbase_off = 256 * vrow + 8 * (tp & 1);
 
-  f32x4 ot[QG][DB];
-  float m_run[QG], l_run[QG];
+  f32x4 ot[DB];
 #pragma unroll
-  for (int qg = 0; qg < QG; ++qg) {
-#pragma unroll
-    for (int d = 0; d < DB; ++d) ot[qg][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    m_run[qg] = -1e30f;
-    l_run[qg] = 0.f;
-  }
+  for (int d = 0; d < DB; ++d) ot[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;
 
   dma_tile(K, ldk, 0, smem);
   dma_tile(V, ldv, 0, smem + TILE);
 #pragma unroll
-  for (int qg = 0; qg < QG; ++qg)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[qg][ks]));
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -164,13 +150,10 @@ __global__ __launch_bounds__(512 / QG, 2 / QG) void attn_fwd_hd_kernel(const uin
       dma_tile(V, ldv, t + 1, smem + (cur ^ 1) * 2 * TILE + TILE);
     }
 
-    // ---- S^T = K.Q^T : 2 key blocks x KS k-steps; every K fragment feeds the QG query groups of the wave
-    f32x4 st[QG][2];
-#pragma unroll
-    for (int qg = 0; qg < QG; ++qg) {
-      st[qg][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      st[qg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    // ---- S^T = K.Q^T : 2 key blocks x KS k-steps
+    f32x4 st[2];
+    st[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    st[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int gch = 4 * ks;                             // + g ; sub-image = gch>>4 is compile-time, (gch&15)+g < 16
@@ -178,62 +161,49 @@ __global__ __launch_bounds__(512 / QG, 2 / QG) void attn_fwd_hd_kernel(const uin
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const typename T::vec8 kf = *(const typename T::vec8*)(kb + off + 4096 * b);
-#pragma unroll
-        for (int qg = 0; qg < QG; ++qg) st[qg][b] = T::mfma16(kf, qf[qg][ks], st[qg][b]);
+        st[b] = T::mfma16(kf, qf[ks], st[b]);
       }
     }
     if (t == nt - 1 && (S & (KTH - 1))) {                 // ragged tail: key = 32t + 16b + 4g + r
 #pragma unroll
-      for (int qg = 0; qg < QG; ++qg)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (t * KTH + 16 * b + 4 * g + r >= S) st[qg][b][r] = -INFINITY;
-    }
-
-    // ---- online softmax with deferred rescale (same rule as attn_fwd3_kernel; the decision is uniform per 16-query group:
-    // a group's queries sit on all 64 lanes, so `__any` per group - as the 16-query wave of the QG = 1 form decides)
-    typename T::vec8 pf[QG];
-#pragma unroll
-    for (int qg = 0; qg < QG; ++qg) {
-      float mx = fmaxf(fmaxf(fmaxf(st[qg][0][0], st[qg][0][1]), fmaxf(st[qg][0][2], st[qg][0][3])),
-                       fmaxf(fmaxf(st[qg][1][0], st[qg][1][1]), fmaxf(st[qg][1][2], st[qg][1][3])));
-      mx = xgroup_max(mx);
-      const float m_new = fmaxf(m_run[qg], mx);
-      if (__any((m_new - m_run[qg]) * c > RESCALE_H_LOG2)) {
-        const float alpha = __builtin_amdgcn_exp2f((m_run[qg] - m_new) * c);
-        m_run[qg] = m_new;
-        l_run[qg] *= alpha;
-#pragma unroll
-        for (int d = 0; d < DB; ++d) {
-          f32x4 v = ot[qg][d];
-          if constexpr (QG > 1) asm volatile("" : "+a"(v));   // O^T lives in the accumulator file: without this pin hipcc
-          v *= alpha;                                         // hoists the 224 v_accvgpr_read out of this rare branch to
-          ot[qg][d] = v;                                      // the top of every tile (and spills the Q fragments for it)
-        }
-      }
-      const float mc = m_run[qg] * c;
-      float psum = 0.f;
-#pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          st[qg][b][r] = __builtin_amdgcn_exp2f(st[qg][b][r] * c - mc);
-          psum += st[qg][b][r];
-        }
-      l_run[qg] += psum;                                  // per-lane partial; lane groups are summed at the end
-      u32x4 pw;
-      pw[0] = pack2<T>(st[qg][0][0], st[qg][0][1]); pw[1] = pack2<T>(st[qg][0][2], st[qg][0][3]);
-      pw[2] = pack2<T>(st[qg][1][0], st[qg][1][1]); pw[3] = pack2<T>(st[qg][1][2], st[qg][1][3]);
-      pf[qg] = __builtin_bit_cast(typename T::vec8, pw);
+        for (int r = 0; r < 4; ++r)
+          if (t * KTH + 16 * b + 4 * g + r >= S) st[b][r] = -INFINITY;
     }
+
+    // ---- online softmax with deferred rescale (same rule as attn_fwd3_kernel; wave-uniform decision)
+    float mx = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])),
+                     fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
+    mx = xgroup_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    if (__any((m_new - m_run) * c > RESCALE_H_LOG2)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) ot[d] *= alpha;
+    }
+    const float mc = m_run * c;
+    float psum = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st[b][r] = __builtin_amdgcn_exp2f(st[b][r] * c - mc);
+        psum += st[b][r];
+      }
+    l_run += psum;                                        // per-lane partial; lane groups are summed at the end
+    u32x4 pw;
+    pw[0] = pack2<T>(st[0][0], st[0][1]); pw[1] = pack2<T>(st[0][2], st[0][3]);
+    pw[2] = pack2<T>(st[1][0], st[1][1]); pw[3] = pack2<T>(st[1][2], st[1][3]);
+    const typename T::vec8 pf = __builtin_bit_cast(typename T::vec8, pw);
 
     // ---- O^T += V^T.P^T : DB blocks of 16 columns, one 32-key k-step.  The transposed reads are inline asm with
     // hand-counted lgkmcnt waits (as attn_fwd3_kernel): through the builtin hipcc puts an s_waitcnt vmcnt(0) in front of
     // the first one (it cannot prove that the read does not alias the LDS-DMA in flight), which drained the next tile's
     // DMAs in the middle of this one.  Step db issues the two reads of step db + 2, then waits until only the younger
-    // reads are outstanding.  A V^T fragment feeds the QG query groups.
+    // reads are outstanding.
     const unsigned vbl = (unsigned)(uintptr_t)(MAVLM_LDS const char*)vb;
     {
       u32x2 vlo[DB], vhi[DB];
@@ -256,8 +226,7 @@ __global__ __launch_bounds__(512 / QG, 2 / QG) void attn_fwd_hd_kernel(const uin
         __builtin_amdgcn_sched_barrier(0);                    // keep the MFMA below the wait
         u32x4 both;
         both[0] = vlo[db][0]; both[1] = vlo[db][1]; both[2] = vhi[db][0]; both[3] = vhi[db][1];
-#pragma unroll
-        for (int qg = 0; qg < QG; ++qg) ot[qg][db] = T::mfma16(__builtin_bit_cast(typename T::vec8, both), pf[qg], ot[qg][db]);
+        ot[db] = T::mfma16(__builtin_bit_cast(typename T::vec8, both), pf, ot[db]);
         __builtin_amdgcn_sched_barrier(0);
       };
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // nothing older than the reads below is outstanding
@@ -274,10 +243,368 @@ __global__ __launch_bounds__(512 / QG, 2 / QG) void attn_fwd_hd_kernel(const uin
   }
 
   // ---- epilogue: O[q][h*HD + 16 db + 4g + 0..3] = O^T / l
+  const float l_tot = xgroup_sum(l_run);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + qi;
+  if (q < R) {
+    if (tps > 0) {
+      float* pp = Opart + ((size_t)split * R + q) * (H * HD) + h * HD + 4 * g;
 #pragma unroll
-  for (int qg = 0; qg < QG; ++qg) {
+      for (int db = 0; db < DB; ++db)
+        *(f32x4*)(pp + 16 * db) = f32x4{ot[db][0] * inv, ot[db][1] * inv, ot[db][2] * inv, ot[db][3] * inv};
+      if (g == 0) lse_part[((size_t)split * H + h) * R + q] = m_run * c + log2f(l_tot);
+    } else {
+      uint16_t* op = O + (size_t)q * ldo + h * HD + 4 * g;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+        *(u32x2*)(op + 16 * db) = pack4<T>(ot[db][0] * inv, ot[db][1] * inv, ot[db][2] * inv, ot[db][3] * inv);
+      if (lse2 != nullptr && g == 0) lse2[(size_t)h * R + q] = m_run * c + log2f(l_tot);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the head_dim-448 forward with 32-QUERY waves (two 16-query groups per wave), software-pipelined like
+// attn_fwd3_kernel.
+//
+// Why: in attn_fwd_hd_kernel every wave reads the whole 32-key K and V tiles from LDS for 16 queries: 16 flop per LDS byte,
+// which is the MFMA peak only at the full LDS rate - the kernel sat at 0.6-0.7 PFLOP/s with the LDS pipe as the bound.  Here a
+// wave keeps O^T of TWO query groups (2 x 112 accumulator registers) and the Q fragments of both (2 x 56), and feeds every K
+// row fragment / transposed V fragment it reads to two MFMAs: half the LDS bytes per flop.  That is one wave per SIMD
+// (4 waves x 32 queries per workgroup, 512-register budget), so nothing else hides a wave's latencies: the tile loop is
+// pipelined inside the wave exactly as attn_fwd3_kernel's -
+//   [A]  S'(t+1) = K(t+1).Q^T   ||  p = exp2(s c - m c) and the 16-bit converts of tile t, the LDS-DMA pieces of K(t+2), V(t+1)
+//   [B]  O^T += V(t)^T.P(t)^T   ||  row sums of tile t, row maxima of tile t+1
+// with hand-counted lgkmcnt waits around inline-asm fragment reads (the compiler drains its own read-ahead), buffer-load
+// LDS-DMA (one loop-invariant lane offset per piece, the tile in the scalar offset; rows past S read as zeros), and K / V in
+// separate 2-slot rings (K runs one tile ahead of V).  Same image layout, swizzle and rounding points as attn_fwd_hd_kernel;
+// each 16-query group keeps its own running maximum and takes its deferred rescales alone.
+template <typename T, int HD, int KPF, int VPF, int DMAV>
+__global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __restrict__ Q, int ldq,
+                                                              const uint16_t* __restrict__ K, int ldk,
+                                                              const uint16_t* __restrict__ V, int ldv,
+                                                              uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
+                                                              int R, int S, int H, float c, float* __restrict__ Opart,
+                                                              float* __restrict__ lse_part, int tps, long long kv_bs) {
+  {
+    const size_t vb = blockIdx.z;                           // row batch: see attn_fwd_hd_kernel
+    Q += vb * R * ldq;
+    O += vb * R * ldo;
+    K += vb * kv_bs;
+    V += vb * kv_bs;
+    if (lse2 != nullptr) lse2 += vb * H * R;
+  }
+  const int split = blockIdx.y;
+  if (tps > 0) {
+    const int k0 = split * tps * KTH;
+    K += (size_t)k0 * ldk;
+    V += (size_t)k0 * ldv;
+    S = (S - k0 < tps * KTH) ? S - k0 : tps * KTH;
+  }
+  constexpr int NSUB = (HD + 127) / 128;
+  constexpr int SUB = KTH * 256;
+  constexpr int TILE = NSUB * SUB;
+  constexpr int KS = HD / 32;
+  constexpr int DB = HD / 16;
+  constexpr int NCH = HD / 8;
+  constexpr int NPW = NSUB * 2;                             // 1 KiB DMA pieces per wave and tile (NSUB * 8 over 4 waves)
+  constexpr int NA = 2 * KS;                                // MFMA steps of phase [A] (k-step, key block), 2 MFMAs each
+  static_assert(2 * TILE <= 65536 && NPW * 2 <= NA && NA >= 24 && DB >= 16, "phase schedules assume a wide head");
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // K slots at 0, TILE ; V slots at 2 TILE, 3 TILE
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.x % H;
+  const int q0 = (blockIdx.x / H) * 128 + wave * 32;        // + 16 qg
+  const int qi = lane & 15, g = lane >> 4;
+  const int nt = (S + KTH - 1) / KTH;
+
+  typename T::vec8 qf[2][KS];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    int qrow = q0 + 16 * qg + qi;
+    qrow = qrow < R ? qrow : R - 1;
+    const uint16_t* qp = Q + (size_t)qrow * ldq + h * HD + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[qg][ks] = *(const typename T::vec8*)(qp + 32 * ks);
+  }
+
+  // ---- LDS-DMA: piece k (0..NPW-1) of wave w is instruction id = w + 4k of the tile: 1 KiB = rows 4 rg .. 4 rg + 3 of
+  // sub-image sub (id = 8 sub + rg), at LDS offset id * 1024 of the slot.
+  auto head_rsrc = [&](const uint16_t* base, int ld) {
+    const uintptr_t a = (uintptr_t)(base + h * HD);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const uint32_t bytes = __builtin_amdgcn_readfirstlane((uint32_t)(S - 1) * (uint32_t)ld * 2u + (uint32_t)HD * 2u);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, bytes, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t krs = head_rsrc(K, ldk), vrs = head_rsrc(V, ldv);
+  // The swizzle term of a row, x(row) = ((row & 3) << 2) | ((row >> 2) & 3) with row = 4 rg + (lane >> 4), rg = w + 4 (k & 1),
+  // is ((lane >> 4) << 2) | w for every piece: the lane's source chunk inside a sub-image does not depend on k.  ONE lane
+  // offset per operand; the piece adds the uniform (k & 1) 16 rows + (k >> 1) 256 bytes to the scalar offset.  The pad chunks
+  // of the last sub-image (columns HD .. 128 NSUB) then read whatever follows the head's columns - inside the descriptor it is
+  // neighbouring data, behind its end zeros - and nothing ever reads them from LDS.
+  const int drow = 4 * wave + (lane >> 4);
+  const int dch = (lane & 15) ^ (((lane >> 4) << 2) | wave);
+  const int koff = (drow * ldk + dch * 8) * 2, voff = (drow * ldv + dch * 8) * 2;
+  const unsigned lds_wave = (unsigned)(uintptr_t)(MAVLM_LDS char*)smem + wave * 1024;
+  auto dma_piece = [&](__amdgpu_buffer_rsrc_t rs, int off, int ld, int toff, int slot_off, int k) {
+    unsigned base = lds_wave;
+    asm volatile("" : "+s"(base));            // M0 = base + constant stays a one-instruction recompute (no hoisted SGPRs)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (MAVLM_LDS void*)(uintptr_t)(base + slot_off + k * 4096), 16, off,
+                                             toff + (k & 1) * 32 * ld + (k >> 1) * 256, 0, 0);
+  };
+  auto dma_tile = [&](__amdgpu_buffer_rsrc_t rs, int off, int ld, int t, int slot_off) {
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) dma_piece(rs, off, ld, t * KTH * ld * 2, slot_off, k);
+  };
+
+  // ---- fragment read geometry: loop-invariant 32-bit LDS addresses; slot / sub-image / key block are immediates
+  const int xq = imgh_x(qi);
+  const unsigned sbase = (unsigned)(uintptr_t)(MAVLM_LDS const char*)smem;
+  unsigned kad[4];                                            // k-step ks reads kad[ks & 3] + (ks >> 2) SUB + 4096 b + slot TILE
+#pragma unroll
+  for (int j = 0; j < 4; ++j) kad[j] = sbase + 256 * qi + 16 * ((4 * j + g) ^ xq);
+  const int tq = (lane & 15) >> 2, tp = lane & 3;
+  const int vrow = 4 * g + tq;
+  const int vx = imgh_x(vrow);
+  unsigned vad[8];                                            // block db reads vad[db & 7] + (db >> 3) SUB (+ 4096) + slot TILE
+#pragma unroll
+  for (int j = 0; j < 8; ++j) vad[j] = sbase + 2 * TILE + 256 * vrow + 8 * (tp & 1) + 16 * ((2 * j + (tp >> 1)) ^ vx);
+
+  f32x4 ot[2][DB];
+  f32x4 st[2][2][2];                                          // [parity][query group][key block]
+  float m_run[2], l_run[2];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+#pragma unroll
+    for (int d = 0; d < DB; ++d) ot[qg][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m_run[qg] = -1e30f;
+    l_run[qg] = 0.f;
+  }
+
+  auto mask_tail = [&](auto par, int t) {                     // key = 32 t + 16 b + 4 g + r
+    constexpr int P = decltype(par)::value;
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (t * KTH + 16 * b + 4 * g + r >= S) st[P][qg][b][r] = -INFINITY;
+  };
+  // deferred rescale of one query group against the (group-wide) row maxima `mx` of the next tile
+  auto rescale = [&](int qg, float mx) {
+    mx = xgroup_max(mx);
+    const float m_new = fmaxf(m_run[qg], mx);
+    if (__any((m_new - m_run[qg]) * c > RESCALE_H_LOG2)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run[qg] - m_new) * c);
+      m_run[qg] = m_new;
+      l_run[qg] *= alpha;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        // O^T lives in the accumulator file.  The pins keep each read - multiply - write of 4 registers together and inside
+        // this rare branch: left alone hipcc hoists all 224 v_accvgpr_read to the top of every tile, or runs the 112 reads
+        // of a group before the first write - either way the copies push Q fragments out to scratch.
+        f32x4 v = ot[qg][d];
+        asm volatile("" : "+a"(v));
+        v *= alpha;
+        asm volatile("" : "+a"(v));
+        ot[qg][d] = v;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  // ---- prologue: K(0), V(0), K(1) ; S(0) ; reference maxima of tile 0
+  dma_tile(krs, koff, ldk, 0, 0);
+  dma_tile(vrs, voff, ldv, 0, 2 * TILE);
+  if (nt > 1) dma_tile(krs, koff, ldk, 1, TILE);
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[qg][ks]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  {
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) st[0][qg][b] = st[1][qg][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const typename T::vec8 kf = *(const typename T::vec8*)(smem + (kad[ks & 3] - sbase) + (ks >> 2) * SUB + 4096 * b);
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg) st[0][qg][b] = T::mfma16(kf, qf[qg][ks], st[0][qg][b]);
+      }
+    if (nt == 1 && (S & (KTH - 1))) mask_tail(HIC<0>{}, 0);
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+      const f32x4 s0 = st[0][qg][0], s1 = st[0][qg][1];
+      rescale(qg, fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3]))));
+    }
+  }
+
+  // ---- one pipelined iteration: S(t) in st[P] (reference maxima decided), S'(t+1) into st[P^1]
+  auto iteration = [&](auto par, int t) {
+    constexpr int P = decltype(par)::value;
+    constexpr int N = P ^ 1;
+    const bool has_next = t + 1 < nt;
+    const int ktile = (t + 2) * KTH * ldk * 2, vtile = (t + 1) * KTH * ldv * 2;   // scalar byte offsets of K(t+2), V(t+1)
+    const float mc0 = m_run[0] * c, mc1 = m_run[1] * c;
+    typename T::vec8 pf[2];
+    float psum0 = 0.f, psum1 = 0.f;
+    auto expo = [&](int e) {                                  // element e = (qg = e>>3, b = (e>>2)&1, r = e&3) of tile t
+      float x = st[P][e >> 3][(e >> 2) & 1][e & 3];
+      asm volatile("" : "+v"(x));
+      x = __builtin_amdgcn_exp2f(x * c - ((e >> 3) ? mc1 : mc0));
+      if (e >> 3) psum1 += x; else psum0 += x;                // fp32 row sum, element order
+      asm volatile("" : "+v"(x));
+      st[P][e >> 3][(e >> 2) & 1][e & 3] = x;
+    };
+    auto cvt = [&](int qg) {
+      u32x4 pw;
+      pw[0] = pack2<T>(st[P][qg][0][0], st[P][qg][0][1]); pw[1] = pack2<T>(st[P][qg][0][2], st[P][qg][0][3]);
+      pw[2] = pack2<T>(st[P][qg][1][0], st[P][qg][1][1]); pw[3] = pack2<T>(st[P][qg][1][2], st[P][qg][1][3]);
+      asm volatile("" : "+v"(pw));                            // converted HERE (phase [A]); the fp32 values die with it
+      pf[qg] = __builtin_bit_cast(typename T::vec8, pw);
+    };
+    if (has_next) {
+      // [A] K(t+1) sits in K slot N.  Step i = (ks = i>>1, b = i&1): one K row fragment, two MFMAs (query groups).  The K
+      // reads are the only LGKM operations in flight here (one per step): step i issues the read of step i + KPF, then waits
+      // until only the younger ones are outstanding.
+#pragma unroll
+      for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) st[N][qg][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      static_assert(KPF >= 1 && KPF <= 6 && VPF >= 1 && VPF <= 4, "extend the wait tables");
+      u32x4 kfr[NA];
+      auto kread = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int off = N * TILE + ((i >> 1) >> 2) * SUB + 4096 * (i & 1);
+        const unsigned a = kad[(i >> 1) & 3];
+        u32x4 v;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "i"(off));
+        kfr[i] = v;
+      };
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      kread(HIC<0>{});
+      if constexpr (KPF > 1) kread(HIC<1>{});
+      if constexpr (KPF > 2) kread(HIC<2>{});
+      if constexpr (KPF > 3) kread(HIC<3>{});
+      if constexpr (KPF > 4) kread(HIC<4>{});
+      if constexpr (KPF > 5) kread(HIC<5>{});
+      __builtin_amdgcn_sched_barrier(0);
+      auto astep = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int ahead = (NA - 1 - i) < KPF ? (NA - 1 - i) : KPF;
+        if constexpr (i + KPF < NA) kread(HIC<(i + KPF < NA ? i + KPF : NA - 1)>{});
+        if constexpr (ahead == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if constexpr (ahead == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        else if constexpr (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else if constexpr (ahead == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        else if constexpr (ahead == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else if constexpr (ahead == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);                    // keep the MFMAs below the wait
+        const typename T::vec8 kf = __builtin_bit_cast(typename T::vec8, kfr[i]);
+        st[N][0][i & 1] = T::mfma16(kf, qf[0][i >> 1], st[N][0][i & 1]);
+        st[N][1][i & 1] = T::mfma16(kf, qf[1][i >> 1], st[N][1][i & 1]);
+        // K(t+2) -> K slot P, V(t+1) -> V slot N (both last read before the previous barrier): one piece per step
+        // (measured: K pieces here and V pieces in phase [B], one per 3 steps, -2 %; read-ahead 5 / 3 or 6 / 4 steps +-0;
+        //  with no DMA at all in the loop the same kernel runs 12 % faster - what staging costs one wave per SIMD)
+        if constexpr (DMAV == 0) {
+          if constexpr (i < 2 * NPW && (i & 1) == 0) dma_piece(krs, koff, ldk, ktile, P * TILE, i >> 1);
+          if constexpr (i < 2 * NPW && (i & 1) == 1) dma_piece(vrs, voff, ldv, vtile, (2 + N) * TILE, i >> 1);
+        }
+        if constexpr (i < 16) expo(i);                        // 16 probabilities of tile t, one per step
+        if constexpr (i == 18) cvt(0);
+        if constexpr (i == 20) cvt(1);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      hd_for_each(std::make_integer_sequence<int, NA>{}, astep);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) expo(e);
+      cvt(0);
+      cvt(1);
+    }
+
+    // [B] O^T += V(t)^T.P(t)^T : V(t) sits in V slot P.  Step db: two transposed reads, two MFMAs; the row maxima of tile t+1
+    // ride along (one score per step).
+    if (has_next && t + 1 == nt - 1 && (S & (KTH - 1))) mask_tail(HIC<N>{}, t + 1);
+    float mx0 = -INFINITY, mx1 = -INFINITY;
+    {
+      u32x2 vlo[DB], vhi[DB];
+      auto vrd = [&](auto ic) {
+        constexpr int db = decltype(ic)::value;
+        constexpr int off = P * TILE + (db >> 3) * SUB;
+        const unsigned a0 = vad[db & 7];
+        u32x2 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "i"(off));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a0), "i"(off + 4096));   // rows + 16
+        vlo[db] = lo; vhi[db] = hi;
+      };
+      auto vstep = [&](auto ic) {
+        constexpr int db = decltype(ic)::value;
+        if constexpr (db + VPF < DB) vrd(HIC<(db + VPF < DB ? db + VPF : DB - 1)>{});
+        constexpr int ahead = (DB - 1 - db) < VPF ? (DB - 1 - db) : VPF;
+        if constexpr (ahead == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if constexpr (ahead == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else if constexpr (ahead == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else if constexpr (ahead == 3) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 both;
+        both[0] = vlo[db][0]; both[1] = vlo[db][1]; both[2] = vhi[db][0]; both[3] = vhi[db][1];
+        const typename T::vec8 vf = __builtin_bit_cast(typename T::vec8, both);
+        ot[0][db] = T::mfma16(vf, pf[0], ot[0][db]);
+        ot[1][db] = T::mfma16(vf, pf[1], ot[1][db]);
+        if constexpr (db < 16) {                              // score e = db of tile t+1: (qg, b, r) as in expo
+          constexpr int e = db;
+          float sv = st[N][e >> 3][(e >> 2) & 1][e & 3];     // (stale values when there is no next tile: mx is not used then)
+          asm volatile("" : "+v"(sv));                        // fetched from the accumulator file here, one per step
+          if constexpr ((e >> 3) == 0) mx0 = fmaxf(mx0, sv); else mx1 = fmaxf(mx1, sv);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // nothing older than the reads below is outstanding
+      vrd(HIC<0>{});
+      if constexpr (VPF > 1) vrd(HIC<1>{});
+      if constexpr (VPF > 2) vrd(HIC<2>{});
+      if constexpr (VPF > 3) vrd(HIC<3>{});
+      __builtin_amdgcn_sched_barrier(0);
+      hd_for_each(std::make_integer_sequence<int, DB>{}, vstep);
+    }
+    l_run[0] += psum0;                                        // per-lane partials; the lane groups are summed at the end
+    l_run[1] += psum1;
+    if (has_next) {                                           // reference maxima for tile t+1 (after P.V(t): it touches O)
+      rescale(0, mx0);
+      rescale(1, mx1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of K(t+2), V(t+1) have landed
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    iteration(HIC<0>{}, t);
+    iteration(HIC<1>{}, t + 1);
+  }
+  if (t < nt) iteration(HIC<0>{}, t);
+
+  // ---- epilogue: O[q][h*HD + 16 db + 4g + 0..3] = O^T / l
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
     const float l_tot = xgroup_sum(l_run[qg]);
     const float inv = 1.0f / l_tot;
+    const float lse = __builtin_fmaf(m_run[qg], c, log2f(l_tot));
     const int q = q0 + 16 * qg + qi;
     if (q < R) {
       if (tps > 0) {
@@ -285,13 +612,13 @@ __global__ __launch_bounds__(512 / QG, 2 / QG) void attn_fwd_hd_kernel(const uin
 #pragma unroll
         for (int db = 0; db < DB; ++db)
           *(f32x4*)(pp + 16 * db) = f32x4{ot[qg][db][0] * inv, ot[qg][db][1] * inv, ot[qg][db][2] * inv, ot[qg][db][3] * inv};
-        if (g == 0) lse_part[((size_t)split * H + h) * R + q] = m_run[qg] * c + log2f(l_tot);
+        if (g == 0) lse_part[((size_t)split * H + h) * R + q] = lse;
       } else {
         uint16_t* op = O + (size_t)q * ldo + h * HD + 4 * g;
 #pragma unroll
         for (int db = 0; db < DB; ++db)
           *(u32x2*)(op + 16 * db) = pack4<T>(ot[qg][db][0] * inv, ot[qg][db][1] * inv, ot[qg][db][2] * inv, ot[qg][db][3] * inv);
-        if (lse2 != nullptr && g == 0) lse2[(size_t)h * R + q] = m_run[qg] * c + log2f(l_tot);
+        if (lse2 != nullptr && g == 0) lse2[(size_t)h * R + q] = lse;
       }
     }
   }
@@ -395,7 +722,10 @@ __global__ __launch_bounds__(256, 1) void attn_colsum_hd_kernel(const uint16_t* 
 template <typename T, int HD, int QG>
 hipError_t launch_fwd_hd(const mavlm_attn_args& a, hipStream_t s) {
   constexpr int LDS = 4 * ((HD + 127) / 128) * KTH * 256;
-  auto kern = attn_fwd_hd_kernel<T, HD, QG>;
+  void (*kern)(const uint16_t*, int, const uint16_t*, int, const uint16_t*, int, uint16_t*, int, float*, int, int, int, float, float*,
+               float*, int, long long);
+  if constexpr (QG == 2) kern = attn_fwd_hd2_kernel<T, HD, 3, 2, 0>;
+  else kern = attn_fwd_hd_kernel<T, HD>;
   static mavlm_per_device_once once;
   {
     hipError_t e = once.dyn_lds((const void*)kern, LDS);
@@ -411,7 +741,7 @@ hipError_t launch_fwd_hd(const mavlm_attn_args& a, hipStream_t s) {
   float* opart = a.split_ws;
   float* lpart = ns > 1 ? a.split_ws + (size_t)ns * a.R * a.H * HD : nullptr;
   mavlm_prof_scope prof(MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD, 2.0 * HD * a.H * (2.0 * a.R + 2.0 * a.S), s);
-  hipLaunchKernelGGL(kern, dim3(((a.R + 127) / 128) * Hv, ns, nb), dim3(512 / QG), LDS, s, (const uint16_t*)a.Q, a.ldq,
+  hipLaunchKernelGGL(kern, dim3(((a.R + 127) / 128) * Hv, ns, nb), dim3(QG >= 2 ? 256 : 512), LDS, s, (const uint16_t*)a.Q, a.ldq,
                      (const uint16_t*)a.K, a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, Hv, c,
                      opart, lpart, tps, (long long)a.kv_bstride);
   if (ns > 1) return mavlm_launch_attention_combine(opart, lpart, a.O, a.ldo, a.lse2, a.R, a.H, HD, ns, std::is_same<T, F16>::value ? MAVLM_F16 : MAVLM_BF16, s);
@@ -457,11 +787,10 @@ size_t mavlm_attention_hd_split_ws_floats(int R, int S, int H, int head_dim) {
   return ns > 1 ? (size_t)ns * R * H * head_dim + (size_t)ns * H * R : 0;
 }
 
-int g_mavlm_attn_hd_qg = 0;      // tuning hook: 0 = automatic (two query groups per wave at head_dim 448), 1 / 2 = forced
+int g_mavlm_attn_hd_qg = 0;      // tuning hook: 0 = automatic (32-query waves at head_dim 448), 1 = 16-query waves, 2 = 32-query
 hipError_t mavlm_launch_attention_hd(const mavlm_attn_args& a, int head_dim, int dtype, hipStream_t s) {
   const bool f16 = dtype == MAVLM_F16;
   if (head_dim == 448) {
-    // same arithmetic per query either way (a 16-query group decides its rescales alone): results are bit-identical
     if (g_mavlm_attn_hd_qg != 1) return f16 ? launch_fwd_hd<F16, 448, 2>(a, s) : launch_fwd_hd<BF16, 448, 2>(a, s);
     return f16 ? launch_fwd_hd<F16, 448, 1>(a, s) : launch_fwd_hd<BF16, 448, 1>(a, s);
   }

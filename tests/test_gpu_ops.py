@@ -426,11 +426,23 @@ def test_pool_bilinear_vs_oracle_and_reference_golden(mode):
 @pytest.mark.parametrize("hd,R,S,H", [(128, 200, 300, 2), (448, 16, 32, 1), (448, 200, 300, 2), (448, 129, 97, 1),
                                       (448, 392, 588, 8), (128, 1, 1, 1), (448, 1, 1, 1), (448, 196, 2048, 2),
                                       (128, 100, 1100, 1), (448, 1568, 6272, 8)])
-def test_attention_wide_heads_vs_oracle(mode, hd, R, S, H):
-    """attention_hd.hip: 16-query waves on 16x16x32 MFMA, head_dim 448 (LLaVA-OneVision-7B) and 128 (cross-check of
-    the same machinery); oracle emulation with that kernel's tiling (32-key tiles, 16-query waves).  The last three
+@pytest.mark.parametrize("groups", [2, 1])
+def test_attention_wide_heads_vs_oracle(mode, hd, R, S, H, groups):
+    """attention_hd.hip: head_dim 448 (LLaVA-OneVision-7B) with the pipelined 32-query waves (groups = 2, the default) and
+    with the 16-query waves of rounds 1-2 (groups = 1), and 128 (cross-check of the same machinery); oracle emulation with
+    that kernel's tiling (32-key tiles, 16-query groups: each group keeps its own maximum in both forms).  The last three
     shapes are small grids with many key tiles: the kernel splits the keys (partials + merge), the oracle mirrors the
     plan."""
+    if hd != 448 and groups == 1:
+        pytest.skip("one kernel form below 448")
+    capi.lib().mavlm_set_attention_wide_groups(groups)
+    try:
+        _wide_heads_vs_oracle(mode, hd, R, S, H)
+    finally:
+        capi.lib().mavlm_set_attention_wide_groups(0)
+
+
+def _wide_heads_vs_oracle(mode, hd, R, S, H):
     r = O.rounder(mode)
     W = H * hd
     q = r(O.hash_normal_like((R, W), 81))
@@ -446,9 +458,19 @@ def test_attention_wide_heads_vs_oracle(mode, hd, R, S, H):
     assert abs(float(part.sum()) - H * R) < 1e-3 * H * R
 
 
-def test_attention_wide_heads_identity_v_and_rescale():
+@pytest.mark.parametrize("groups", [2, 1])
+def test_attention_wide_heads_identity_v_and_rescale(groups):
     """One-hot V (ctx = probabilities: catches key/column permutation errors of the P.V operand mapping at 448) and a
-    late dominating key (forces the deferred-rescale branch)."""
+    late dominating key (forces the deferred-rescale branch - in the 32-query form the rescale of ONE of the wave's two
+    query groups, whose O^T sits in the accumulator file)."""
+    capi.lib().mavlm_set_attention_wide_groups(groups)
+    try:
+        _wide_identity_v(groups)
+    finally:
+        capi.lib().mavlm_set_attention_wide_groups(0)
+
+
+def _wide_identity_v(groups):
     R, S, H, hd = 48, 160, 1, 448
     r = O.bf16_round
     q = r(O.hash_normal_like((R, hd), 91) * 0.3)
