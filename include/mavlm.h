@@ -337,9 +337,10 @@ int mavlm_set_attention_streamk_waves(int32_t waves);
 /* workgroups of the column-sum pass's balanced schedule: 0 = automatic (512), or 64 .. 1024.  Changes the fp32 summation
  * order of the column sums (pieces per unit), nothing else. */
 int mavlm_set_attention_colsum_wgs(int32_t wgs);
-/* the head_dim-448 forward: 0 = automatic (2), 2 = 32-query waves (two 16-query groups share every K / V fragment read from
- * LDS; software-pipelined tile loop), 1 = the 16-query waves of rounds 1-2.  Same rounding points; the fp32 row sums are added
- * in a different order (results agree to fp32 rounding, not bit for bit). */
+/* the head_dim-448 forward: 0 = automatic (2), 2 = 32-query waves on 32x32x16 MFMAs, software-pipelined tile loop (half the
+ * LDS bytes per flop of the 16-query form), 1 = the 16-query waves of rounds 1-2.  Same rounding points; a 32-query wave takes
+ * its deferred rescales as one group and adds the fp32 row sums in a different order (results agree to the tolerance of the
+ * oracle tests, not bit for bit). */
 int mavlm_set_attention_wide_groups(int32_t groups);
 /* how mavlm_step obtains the frame scores of the last formation layer (head_dim <= 128, patches % 4 == 0, <= 64 frames per
  * chunk): 1 (default) = fused into that layer's attention forward - every query row carries the probability mass of the

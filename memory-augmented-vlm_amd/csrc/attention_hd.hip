@@ -264,22 +264,33 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd_kernel(const uint16_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Round 3: the head_dim-448 forward with 32-QUERY waves (two 16-query groups per wave), software-pipelined like
-// attn_fwd3_kernel.
+// Round 3: the head_dim-448 forward with 32-QUERY waves on v_mfma_f32_32x32x16, software-pipelined like attn_fwd3_kernel.
 //
-// Why: in attn_fwd_hd_kernel every wave reads the whole 32-key K and V tiles from LDS for 16 queries: 16 flop per LDS byte,
-// which is the MFMA peak only at the full LDS rate - the kernel sat at 0.6-0.7 PFLOP/s with the LDS pipe as the bound.  Here a
-// wave keeps O^T of TWO query groups (2 x 112 accumulator registers) and the Q fragments of both (2 x 56), and feeds every K
-// row fragment / transposed V fragment it reads to two MFMAs: half the LDS bytes per flop.  That is one wave per SIMD
-// (4 waves x 32 queries per workgroup, 512-register budget), so nothing else hides a wave's latencies: the tile loop is
-// pipelined inside the wave exactly as attn_fwd3_kernel's -
-//   [A]  S'(t+1) = K(t+1).Q^T   ||  p = exp2(s c - m c) and the 16-bit converts of tile t, the LDS-DMA pieces of K(t+2), V(t+1)
-//   [B]  O^T += V(t)^T.P(t)^T   ||  row sums of tile t, row maxima of tile t+1
-// with hand-counted lgkmcnt waits around inline-asm fragment reads (the compiler drains its own read-ahead), buffer-load
-// LDS-DMA (one loop-invariant lane offset per piece, the tile in the scalar offset; rows past S read as zeros), and K / V in
-// separate 2-slot rings (K runs one tile ahead of V).  Same image layout, swizzle and rounding points as attn_fwd_hd_kernel;
-// each 16-query group keeps its own running maximum and takes its deferred rescales alone.
-template <typename T, int HD, int KPF, int VPF, int DMAV>
+// Why.  In attn_fwd_hd_kernel every wave reads the whole 32-key K and V tiles from LDS for 16 queries: 16 flop per LDS byte,
+// the kernel sat at 0.6-0.7 PFLOP/s with the LDS pipe as the bound (and 2-way bank conflicts on the 16x16x32 K reads).  A
+// 32-query wave halves the LDS bytes per flop, but its state - O^T 32 x 448 fp32 = 224 accumulator registers, the Q fragments
+// 112 - leaves room for ONE wave per SIMD, and a lone wave issues one instruction per 4 clocks whatever its kind.  A first
+// form of this kernel (two 16-query groups per wave on 16x16x32: 112 MFMAs + ~460 other instructions per tile) ran 0.88
+// PFLOP/s at R = 12 544, S = 6 272 with the matrix pipe 47 % busy inside the loop (rocprofv3: SQ_ACTIVE_INST_ANY 49 %,
+// SQ_WAIT_INST_ANY 29 %, SQ_WAIT_ANY 21 % of the wave cycles; LDS 36 % busy, half of it bank conflicts): bound by instruction
+// issue, not by LDS or latency (read-ahead depth and DMA placement: no effect).  The 32x32x16 shape does the same flops in
+// HALF the MFMAs (56 per tile, 32 clocks each, 8 of them holding the issue port): six free issue slots per MFMA instead of
+// two, conflict-free K reads; with ~165 / ~145 other instructions in the two phases of a tile (K pieces in [A], V pieces in
+// [B]; sub-image offsets as instruction immediates; accumulator read + fma + exp as one asm statement; the ragged-tail mask a
+// real branch) it runs 0.96 PFLOP/s at that shape - a 784-workgroup grid that fills 3.06 rounds of 256 CUs - the matrix pipe
+// 55 % busy, the rest now mostly waits (SQ_WAIT_ANY 34 %: one exposed LDS round trip per phase, the barrier per tile).
+//
+// Mapping = attn_fwd3_kernel's, a 128-column sub-image standing where its head stood:
+//   S^T[key][query] = K.Q^T : 28 k-steps of 16 dims, one ds_read_b128 K row fragment per MFMA (lane = key row, half = lane>>5);
+//                     accumulator register i of lane (query r, half hh) is key (i & 3) + 8 (i >> 2) + 4 hh of the tile
+//   O^T[d][query] += V^T.P^T : 14 blocks of 32 columns x 2 k-steps of 16 keys; the S^T registers are the B operand as they are
+//                     (k-slot j of half hh = key 16 bs + {0-3, 8-11}[j] + 4 hh), the V^T fragment is two ds_read_b64_tr_b16
+//   [A]  S'(t+1) = K(t+1).Q^T   ||  p = exp2(s c - m c), 16-bit converts and row sums of tile t, LDS-DMA of K(t+2), V(t+1)
+//   [B]  O^T += V(t)^T.P(t)^T   ||  row maxima of tile t+1
+// with hand-counted lgkmcnt waits around inline-asm fragment reads, buffer-load LDS-DMA (one loop-invariant lane offset per
+// operand, tile and piece in the scalar offset; rows past S read as zeros) and K / V in separate 2-slot rings (K runs one
+// tile ahead of V).  Same image layout, swizzle and rounding points as attn_fwd_hd_kernel; 4 waves x 32 queries per workgroup.
+template <typename T, int HD, int KPF, int VPF>
 __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __restrict__ Q, int ldq,
                                                               const uint16_t* __restrict__ K, int ldk,
                                                               const uint16_t* __restrict__ V, int ldv,
@@ -304,29 +315,29 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
   constexpr int NSUB = (HD + 127) / 128;
   constexpr int SUB = KTH * 256;
   constexpr int TILE = NSUB * SUB;
-  constexpr int KS = HD / 32;
-  constexpr int DB = HD / 16;
-  constexpr int NCH = HD / 8;
+  constexpr int KS = HD / 16;                               // k-steps of S^T = K.Q^T (32x32x16)
+  constexpr int DB = HD / 32;                               // 32-column blocks of O^T
+  constexpr int NB = 2 * DB;                                // MFMA steps of phase [B]: (16-key step bs, block)
   constexpr int NPW = NSUB * 2;                             // 1 KiB DMA pieces per wave and tile (NSUB * 8 over 4 waves)
-  constexpr int NA = 2 * KS;                                // MFMA steps of phase [A] (k-step, key block), 2 MFMAs each
-  static_assert(2 * TILE <= 65536 && NPW * 2 <= NA && NA >= 24 && DB >= 16, "phase schedules assume a wide head");
+  static_assert(HD % 32 == 0 && 2 * TILE <= 65536 && 2 * NPW <= KS && KS >= 22 && NB >= 16, "phase schedules assume a wide head");
+  static_assert(KPF >= 1 && KPF <= 6 && VPF >= 1 && VPF <= 4, "extend the wait tables");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // K slots at 0, TILE ; V slots at 2 TILE, 3 TILE
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.x % H;
-  const int q0 = (blockIdx.x / H) * 128 + wave * 32;        // + 16 qg
-  const int qi = lane & 15, g = lane >> 4;
+  const int q0 = (blockIdx.x / H) * 128 + wave * 32;
+  const int r = lane & 31, hh = lane >> 5;
   const int nt = (S + KTH - 1) / KTH;
 
-  typename T::vec8 qf[2][KS];
-#pragma unroll
-  for (int qg = 0; qg < 2; ++qg) {
-    int qrow = q0 + 16 * qg + qi;
+  // ---- Q fragments (B operand): lane holds Q[q0 + r][h*HD + 16 ks + 8 hh + 0..7]
+  typename T::vec8 qf[KS];
+  {
+    int qrow = q0 + r;
     qrow = qrow < R ? qrow : R - 1;
-    const uint16_t* qp = Q + (size_t)qrow * ldq + h * HD + 8 * g;
+    const uint16_t* qp = Q + (size_t)qrow * ldq + h * HD + 8 * hh;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[qg][ks] = *(const typename T::vec8*)(qp + 32 * ks);
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const typename T::vec8*)(qp + 16 * ks);
   }
 
   // ---- LDS-DMA: piece k (0..NPW-1) of wave w is instruction id = w + 4k of the tile: 1 KiB = rows 4 rg .. 4 rg + 3 of
@@ -348,69 +359,69 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
   const int dch = (lane & 15) ^ (((lane >> 4) << 2) | wave);
   const int koff = (drow * ldk + dch * 8) * 2, voff = (drow * ldv + dch * 8) * 2;
   const unsigned lds_wave = (unsigned)(uintptr_t)(MAVLM_LDS char*)smem + wave * 1024;
-  auto dma_piece = [&](__amdgpu_buffer_rsrc_t rs, int off, int ld, int toff, int slot_off, int k) {
+  auto dma_piece = [&](__amdgpu_buffer_rsrc_t rs, int off, int ld, int toff, int slot_off, auto kc) {
+    constexpr int k = decltype(kc)::value;
     unsigned base = lds_wave;
     asm volatile("" : "+s"(base));            // M0 = base + constant stays a one-instruction recompute (no hoisted SGPRs)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (MAVLM_LDS void*)(uintptr_t)(base + slot_off + k * 4096), 16, off,
-                                             toff + (k & 1) * 32 * ld + (k >> 1) * 256, 0, 0);
+    // the sub-image's column offset rides in the instruction's immediate offset (no scalar add per piece); the hardware adds
+    // that immediate to the LDS address as well (LDS address = M0 + immediate + 16 lane), so it is taken out of M0 again
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (MAVLM_LDS void*)(uintptr_t)(base + slot_off + k * 4096 - (k >> 1) * 256), 16, off,
+                                             toff + (k & 1) * 32 * ld, (k >> 1) * 256, 0);
   };
   auto dma_tile = [&](__amdgpu_buffer_rsrc_t rs, int off, int ld, int t, int slot_off) {
-#pragma unroll
-    for (int k = 0; k < NPW; ++k) dma_piece(rs, off, ld, t * KTH * ld * 2, slot_off, k);
+    hd_for_each(std::make_integer_sequence<int, NPW>{}, [&](auto kc) { dma_piece(rs, off, ld, t * KTH * ld * 2, slot_off, kc); });
   };
 
-  // ---- fragment read geometry: loop-invariant 32-bit LDS addresses; slot / sub-image / key block are immediates
-  const int xq = imgh_x(qi);
+  // ---- fragment read geometry (attn_fwd3_kernel's, per 128-column sub-image): loop-invariant 32-bit LDS addresses; slot,
+  // sub-image and 16-key step are immediates
+  const int xr = imgh_x(r);
   const unsigned sbase = (unsigned)(uintptr_t)(MAVLM_LDS const char*)smem;
-  unsigned kad[4];                                            // k-step ks reads kad[ks & 3] + (ks >> 2) SUB + 4096 b + slot TILE
+  unsigned kad[8];                                            // k-step ks reads kad[ks & 7] + (ks >> 3) SUB + slot TILE
 #pragma unroll
-  for (int j = 0; j < 4; ++j) kad[j] = sbase + 256 * qi + 16 * ((4 * j + g) ^ xq);
-  const int tq = (lane & 15) >> 2, tp = lane & 3;
-  const int vrow = 4 * g + tq;
-  const int vx = imgh_x(vrow);
-  unsigned vad[8];                                            // block db reads vad[db & 7] + (db >> 3) SUB (+ 4096) + slot TILE
+  for (int j = 0; j < 8; ++j) kad[j] = sbase + 256 * r + 16 * ((2 * j + hh) ^ xr);
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+  const int v_rd = 256 * (4 * hh + tq) + 8 * (tp & 1) + 16 * ((tp >> 1) ^ hh);
+  unsigned vad[4][2];                                         // block dbi reads vad[dbi & 3][jj] + (dbi >> 2) SUB + 4096 bs + slot TILE
 #pragma unroll
-  for (int j = 0; j < 8; ++j) vad[j] = sbase + 2 * TILE + 256 * vrow + 8 * (tp & 1) + 16 * ((2 * j + (tp >> 1)) ^ vx);
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+      vad[db][jj] = sbase + 2 * TILE + v_rd + 256 * 8 * jj + 16 * (((db ^ tq) << 2) | ((tg1 ^ jj) << 1));
 
-  f32x4 ot[2][DB];
-  f32x4 st[2][2][2];                                          // [parity][query group][key block]
-  float m_run[2], l_run[2];
+  f32x16 ot[DB];
 #pragma unroll
-  for (int qg = 0; qg < 2; ++qg) {
+  for (int d = 0; d < DB; ++d)
 #pragma unroll
-    for (int d = 0; d < DB; ++d) ot[qg][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    m_run[qg] = -1e30f;
-    l_run[qg] = 0.f;
-  }
+    for (int i = 0; i < 16; ++i) ot[d][i] = 0.f;
+  f32x16 st[2];                                               // [parity]: S^T of one 32-key tile
+  float m_run = -1e30f, l_run = 0.f;
 
-  auto mask_tail = [&](auto par, int t) {                     // key = 32 t + 16 b + 4 g + r
+  auto mask_tail = [&](auto par, int t) {                     // key = 32 t + (i & 3) + 8 (i >> 2) + 4 hh
     constexpr int P = decltype(par)::value;
 #pragma unroll
-    for (int qg = 0; qg < 2; ++qg)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (t * KTH + 16 * b + 4 * g + r >= S) st[P][qg][b][r] = -INFINITY;
+    for (int i = 0; i < 16; ++i)
+      if (t * KTH + (i & 3) + 8 * (i >> 2) + 4 * hh >= S) st[P][i] = -INFINITY;
   };
-  // deferred rescale of one query group against the (group-wide) row maxima `mx` of the next tile
-  auto rescale = [&](int qg, float mx) {
-    mx = xgroup_max(mx);
-    const float m_new = fmaxf(m_run[qg], mx);
-    if (__any((m_new - m_run[qg]) * c > RESCALE_H_LOG2)) {
-      const float alpha = __builtin_amdgcn_exp2f((m_run[qg] - m_new) * c);
-      m_run[qg] = m_new;
-      l_run[qg] *= alpha;
+  // deferred rescale against the row maxima `mx` (this lane's half of the keys) of the next tile.  The decision needs no
+  // exchange between the two lane halves of a query row: the row maximum exceeds the threshold iff the maximum of one half
+  // does, and `__any` looks at all 64 lanes; the exchange sits in the (rare) rescale branch.
+  auto rescale = [&](float mx) {
+    if (__any((fmaxf(m_run, mx) - m_run) * c > RESCALE_H_LOG2)) {
+      mx = xhalf_max(mx);
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+      l_run *= alpha;
 #pragma unroll
       for (int d = 0; d < DB; ++d) {
-        // O^T lives in the accumulator file.  The pins keep each read - multiply - write of 4 registers together and inside
-        // this rare branch: left alone hipcc hoists all 224 v_accvgpr_read to the top of every tile, or runs the 112 reads
-        // of a group before the first write - either way the copies push Q fragments out to scratch.
-        f32x4 v = ot[qg][d];
+        // O^T lives in the accumulator file.  The pins keep each read - multiply - write of 16 registers together and inside
+        // this rare branch: left alone hipcc hoists all 224 v_accvgpr_read to the top of every tile, or runs every read
+        // before the first write - either way the copies push Q fragments out to scratch.
+        f32x16 v = ot[d];
         asm volatile("" : "+a"(v));
         v *= alpha;
         asm volatile("" : "+a"(v));
-        ot[qg][d] = v;
+        ot[d] = v;
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -421,72 +432,89 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
   dma_tile(vrs, voff, ldv, 0, 2 * TILE);
   if (nt > 1) dma_tile(krs, koff, ldk, 1, TILE);
 #pragma unroll
-  for (int qg = 0; qg < 2; ++qg)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[qg][ks]));
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   {
 #pragma unroll
-    for (int qg = 0; qg < 2; ++qg)
+    for (int i = 0; i < 16; ++i) st[0][i] = st[1][i] = 0.f;
 #pragma unroll
-      for (int b = 0; b < 2; ++b) st[0][qg][b] = st[1][qg][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const typename T::vec8 kf = *(const typename T::vec8*)(smem + (kad[ks & 3] - sbase) + (ks >> 2) * SUB + 4096 * b);
-#pragma unroll
-        for (int qg = 0; qg < 2; ++qg) st[0][qg][b] = T::mfma16(kf, qf[qg][ks], st[0][qg][b]);
-      }
-    if (nt == 1 && (S & (KTH - 1))) mask_tail(HIC<0>{}, 0);
-#pragma unroll
-    for (int qg = 0; qg < 2; ++qg) {
-      const f32x4 s0 = st[0][qg][0], s1 = st[0][qg][1];
-      rescale(qg, fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3]))));
+    for (int ks = 0; ks < KS; ++ks) {
+      const typename T::vec8 kf = *(const typename T::vec8*)(smem + (kad[ks & 7] - sbase) + (ks >> 3) * SUB);
+      st[0] = T::mfma32(kf, qf[ks], st[0]);
     }
+    if (nt == 1 && (S & (KTH - 1))) mask_tail(HIC<0>{}, 0);
+    float mx = st[0][0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[0][i]);
+    rescale(mx);
   }
 
-  // ---- one pipelined iteration: S(t) in st[P] (reference maxima decided), S'(t+1) into st[P^1]
+  // ---- one pipelined iteration: S(t) in st[P] (reference maximum decided), S'(t+1) into st[P^1]
   auto iteration = [&](auto par, int t) {
     constexpr int P = decltype(par)::value;
     constexpr int N = P ^ 1;
     const bool has_next = t + 1 < nt;
     const int ktile = (t + 2) * KTH * ldk * 2, vtile = (t + 1) * KTH * ldv * 2;   // scalar byte offsets of K(t+2), V(t+1)
-    const float mc0 = m_run[0] * c, mc1 = m_run[1] * c;
+    const float mc = m_run * c;
     typename T::vec8 pf[2];
-    float psum0 = 0.f, psum1 = 0.f;
-    auto expo = [&](int e) {                                  // element e = (qg = e>>3, b = (e>>2)&1, r = e&3) of tile t
-      float x = st[P][e >> 3][(e >> 2) & 1][e & 3];
-      asm volatile("" : "+v"(x));
-      x = __builtin_amdgcn_exp2f(x * c - ((e >> 3) ? mc1 : mc0));
-      if (e >> 3) psum1 += x; else psum0 += x;                // fp32 row sum, element order
-      asm volatile("" : "+v"(x));
-      st[P][e >> 3][(e >> 2) & 1][e & 3] = x;
+    float psum = 0.f;
+    // element e of tile t.  The score is pinned to ITS step, and v_exp_f32 is inline asm: a volatile statement keeps its place
+    // between the MFMAs without the register copy the "+v" pin around the builtin cost (a v_mov per probability).  Its readers -
+    // converts and row sums in cvt() - come >= 2 steps after the last exp (the transcendental-result hazard needs one
+    // independent instruction).
+    auto expo = [&](int e) {
+      // S^T sits in the accumulator file: fetched in ITS step (left to hipcc all 16 reads open the phase), scaled and
+      // exponentiated in ONE asm statement (hipcc puts an s_nop behind every inline-asm register read it cannot see into)
+      float y;
+      asm volatile("v_accvgpr_read_b32 %0, %1\n\tv_fma_f32 %0, %2, %0, -%3\n\tv_exp_f32 %0, %0"
+                   : "=&v"(y) : "a"(st[P][e]), "s"(c), "v"(mc));
+      st[P][e] = y;
     };
-    auto cvt = [&](int qg) {
+    auto cvt = [&](int bs) {                                  // P^T fragment of keys 16 bs .. 16 bs + 15 (this lane's 8), row sum
+      float ps = st[P][8 * bs];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) ps += st[P][8 * bs + j];    // fp32, element order
+      asm volatile("" : "+v"(ps));                            // (summed here, not at the top of phase [B])
+      psum += ps;
       u32x4 pw;
-      pw[0] = pack2<T>(st[P][qg][0][0], st[P][qg][0][1]); pw[1] = pack2<T>(st[P][qg][0][2], st[P][qg][0][3]);
-      pw[2] = pack2<T>(st[P][qg][1][0], st[P][qg][1][1]); pw[3] = pack2<T>(st[P][qg][1][2], st[P][qg][1][3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pw[j] = pack2<T>(st[P][8 * bs + 2 * j], st[P][8 * bs + 2 * j + 1]);
       asm volatile("" : "+v"(pw));                            // converted HERE (phase [A]); the fp32 values die with it
-      pf[qg] = __builtin_bit_cast(typename T::vec8, pw);
+      pf[bs] = __builtin_bit_cast(typename T::vec8, pw);
+    };
+    // transposed V(t) fragments (V slot P; landed before the previous barrier).  Step i of phase [B] = (bs = i / DB, block
+    // dbi = i % DB).  The first VPF steps' reads are issued at the END of phase [A], behind its last K read, so that phase [B]
+    // does not open with an exposed LDS round trip.
+    u32x2 vlo[NB], vhi[NB];
+    auto vrd = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int bs = i / DB, dbi = i % DB;
+      constexpr int off = P * TILE + (dbi >> 2) * SUB + 4096 * bs;
+      const unsigned a0 = vad[dbi & 3][0], a1 = vad[dbi & 3][1];
+      u32x2 lo, hi;
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "i"(off));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "i"(off));
+      vlo[i] = lo; vhi[i] = hi;
+    };
+    auto vopen = [&]() {
+      vrd(HIC<0>{});
+      if constexpr (VPF > 1) vrd(HIC<1>{});
+      if constexpr (VPF > 2) vrd(HIC<2>{});
+      if constexpr (VPF > 3) vrd(HIC<3>{});
     };
     if (has_next) {
-      // [A] K(t+1) sits in K slot N.  Step i = (ks = i>>1, b = i&1): one K row fragment, two MFMAs (query groups).  The K
-      // reads are the only LGKM operations in flight here (one per step): step i issues the read of step i + KPF, then waits
-      // until only the younger ones are outstanding.
+      // [A] K(t+1) sits in K slot N.  Step ks: one K row fragment, one MFMA.  The K reads are the only LGKM operations in
+      // flight here: step i issues the read of step i + KPF, then waits until only the younger ones are outstanding.
 #pragma unroll
-      for (int qg = 0; qg < 2; ++qg)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) st[N][qg][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-      static_assert(KPF >= 1 && KPF <= 6 && VPF >= 1 && VPF <= 4, "extend the wait tables");
-      u32x4 kfr[NA];
+      for (int i = 0; i < 16; ++i) st[N][i] = 0.f;
+      u32x4 kfr[KS];
       auto kread = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        constexpr int off = N * TILE + ((i >> 1) >> 2) * SUB + 4096 * (i & 1);
-        const unsigned a = kad[(i >> 1) & 3];
+        constexpr int off = N * TILE + (i >> 3) * SUB;
+        const unsigned a = kad[i & 7];
         u32x4 v;
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "i"(off));
         kfr[i] = v;
@@ -501,8 +529,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
       __builtin_amdgcn_sched_barrier(0);
       auto astep = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        constexpr int ahead = (NA - 1 - i) < KPF ? (NA - 1 - i) : KPF;
-        if constexpr (i + KPF < NA) kread(HIC<(i + KPF < NA ? i + KPF : NA - 1)>{});
+        constexpr int ahead = (KS - 1 - i) < KPF ? (KS - 1 - i) : KPF;
+        if constexpr (i + KPF < KS) kread(HIC<(i + KPF < KS ? i + KPF : KS - 1)>{});
         if constexpr (ahead == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         else if constexpr (ahead == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
         else if constexpr (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
@@ -510,49 +538,47 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
         else if constexpr (ahead == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
         else if constexpr (ahead == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);                    // keep the MFMAs below the wait
-        const typename T::vec8 kf = __builtin_bit_cast(typename T::vec8, kfr[i]);
-        st[N][0][i & 1] = T::mfma16(kf, qf[0][i >> 1], st[N][0][i & 1]);
-        st[N][1][i & 1] = T::mfma16(kf, qf[1][i >> 1], st[N][1][i & 1]);
-        // K(t+2) -> K slot P, V(t+1) -> V slot N (both last read before the previous barrier): one piece per step
-        // (measured: K pieces here and V pieces in phase [B], one per 3 steps, -2 %; read-ahead 5 / 3 or 6 / 4 steps +-0;
-        //  with no DMA at all in the loop the same kernel runs 12 % faster - what staging costs one wave per SIMD)
-        if constexpr (DMAV == 0) {
-          if constexpr (i < 2 * NPW && (i & 1) == 0) dma_piece(krs, koff, ldk, ktile, P * TILE, i >> 1);
-          if constexpr (i < 2 * NPW && (i & 1) == 1) dma_piece(vrs, voff, ldv, vtile, (2 + N) * TILE, i >> 1);
-        }
-        if constexpr (i < 16) expo(i);                        // 16 probabilities of tile t, one per step
+        __builtin_amdgcn_sched_barrier(0);                    // keep the MFMA below the wait
+        st[N] = T::mfma32(__builtin_bit_cast(typename T::vec8, kfr[i]), qf[i], st[N]);
+        // K(t+2) -> K slot P (last read before the previous barrier).  A lone wave issues one instruction per 4 clocks: this
+        // phase carries ~220 instructions beside its 28 MFMAs of 32 clocks, phase [B] ~120 - the V pieces go there.
+        if constexpr (i < 2 * NPW && (i & 1) == 0) dma_piece(krs, koff, ldk, ktile, P * TILE, HIC<((i >> 1) < NPW ? (i >> 1) : 0)>{});
+        if constexpr (i < 16) expo(i);                        // the 16 probabilities of tile t, one per step
         if constexpr (i == 18) cvt(0);
         if constexpr (i == 20) cvt(1);
+        if constexpr (i == KS - 1) vopen();                   // (every K read has returned: the wait of this step was lgkmcnt(0))
         __builtin_amdgcn_sched_barrier(0);
       };
-      hd_for_each(std::make_integer_sequence<int, NA>{}, astep);
+      hd_for_each(std::make_integer_sequence<int, KS>{}, astep);
     } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // nothing older than the reads below is outstanding
+      vopen();
 #pragma unroll
       for (int e = 0; e < 16; ++e) expo(e);
+      __builtin_amdgcn_sched_barrier(0);
       cvt(0);
       cvt(1);
     }
 
-    // [B] O^T += V(t)^T.P(t)^T : V(t) sits in V slot P.  Step db: two transposed reads, two MFMAs; the row maxima of tile t+1
+    // [B] O^T += V(t)^T.P(t)^T : V(t) sits in V slot P.  Step i: two transposed reads, one MFMA; the row maxima of tile t+1
     // ride along (one score per step).
-    if (has_next && t + 1 == nt - 1 && (S & (KTH - 1))) mask_tail(HIC<N>{}, t + 1);
-    float mx0 = -INFINITY, mx1 = -INFINITY;
+    if (has_next && t + 1 == nt - 1 && (S & (KTH - 1))) {
+      // (the pins are side effects the selects depend on: they keep this a scalar branch - if-converted, its 45 compare /
+      //  select instructions ran in every tile, a tenth of the issue slots of phase [B])
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float v = st[N][i];
+        asm volatile("" : "+v"(v));
+        st[N][i] = ((t + 1) * KTH + (i & 3) + 8 * (i >> 2) + 4 * hh >= S) ? -INFINITY : v;
+      }
+    }
+    float mx = -INFINITY;
     {
-      u32x2 vlo[DB], vhi[DB];
-      auto vrd = [&](auto ic) {
-        constexpr int db = decltype(ic)::value;
-        constexpr int off = P * TILE + (db >> 3) * SUB;
-        const unsigned a0 = vad[db & 7];
-        u32x2 lo, hi;
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "i"(off));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a0), "i"(off + 4096));   // rows + 16
-        vlo[db] = lo; vhi[db] = hi;
-      };
       auto vstep = [&](auto ic) {
-        constexpr int db = decltype(ic)::value;
-        if constexpr (db + VPF < DB) vrd(HIC<(db + VPF < DB ? db + VPF : DB - 1)>{});
-        constexpr int ahead = (DB - 1 - db) < VPF ? (DB - 1 - db) : VPF;
+        constexpr int i = decltype(ic)::value;
+        constexpr int bs = i / DB, dbi = i % DB;
+        if constexpr (i + VPF < NB) vrd(HIC<(i + VPF < NB ? i + VPF : NB - 1)>{});
+        constexpr int ahead = (NB - 1 - i) < VPF ? (NB - 1 - i) : VPF;
         if constexpr (ahead == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         else if constexpr (ahead == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
         else if constexpr (ahead == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
@@ -560,32 +586,25 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
         else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         u32x4 both;
-        both[0] = vlo[db][0]; both[1] = vlo[db][1]; both[2] = vhi[db][0]; both[3] = vhi[db][1];
-        const typename T::vec8 vf = __builtin_bit_cast(typename T::vec8, both);
-        ot[0][db] = T::mfma16(vf, pf[0], ot[0][db]);
-        ot[1][db] = T::mfma16(vf, pf[1], ot[1][db]);
-        if constexpr (db < 16) {                              // score e = db of tile t+1: (qg, b, r) as in expo
-          constexpr int e = db;
-          float sv = st[N][e >> 3][(e >> 2) & 1][e & 3];     // (stale values when there is no next tile: mx is not used then)
-          asm volatile("" : "+v"(sv));                        // fetched from the accumulator file here, one per step
-          if constexpr ((e >> 3) == 0) mx0 = fmaxf(mx0, sv); else mx1 = fmaxf(mx1, sv);
+        both[0] = vlo[i][0]; both[1] = vlo[i][1]; both[2] = vhi[i][0]; both[3] = vhi[i][1];
+        ot[dbi] = T::mfma32(__builtin_bit_cast(typename T::vec8, both), pf[bs], ot[dbi]);
+        // V(t+1) -> V slot N (last read before the previous barrier): in the FIRST steps, so that the vmcnt(0) that closes the
+        // tile finds them landed (one piece per 3 steps, the last of them 7 steps before the wait: -3.5 %)
+        if constexpr (i < NPW) dma_piece(vrs, voff, ldv, vtile, (2 + N) * TILE, HIC<(i < NPW ? i : 0)>{});
+        if constexpr (i >= 2 && i < 18) {                     // score i - 2 of tile t+1 (stale values when there is none: mx unused)
+          // fetched from the accumulator file here, one per step.  (Inline asm hides the MFMA -> v_accvgpr_read hazard from
+          // hipcc: two MFMAs of this phase have issued since the last one that wrote S^T - the matrix pipe is in order.)
+          float sv;
+          asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(sv) : "a"(st[N][i - 2]));
+          mx = fmaxf(mx, sv);
         }
         __builtin_amdgcn_sched_barrier(0);
       };
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // nothing older than the reads below is outstanding
-      vrd(HIC<0>{});
-      if constexpr (VPF > 1) vrd(HIC<1>{});
-      if constexpr (VPF > 2) vrd(HIC<2>{});
-      if constexpr (VPF > 3) vrd(HIC<3>{});
       __builtin_amdgcn_sched_barrier(0);
-      hd_for_each(std::make_integer_sequence<int, DB>{}, vstep);
+      hd_for_each(std::make_integer_sequence<int, NB>{}, vstep);
     }
-    l_run[0] += psum0;                                        // per-lane partials; the lane groups are summed at the end
-    l_run[1] += psum1;
-    if (has_next) {                                           // reference maxima for tile t+1 (after P.V(t): it touches O)
-      rescale(0, mx0);
-      rescale(1, mx1);
-    }
+    l_run += psum;                                            // per-lane partial (this half's keys); halves are summed at the end
+    if (has_next) rescale(mx);                                // reference maximum for tile t+1 (after P.V(t): it touches O)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of K(t+2), V(t+1) have landed
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -599,27 +618,30 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
   }
   if (t < nt) iteration(HIC<0>{}, t);
 
-  // ---- epilogue: O[q][h*HD + 16 db + 4g + 0..3] = O^T / l
+  // ---- epilogue: O[q][h*HD + 32 dbi + 8 g + 4 hh + 0..3] = O^T / l
+  const float l_tot = xhalf_sum(l_run);
+  const float inv = 1.0f / l_tot;
+  const float lse = __builtin_fmaf(m_run, c, log2f(l_tot));
+  const int q = q0 + r;
+  if (q < R) {
+    if (tps > 0) {
+      float* pp = Opart + ((size_t)split * R + q) * (H * HD) + h * HD + 4 * hh;
 #pragma unroll
-  for (int qg = 0; qg < 2; ++qg) {
-    const float l_tot = xgroup_sum(l_run[qg]);
-    const float inv = 1.0f / l_tot;
-    const float lse = __builtin_fmaf(m_run[qg], c, log2f(l_tot));
-    const int q = q0 + 16 * qg + qi;
-    if (q < R) {
-      if (tps > 0) {
-        float* pp = Opart + ((size_t)split * R + q) * (H * HD) + h * HD + 4 * g;
+      for (int d = 0; d < DB; ++d)
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
-          *(f32x4*)(pp + 16 * db) = f32x4{ot[qg][db][0] * inv, ot[qg][db][1] * inv, ot[qg][db][2] * inv, ot[qg][db][3] * inv};
-        if (g == 0) lse_part[((size_t)split * H + h) * R + q] = lse;
-      } else {
-        uint16_t* op = O + (size_t)q * ldo + h * HD + 4 * g;
+        for (int g = 0; g < 4; ++g)
+          *(f32x4*)(pp + 32 * d + 8 * g) = f32x4{ot[d][4 * g] * inv, ot[d][4 * g + 1] * inv, ot[d][4 * g + 2] * inv,
+                                                 ot[d][4 * g + 3] * inv};
+      if (hh == 0) lse_part[((size_t)split * H + h) * R + q] = lse;
+    } else {
+      uint16_t* op = O + (size_t)q * ldo + h * HD + 4 * hh;
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
-          *(u32x2*)(op + 16 * db) = pack4<T>(ot[qg][db][0] * inv, ot[qg][db][1] * inv, ot[qg][db][2] * inv, ot[qg][db][3] * inv);
-        if (lse2 != nullptr && g == 0) lse2[(size_t)h * R + q] = lse;
-      }
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(u32x2*)(op + 32 * d + 8 * g) = pack4<T>(ot[d][4 * g] * inv, ot[d][4 * g + 1] * inv, ot[d][4 * g + 2] * inv,
+                                                    ot[d][4 * g + 3] * inv);
+      if (lse2 != nullptr && hh == 0) lse2[(size_t)h * R + q] = lse;
     }
   }
 }
@@ -724,7 +746,7 @@ hipError_t launch_fwd_hd(const mavlm_attn_args& a, hipStream_t s) {
   constexpr int LDS = 4 * ((HD + 127) / 128) * KTH * 256;
   void (*kern)(const uint16_t*, int, const uint16_t*, int, const uint16_t*, int, uint16_t*, int, float*, int, int, int, float, float*,
                float*, int, long long);
-  if constexpr (QG == 2) kern = attn_fwd_hd2_kernel<T, HD, 3, 2, 0>;
+  if constexpr (QG == 2) kern = attn_fwd_hd2_kernel<T, HD, 3, 3>;
   else kern = attn_fwd_hd_kernel<T, HD>;
   static mavlm_per_device_once once;
   {

@@ -334,8 +334,11 @@ WAVE_ROWS = 32        # queries per wave: the rescale decision is wave-uniform (
 
 def kernel_tiling(head_dim: int) -> Tuple[int, int]:
     """(keys per tile, queries per wave) of the HIP attention kernel that serves this head_dim:
-    attention3.hip (<= 128, zero-padded to 128): 64 / 32;  attention_hd.hip (448): 32 / 16."""
-    return (KV_TILE, WAVE_ROWS) if head_dim <= 128 else (32, 16)
+    attention3.hip (<= 128, zero-padded to 128): 64 / 32;  attention_hd.hip: 32 / 32 at 448 (attn_fwd_hd2_kernel, round 3),
+    32 / 16 at the other wide widths (224, 256: attn_fwd_hd_kernel)."""
+    if head_dim <= 128:
+        return (KV_TILE, WAVE_ROWS)
+    return (32, 32) if head_dim == 448 else (32, 16)
 
 
 def split_plan(R: int, S: int, heads: int) -> Tuple[int, int]:

@@ -14,7 +14,9 @@ dev = torch.device("cuda", 0)
 lib = capi.lib()
 Hh, hd = 8, 448
 MODES = [int(v) for v in os.environ.get("MODES", "1,2").split(",")]
-for (Rr, Ss) in ((64, 6272), (1568, 6272), (1568, 18816), (12544, 6272), (12544, 18816), (1000, 777), (100, 31), (129, 33)):
+SHAPES = [tuple(int(v) for v in t.split("x")) for t in os.environ.get(
+    "SHAPES", "64x6272,1568x6272,1568x18816,12544x6272,12544x18816,1000x777,100x31,129x33").split(",")]
+for (Rr, Ss) in SHAPES:
     g = torch.Generator(device="cpu").manual_seed(Rr + Ss)
     q = torch.randn(Rr, Hh * hd, generator=g).to(dev).bfloat16()
     kv = torch.randn(Ss, 2 * Hh * hd, generator=g).to(dev).bfloat16()

@@ -430,25 +430,25 @@ def test_pool_bilinear_vs_oracle_and_reference_golden(mode):
 def test_attention_wide_heads_vs_oracle(mode, hd, R, S, H, groups):
     """attention_hd.hip: head_dim 448 (LLaVA-OneVision-7B) with the pipelined 32-query waves (groups = 2, the default) and
     with the 16-query waves of rounds 1-2 (groups = 1), and 128 (cross-check of the same machinery); oracle emulation with
-    that kernel's tiling (32-key tiles, 16-query groups: each group keeps its own maximum in both forms).  The last three
+    32-key tiles and the deferred-rescale decision per 16 / 32 query rows.  The last three
     shapes are small grids with many key tiles: the kernel splits the keys (partials + merge), the oracle mirrors the
     plan."""
     if hd != 448 and groups == 1:
         pytest.skip("one kernel form below 448")
     capi.lib().mavlm_set_attention_wide_groups(groups)
     try:
-        _wide_heads_vs_oracle(mode, hd, R, S, H)
+        _wide_heads_vs_oracle(mode, hd, R, S, H, 32 if (groups == 2 and hd == 448) else 16)
     finally:
         capi.lib().mavlm_set_attention_wide_groups(0)
 
 
-def _wide_heads_vs_oracle(mode, hd, R, S, H):
+def _wide_heads_vs_oracle(mode, hd, R, S, H, wave_rows):
     r = O.rounder(mode)
     W = H * hd
     q = r(O.hash_normal_like((R, W), 81))
     k = r(O.hash_normal_like((S, W), 82))
     v = r(O.hash_normal_like((S, W), 83))
-    ctx, lse2, col, _ = O.attention_heads(q, k, v, H, mode, want_colsum=True, kv_tile=32, wave_rows=16)
+    ctx, lse2, col, _ = O.attention_heads(q, k, v, H, mode, want_colsum=True, kv_tile=32, wave_rows=wave_rows)
     got, lse = ops.attention(to_dev(q, mode), to_dev(k, mode), to_dev(v, mode), H, want_lse=True, head_dim=hd,
                              wide_kernel=True)
     assert O.rel_l2(to_np(got), r(ctx)) < TOL
@@ -461,8 +461,8 @@ def _wide_heads_vs_oracle(mode, hd, R, S, H):
 @pytest.mark.parametrize("groups", [2, 1])
 def test_attention_wide_heads_identity_v_and_rescale(groups):
     """One-hot V (ctx = probabilities: catches key/column permutation errors of the P.V operand mapping at 448) and a
-    late dominating key (forces the deferred-rescale branch - in the 32-query form the rescale of ONE of the wave's two
-    query groups, whose O^T sits in the accumulator file)."""
+    late dominating key (forces the deferred-rescale branch - in the 32-query form on an O^T that sits in the accumulator
+    file)."""
     capi.lib().mavlm_set_attention_wide_groups(groups)
     try:
         _wide_identity_v(groups)
@@ -478,7 +478,7 @@ def _wide_identity_v(groups):
     v = np.zeros((S, hd), np.float32)
     v[np.arange(S), (np.arange(S) * 11 + 5) % hd] = 1.0
     k[32 * 4 + 17] = r(q[5] * 6.0)
-    ctx, lse2, _, _ = O.attention_heads(q, k, v, H, "bf16", kv_tile=32, wave_rows=16)
+    ctx, lse2, _, _ = O.attention_heads(q, k, v, H, "bf16", kv_tile=32, wave_rows=32 if groups == 2 else 16)
     got, lse = ops.attention(to_dev(q), to_dev(k), to_dev(v), H, want_lse=True, head_dim=hd)
     assert O.rel_l2(to_np(got), r(ctx)) < TOL
     np.testing.assert_allclose(to_np(lse), lse2, rtol=0, atol=5e-3)
