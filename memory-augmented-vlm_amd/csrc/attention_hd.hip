@@ -606,6 +606,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
     }
     l_run += psum;                                            // per-lane partial (this half's keys); halves are summed at the end
     if (has_next) rescale(mx);                                // reference maximum for tile t+1 (after P.V(t): it touches O)
+    // (tried: the barrier VPF steps before the end of phase [B] - legal once every V(t) fragment is in registers - with the first
+    //  K fragments of the next tile read behind it, under the last MFMAs and the rescale check: 940 -> 906 TFLOP/s, reverted)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of K(t+2), V(t+1) have landed
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
