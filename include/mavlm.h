@@ -229,6 +229,11 @@ int mavlm_attention_hd(const void* Q, int32_t ldq, const void* K, int32_t ldk, c
  * 8 memory tokens at the OneVision-7B width); ws = mavlm_attention_hd_ws_floats(...) floats (0 = no split).  Same
  * scheme and merge kernel as mavlm_attention_ws; mavlm_step uses the same plan. */
 int64_t mavlm_attention_hd_ws_floats(int32_t R, int32_t S, int32_t H, int32_t head_dim);
+/* schedule of the wide-head forward for this shape (H = heads of ALL videos of a row batch): info[0] = workgroups of the
+ * levelled stream-K plan of the 32-query-wave kernel (head_dim 448; 0 = plain grid), info[1] = whole units per workgroup,
+ * info[2] = cut levels, info[3] = key splits of the small-grid form (1 = none).  Part of the rounding plan (the oracle mirrors
+ * it: oracle/memory_path.py streamk_plan_wide / split_plan_wide). */
+int mavlm_attention_hd_plan_info(int32_t R, int32_t S, int32_t H, int32_t head_dim, int32_t* info);
 int mavlm_attention_hd_ws(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                           int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, int32_t head_dim, float scale, float* ws,
                           int64_t ws_floats, int32_t dtype, void* stream);

@@ -76,6 +76,7 @@ SIGNATURES = {
     "mavlm_attention_ws_floats": (C.c_int64, [i32, i32, i32]),
     "mavlm_attention_ws": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.c_float, vp, C.c_int64, i32, vp]),
     "mavlm_attention_hd_ws_floats": (C.c_int64, [i32, i32, i32, i32]),
+    "mavlm_attention_hd_plan_info": (C.c_int, [i32, i32, i32, i32, vp]),
     "mavlm_attention_hd_ws": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, C.c_float, vp, C.c_int64,
                                         i32, vp]),
     "mavlm_attention_colsum_hd": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, C.c_float, i32, vp]),

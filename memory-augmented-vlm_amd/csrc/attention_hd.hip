@@ -263,6 +263,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd_kernel(const uint16_t* __r
   }
 }
 
+// Levelled stream-K plan of attn_fwd_hd2_kernel - the schedule of attn_fwd3_kernel (attention3.hip: after `full` whole units
+// per workgroup, the remaining units are cut into 2^k equal key ranges level by level) over 128-query units, 32-key tiles and
+// G = 256 workgroups (one per CU).
+struct hd_sk_plan {
+  int wgs;           // G (0 = schedule not used)
+  int full;          // whole units per workgroup
+  int nlev;
+  int k[6];          // level: units are cut into 2^k key ranges
+  int base[6];       // first unit of the level
+  int nun[6];        // units of the level (<= G >> k)
+  int slot[6];       // first partial slot of the level (+ virtual workgroup id)
+};
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Round 3: the head_dim-448 forward with 32-QUERY waves on v_mfma_f32_32x32x16, software-pipelined like attn_fwd3_kernel.
 //
@@ -292,27 +305,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_hd_kernel(const uint16_t* __r
 // operand, tile and piece in the scalar offset; rows past S read as zeros) and K / V in separate 2-slot rings (K runs one
 // tile ahead of V).  Same image layout, swizzle and rounding points as attn_fwd_hd_kernel; 4 waves x 32 queries per workgroup.
 template <typename T, int HD, int KPF, int VPF>
-__global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __restrict__ Q, int ldq,
-                                                              const uint16_t* __restrict__ K, int ldk,
-                                                              const uint16_t* __restrict__ V, int ldv,
-                                                              uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
-                                                              int R, int S, int H, float c, float* __restrict__ Opart,
-                                                              float* __restrict__ lse_part, int tps, long long kv_bs) {
-  {
-    const size_t vb = blockIdx.z;                           // row batch: see attn_fwd_hd_kernel
-    Q += vb * R * ldq;
-    O += vb * R * ldo;
-    K += vb * kv_bs;
-    V += vb * kv_bs;
-    if (lse2 != nullptr) lse2 += vb * H * R;
-  }
-  const int split = blockIdx.y;
-  if (tps > 0) {
-    const int k0 = split * tps * KTH;
-    K += (size_t)k0 * ldk;
-    V += (size_t)k0 * ldv;
-    S = (S - k0 < tps * KTH) ? S - k0 : tps * KTH;
-  }
+__global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __restrict__ Qa, int ldq,
+                                                              const uint16_t* __restrict__ Ka, int ldk,
+                                                              const uint16_t* __restrict__ Va, int ldv,
+                                                              uint16_t* __restrict__ Oa, int ldo, float* __restrict__ lse2a,
+                                                              int R, int S_all, int H, float c, float* __restrict__ Opart,
+                                                              float* __restrict__ lse_part, int tps, long long kv_bs,
+                                                              hd_sk_plan plan) {
   constexpr int NSUB = (HD + 127) / 128;
   constexpr int SUB = KTH * 256;
   constexpr int TILE = NSUB * SUB;
@@ -326,10 +325,70 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = blockIdx.x % H;
-  const int q0 = (blockIdx.x / H) * 128 + wave * 32;
   const int r = lane & 31, hh = lane >> 5;
-  const int nt = (S + KTH - 1) / KTH;
+  const int nt_all = (S_all + KTH - 1) / KTH;
+  const int nqb = (R + 127) / 128;
+
+  // ---- schedule (H = heads per video; "global head" hg = video * H + head).  A workgroup runs one or more SEGMENTS: a unit
+  // (global head, 128-query block) x a contiguous range of its key tiles, with a fresh online-softmax state.
+  //   * plain (plan.wgs == 0, tps == 0): blockIdx = (unit of the video, -, video), one whole-unit segment.
+  //   * split-KV (tps > 0; small single-video grids): blockIdx.y owns the key tiles [y tps, (y+1) tps); normalised fp32 partial
+  //     + log-sum-exp per split, merged by attn_combine_kernel (attention3.hip).
+  //   * levelled stream-K (plan.wgs = G > 0; more units than CUs): G persistent workgroups take plan.full whole units each, then
+  //     the levels - unit ul of level (k, base) is cut into 2^k key ranges, piece p going to virtual workgroup (ul << k) + p; XCD
+  //     x owns the virtual ids [x G/8, (x+1) G/8): contiguous units of the head-major order, and the 2^k workgroups that share
+  //     a unit sit on one XCD.  Pieces write partials into slot plan.slot[level] + virtual id; attn_combine_hd_sk_kernel merges.
+  const int sk_v = plan.wgs > 0 ? xcd_remap((int)blockIdx.x, plan.wgs) : 0;
+  const int nseg = plan.wgs > 0 ? plan.full + plan.nlev : 1;
+  for (int si = 0; si < nseg; ++si) {
+  int hg, qblk, t_lo, nt, out_kind, split = 0, sk_slot = 0;   // out_kind 0: O / lse2, 1: split-KV partial, 2: stream-K partial
+  if (plan.wgs > 0) {
+    int u;
+    if (si < plan.full) {
+      u = si * plan.wgs + sk_v;
+      t_lo = 0;
+      nt = nt_all;
+      out_kind = 0;
+    } else {
+      const int lv = si - plan.full;
+      int lk = plan.k[0], lbase = plan.base[0], lnun = plan.nun[0], lslot = plan.slot[0];
+#pragma unroll
+      for (int j = 1; j < 6; ++j)                              // (static indices: the plan lives in scalar registers)
+        if (lv == j) { lk = plan.k[j]; lbase = plan.base[j]; lnun = plan.nun[j]; lslot = plan.slot[j]; }
+      const int ul = sk_v >> lk;
+      if (ul >= lnun) continue;                                // this workgroup has no unit on this (partial) level
+      const int piece = sk_v & ((1 << lk) - 1);
+      u = lbase + ul;
+      t_lo = (int)(((long long)piece * nt_all) >> lk);
+      nt = (int)(((long long)(piece + 1) * nt_all) >> lk) - t_lo;
+      out_kind = 2;
+      sk_slot = lslot + sk_v;
+      if (nt == 0) {                                           // fewer key tiles than pieces: a neutral partial (weight 0)
+        float* pp = Opart + ((size_t)sk_slot * 128 + wave * 32 + r) * HD + (HD / 2) * hh;
+#pragma unroll
+        for (int g = 0; g < HD / 8; ++g) *(f32x4*)(pp + 4 * g) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (hh == 0) lse_part[(size_t)sk_slot * 128 + wave * 32 + r] = -INFINITY;
+        continue;
+      }
+    }
+    hg = u / nqb;
+    qblk = u - hg * nqb;
+  } else {
+    hg = (int)blockIdx.z * H + (int)(blockIdx.x % H);
+    qblk = blockIdx.x / H;
+    split = blockIdx.y;
+    t_lo = tps > 0 ? split * tps : 0;
+    nt = tps > 0 ? ((nt_all - t_lo < tps) ? nt_all - t_lo : tps) : nt_all;
+    out_kind = tps > 0 ? 1 : 0;
+  }
+  const int vb = hg / H, h = hg - vb * H;                      // video of the row batch, head inside it
+  const uint16_t* const Q = Qa + (size_t)vb * R * ldq;
+  uint16_t* const O = Oa + (size_t)vb * R * ldo;
+  const uint16_t* const K = Ka + (size_t)vb * kv_bs + (size_t)t_lo * KTH * ldk;
+  const uint16_t* const V = Va + (size_t)vb * kv_bs + (size_t)t_lo * KTH * ldv;
+  float* const lse2 = lse2a != nullptr ? lse2a + (size_t)vb * H * R : nullptr;
+  const int S = (S_all - t_lo * KTH < nt * KTH) ? S_all - t_lo * KTH : nt * KTH;      // keys of this segment
+  const int q0 = qblk * 128 + wave * 32;
 
   // ---- Q fragments (B operand): lane holds Q[q0 + r][h*HD + 16 ks + 8 hh + 0..7]
   typename T::vec8 qf[KS];
@@ -626,8 +685,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
   const float inv = 1.0f / l_tot;
   const float lse = __builtin_fmaf(m_run, c, log2f(l_tot));
   const int q = q0 + r;
-  if (q < R) {
-    if (tps > 0) {
+  if (out_kind == 2) {                                        // stream-K partial: [slot][128 rows][HD] + [slot][128]
+    float* pp = Opart + ((size_t)sk_slot * 128 + wave * 32 + r) * HD + 4 * hh;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(f32x4*)(pp + 32 * d + 8 * g) = f32x4{ot[d][4 * g] * inv, ot[d][4 * g + 1] * inv, ot[d][4 * g + 2] * inv,
+                                               ot[d][4 * g + 3] * inv};
+    if (hh == 0) lse_part[(size_t)sk_slot * 128 + wave * 32 + r] = lse;
+  } else if (q < R) {
+    if (out_kind == 1) {
       float* pp = Opart + ((size_t)split * R + q) * (H * HD) + h * HD + 4 * hh;
 #pragma unroll
       for (int d = 0; d < DB; ++d)
@@ -646,6 +714,79 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
                                                     ot[d][4 * g + 3] * inv);
       if (lse2 != nullptr && hh == 0) lse2[(size_t)h * R + q] = lse;
     }
+  }
+  }  // segments
+}
+
+// Stream-K merge for attn_fwd_hd2_kernel: unit `ul` of level j (cut into NP = 2^k key ranges) has its partials in the slots
+// plan.slot[j] + (ul << k) + p, p = 0 .. NP - 1 in key order: O = sum_p w_p O_p, w_p = 2^(lse_p - lse), lse = log2 sum_p 2^lse_p
+// (an empty range carries lse = -inf: weight 0).  One workgroup per 16 rows of a cut unit: a partial row is HD / 4 lanes x
+// 16 bytes, two rows per pass of 256 threads.  NP is a compile-time constant per level so that the loads of a row are issued back
+// to back (attention3.hip: as run-time loops the merge was latency-bound).
+template <typename T, int HD, int NP>
+__device__ __forceinline__ void combine_hd_sk_rows(const float* __restrict__ Opart, const float* __restrict__ lse_part, size_t s0,
+                                                   uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2, int R, int H,
+                                                   int hg, int qblk, int part) {
+  const int c4 = threadIdx.x & 127, rsub = threadIdx.x >> 7;
+  const int vb = hg / H, h = hg - vb * H;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = part * 16 + it * 2 + rsub;
+    const int q = qblk * 128 + row;
+    if (q >= R || c4 >= HD / 4) continue;
+    float l[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) l[p] = lse_part[(s0 + p) * 128 + row];
+    float mx = l[0];
+#pragma unroll
+    for (int p = 1; p < NP; ++p) mx = fmaxf(mx, l[p]);
+    float den = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) den += __builtin_amdgcn_exp2f(l[p] - mx);
+    const float lse = mx + log2f(den);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int CH = NP < 8 ? NP : 8;                        // partial rows in flight per lane
+#pragma unroll
+    for (int p0 = 0; p0 < NP; p0 += CH) {
+      f32x4 a[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) a[j] = *(const f32x4*)(Opart + ((s0 + p0 + j) * 128 + row) * HD + 4 * c4);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {                           // key order
+        const float w = __builtin_amdgcn_exp2f(l[p0 + j] - lse);
+        acc[0] += w * a[j][0]; acc[1] += w * a[j][1]; acc[2] += w * a[j][2]; acc[3] += w * a[j][3];
+      }
+    }
+    *(u32x2*)(O + ((size_t)vb * R + q) * ldo + h * HD + 4 * c4) = pack4<T>(acc[0], acc[1], acc[2], acc[3]);
+    if (lse2 != nullptr && c4 == 0) lse2[(size_t)hg * R + q] = lse;
+  }
+}
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_combine_hd_sk_kernel(const float* __restrict__ Opart, const float* __restrict__ lse_part,
+                                                                 uint16_t* __restrict__ O, int ldo, float* __restrict__ lse2,
+                                                                 int R, int H, hd_sk_plan plan) {
+  int b = blockIdx.x >> 3, lk = 0, lbase = 0, lslot = 0;      // 8 workgroups per cut unit (16 query rows each)
+  const int part = blockIdx.x & 7;
+  bool found = false;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    if (!found && j < plan.nlev) {
+      if (b < plan.nun[j]) { lk = plan.k[j]; lbase = plan.base[j]; lslot = plan.slot[j]; found = true; }
+      else b -= plan.nun[j];
+    }
+  }
+  if (!found) return;
+  const int nqb = (R + 127) / 128;
+  const int u = lbase + b;
+  const int hg = u / nqb, qblk = u - hg * nqb;
+  const size_t s0 = (size_t)lslot + ((size_t)b << lk);
+  switch (lk) {
+    case 1: combine_hd_sk_rows<T, HD, 2>(Opart, lse_part, s0, O, ldo, lse2, R, H, hg, qblk, part); break;
+    case 2: combine_hd_sk_rows<T, HD, 4>(Opart, lse_part, s0, O, ldo, lse2, R, H, hg, qblk, part); break;
+    case 3: combine_hd_sk_rows<T, HD, 8>(Opart, lse_part, s0, O, ldo, lse2, R, H, hg, qblk, part); break;
+    case 4: combine_hd_sk_rows<T, HD, 16>(Opart, lse_part, s0, O, ldo, lse2, R, H, hg, qblk, part); break;
+    default: combine_hd_sk_rows<T, HD, 32>(Opart, lse_part, s0, O, ldo, lse2, R, H, hg, qblk, part); break;
   }
 }
 
@@ -744,18 +885,40 @@ __global__ __launch_bounds__(256, 1) void attn_colsum_hd_kernel(const uint16_t* 
   }
 }
 
+// Levelled stream-K plan of the 32-query-wave kernel (see hd_sk_plan): used when the units (128-query blocks x heads of all
+// videos) exceed the 256 workgroups of one-per-CU, a plain grid would leave more than 5 % of its last round empty and a unit has
+// at least 2 g_mavlm_attn_sk_min_tiles key tiles of 32 (the same key count as attention3.hip's rule).  Pure function of the shape
+// (mirrored by oracle/memory_path.py streamk_plan_wide).
+constexpr int HD_SK_WGS = 256;
+static hd_sk_plan hd2_plan(int R, int S, int H) {
+  hd_sk_plan p = {};
+  const int G = HD_SK_WGS;
+  const long units = (long)((R + 127) / 128) * H;
+  if (units <= G || (S + KTH - 1) / KTH < 2 * g_mavlm_attn_sk_min_tiles) return p;
+  const long rounds = (units + G - 1) / G;
+  if ((double)units / (double)(rounds * G) >= 0.95) return p;
+  p.wgs = G;
+  p.full = (int)(units / G);
+  int rem = (int)(units % G), base = p.full * G, slot = 0;
+  for (int k = 1; k <= 4; ++k)
+    if (rem >= (G >> k)) {
+      p.k[p.nlev] = k; p.base[p.nlev] = base; p.nun[p.nlev] = G >> k; p.slot[p.nlev] = slot;
+      ++p.nlev; base += G >> k; rem -= G >> k; slot += G;
+    }
+  while (rem > 0) {                                           // < G/16 units left: 32-way levels of up to G/32 units
+    const int n = rem < (G >> 5) ? rem : (G >> 5);
+    p.k[p.nlev] = 5; p.base[p.nlev] = base; p.nun[p.nlev] = n; p.slot[p.nlev] = slot;
+    ++p.nlev; base += n; rem -= n; slot += G;
+  }
+  return p;
+}
+static size_t hd2_plan_floats(const hd_sk_plan& p, int head_dim) {
+  return p.wgs > 0 ? (size_t)p.wgs * p.nlev * ((size_t)128 * head_dim + 128) : 0;
+}
+
 template <typename T, int HD, int QG>
 hipError_t launch_fwd_hd(const mavlm_attn_args& a, hipStream_t s) {
   constexpr int LDS = 4 * ((HD + 127) / 128) * KTH * 256;
-  void (*kern)(const uint16_t*, int, const uint16_t*, int, const uint16_t*, int, uint16_t*, int, float*, int, int, int, float, float*,
-               float*, int, long long);
-  if constexpr (QG == 2) kern = attn_fwd_hd2_kernel<T, HD, 3, 3>;
-  else kern = attn_fwd_hd_kernel<T, HD>;
-  static mavlm_per_device_once once;
-  {
-    hipError_t e = once.dyn_lds((const void*)kern, LDS);
-    if (e != hipSuccess) return e;
-  }
   const float c = a.scale * 1.44269504088896340736f;
   const int nb = a.nb > 0 ? a.nb : 1;                     // row batch: a.H counts the heads of ALL videos
   if (a.H % nb != 0) return hipErrorInvalidValue;
@@ -765,10 +928,46 @@ hipError_t launch_fwd_hd(const mavlm_attn_args& a, hipStream_t s) {
   if (ns <= 1) { ns = 1; tps = 0; }
   float* opart = a.split_ws;
   float* lpart = ns > 1 ? a.split_ws + (size_t)ns * a.R * a.H * HD : nullptr;
-  mavlm_prof_scope prof(MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD, 2.0 * HD * a.H * (2.0 * a.R + 2.0 * a.S), s);
-  hipLaunchKernelGGL(kern, dim3(((a.R + 127) / 128) * Hv, ns, nb), dim3(QG >= 2 ? 256 : 512), LDS, s, (const uint16_t*)a.Q, a.ldq,
-                     (const uint16_t*)a.K, a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, Hv, c,
-                     opart, lpart, tps, (long long)a.kv_bstride);
+  static mavlm_per_device_once once;
+  if constexpr (QG == 2) {
+    auto kern = attn_fwd_hd2_kernel<T, HD, 3, 3>;
+    {
+      hipError_t e = once.dyn_lds((const void*)kern, LDS);
+      if (e != hipSuccess) return e;
+    }
+    hd_sk_plan plan = {};
+    if (a.split_ws != nullptr) plan = hd2_plan(a.R, a.S, a.H);      // (the caller sized split_ws with mavlm_attention_hd_split_ws_floats)
+    dim3 grid(((a.R + 127) / 128) * Hv, ns, nb);
+    if (plan.wgs > 0) {
+      grid = dim3(plan.wgs, 1, 1);
+      ns = 1; tps = 0;
+      lpart = a.split_ws + (size_t)plan.wgs * plan.nlev * 128 * HD;
+    }
+    {
+      mavlm_prof_scope prof(MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD, 2.0 * HD * a.H * (2.0 * a.R + 2.0 * a.S), s);
+      hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K, a.ldk,
+                         (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, Hv, c, opart, lpart, tps,
+                         (long long)a.kv_bstride, plan);
+    }
+    if (plan.wgs > 0) {
+      int cut = 0;
+      for (int j = 0; j < plan.nlev; ++j) cut += plan.nun[j];
+      mavlm_prof_scope prof(MAVLM_K_ATTN_MERGE, 0.0, (double)cut * 128 * HD * 4.0 * 2.0, s);
+      hipLaunchKernelGGL((attn_combine_hd_sk_kernel<T, HD>), dim3(cut * 8), dim3(256), 0, s, opart, lpart, (uint16_t*)a.O, a.ldo,
+                         a.lse2, a.R, Hv, plan);
+      return hipGetLastError();
+    }
+  } else {
+    auto kern = attn_fwd_hd_kernel<T, HD>;
+    {
+      hipError_t e = once.dyn_lds((const void*)kern, LDS);
+      if (e != hipSuccess) return e;
+    }
+    mavlm_prof_scope prof(MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD, 2.0 * HD * a.H * (2.0 * a.R + 2.0 * a.S), s);
+    hipLaunchKernelGGL(kern, dim3(((a.R + 127) / 128) * Hv, ns, nb), dim3(512), LDS, s, (const uint16_t*)a.Q, a.ldq,
+                       (const uint16_t*)a.K, a.ldk, (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, Hv, c,
+                       opart, lpart, tps, (long long)a.kv_bstride);
+  }
   if (ns > 1) return mavlm_launch_attention_combine(opart, lpart, a.O, a.ldo, a.lse2, a.R, a.H, HD, ns, std::is_same<T, F16>::value ? MAVLM_F16 : MAVLM_BF16, s);
   return hipGetLastError();
 }
@@ -807,9 +1006,22 @@ int mavlm_attention_hd_splits(int R, int S, int H, int* tiles_per_split) {
   return ns;
 }
 
+// fp32 floats of attention partials the wide-head forward of this shape wants (H = heads of ALL videos of a row batch): the
+// stream-K plan of the 32-query-wave kernel (head_dim 448) or the split-KV form of the small single-video grids
 size_t mavlm_attention_hd_split_ws_floats(int R, int S, int H, int head_dim) {
+  if (head_dim == 448 && g_mavlm_attn_hd_qg != 1) {
+    const size_t v = hd2_plan_floats(hd2_plan(R, S, H), head_dim);
+    if (v) return v;
+  }
   const int ns = mavlm_attention_hd_splits(R, S, H, nullptr);
   return ns > 1 ? (size_t)ns * R * H * head_dim + (size_t)ns * H * R : 0;
+}
+// workgroups of the stream-K plan (0 = the plan is not used for this shape); info[3] = {G, whole units per workgroup, levels}
+int mavlm_attention_hd_streamk(int R, int S, int H, int head_dim, int info[3]) {
+  hd_sk_plan p = {};
+  if (head_dim == 448 && g_mavlm_attn_hd_qg != 1) p = hd2_plan(R, S, H);
+  if (info) { info[0] = p.wgs; info[1] = p.full; info[2] = p.nlev; }
+  return p.wgs;
 }
 
 int g_mavlm_attn_hd_qg = 0;      // tuning hook: 0 = automatic (32-query waves at head_dim 448), 1 = 16-query waves, 2 = 32-query

@@ -109,9 +109,12 @@ void carve(mavlm_ctx* x) {
       else cap = items < 200 ? (400 / items > 8 ? 8 : 400 / items) : 0;                      // mavlm_attention_hd_splits
       fl = cap >= 2 ? cap * (R1 * Dp + H * R1) : 0;
     }
+    const int s_long = 1 << 20;          // (the stream-K schedules only depend on "enough key tiles")
     if (!wide_heads(c)) {
-      const int s_long = 1 << 20;        // (the schedule only depends on "enough key tiles")
       const size_t sk = mavlm_attention_split_ws_floats_max((int)R1, s_long, (int)(H * B));
+      if (sk > fl) fl = sk;
+    } else if (mavlm_attention_hd_streamk((int)R1, s_long, (int)(H * B), c.hidden / c.heads, nullptr) > 0) {
+      const size_t sk = mavlm_attention_hd_split_ws_floats((int)R1, s_long, (int)(H * B), c.hidden / c.heads);
       if (sk > fl) fl = sk;
     }
     x->split_floats = fl;
@@ -226,10 +229,15 @@ int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const 
   a.Q = ws(x, x->o_q); a.ldq = Dp; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = ws(x, x->o_ctx); a.ldo = Dp;
   a.lse2 = lse2; a.R = R1; a.S = S; a.H = H * B; a.nb = B; a.kv_bstride = kv_bs; a.scale = attn_scale(c);
   if (wide_heads(c)) {
-    // wide heads (448: the OneVision-7B width): the row batch is the grid's z dimension (never split over the keys: B videos
-    // fill the chip); a single video may take the kernel's split-KV form
-    a.split_ws = (B == 1 && x->split_floats) ? (float*)ws(x, x->o_split) : nullptr;
-    MAVLM_TRY(mavlm_launch_attention_hd(a, c.hidden / c.heads, dt, s));
+    // wide heads (448: the OneVision-7B width): the row batch is the grid's z dimension, or - when its units exceed the 256
+    // workgroups of one-per-CU - the levelled stream-K plan over the (video, head) pairs; a single video with a small grid takes
+    // the kernel's split-KV form.  The schedule is part of the result: the plan is taken only when the carved workspace covers
+    // it under the CURRENT tuning hooks.
+    const int hd = c.hidden / c.heads;
+    const bool sk = mavlm_attention_hd_streamk(R1, S, H * B, hd, nullptr) > 0;
+    if (sk) a.split_ws = mavlm_attention_hd_split_ws_floats(R1, S, H * B, hd) <= x->split_floats ? (float*)ws(x, x->o_split) : nullptr;
+    else a.split_ws = (B == 1 && x->split_floats) ? (float*)ws(x, x->o_split) : nullptr;
+    MAVLM_TRY(mavlm_launch_attention_hd(a, hd, dt, s));
   } else {
     // the schedule is part of the result: take it only when the carved workspace covers this shape's plan under the
     // CURRENT tuning hooks (they may have changed since mavlm_create) - never write past the carve
@@ -381,7 +389,7 @@ int mavlm_set_gemm_tile(int32_t tile) {
   return 0;
 }
 
-extern int g_mavlm_attn_sk_min_tiles, g_mavlm_attn_sk_waves;
+extern int g_mavlm_attn_sk_waves;      // (g_mavlm_attn_sk_min_tiles: mavlm_kernels.h)
 int mavlm_set_attention_streamk_min_tiles(int32_t tiles) {
   if (tiles < 1) return MAVLM_E_ARG;
   g_mavlm_attn_sk_min_tiles = tiles;
@@ -752,6 +760,15 @@ int mavlm_attention_hd(const void* Q, int32_t ldq, const void* K, int32_t ldk, c
   a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.lse2 = lse2;
   a.R = R; a.S = S; a.H = H; a.scale = scale;
   return (int)mavlm_launch_attention_hd(a, head_dim, dtype, (hipStream_t)stream);
+}
+
+int mavlm_attention_hd_plan_info(int32_t R, int32_t S, int32_t H, int32_t head_dim, int32_t* info) {
+  if (R <= 0 || S <= 0 || H <= 0 || !info) return MAVLM_E_ARG;
+  int v[3] = {0, 0, 0};
+  mavlm_attention_hd_streamk(R, S, H, head_dim, v);
+  info[0] = v[0]; info[1] = v[1]; info[2] = v[2];
+  info[3] = v[0] > 0 ? 1 : mavlm_attention_hd_splits(R, S, H, nullptr);
+  return 0;
 }
 
 int64_t mavlm_attention_hd_ws_floats(int32_t R, int32_t S, int32_t H, int32_t head_dim) {

@@ -96,6 +96,8 @@ size_t mavlm_attention_split_ws_floats_max(int R, int S, int H);   // ... over b
 // the same for the wide-head kernel (attention_hd.hip) and the merge kernel both use (attention3.hip)
 int mavlm_attention_hd_splits(int R, int S, int H, int* tiles_per_split);
 size_t mavlm_attention_hd_split_ws_floats(int R, int S, int H, int head_dim);
+int mavlm_attention_hd_streamk(int R, int S, int H, int head_dim, int info[3]);
+extern int g_mavlm_attn_sk_min_tiles;   // attention3.hip: key tiles (of 64) a unit needs before the stream-K schedules apply
 hipError_t mavlm_launch_attention_combine(const float* opart, const float* lpart, void* O, int ldo, float* lse2, int R, int H,
                                           int hd, int ns, int dtype, hipStream_t s);
 // software-pipelined LDS-DMA variant (attention3.hip); mavlm_launch_attention dispatches to it

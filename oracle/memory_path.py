@@ -338,7 +338,7 @@ def kernel_tiling(head_dim: int) -> Tuple[int, int]:
     32 / 16 at the other wide widths (224, 256: attn_fwd_hd_kernel)."""
     if head_dim <= 128:
         return (KV_TILE, WAVE_ROWS)
-    return (32, 32) if head_dim == 448 else (32, 16)
+    return (32, 32) if (head_dim == 448 and WIDE_GROUPS != 1) else (32, 16)
 
 
 def split_plan(R: int, S: int, heads: int) -> Tuple[int, int]:
@@ -440,6 +440,51 @@ def split_plan_wide(R: int, S: int, heads: int) -> Tuple[int, int]:
     tps = -(-nt // ns)
     ns = -(-nt // tps)
     return ns, (tps if ns > 1 else 0)
+
+
+WIDE_GROUPS = 2       # mirror of mavlm_set_attention_wide_groups: 2 (default) = 32-query waves at head_dim 448, 1 = 16-query
+
+
+def streamk_plan_wide(R: int, S: int, heads: int):
+    """Mirrors hd2_plan (csrc/attention_hd.hip): the levelled stream-K plan of the 32-query-wave kernel (head_dim 448) over
+    128-query units, 32-key tiles and G = 256 workgroups; `heads` counts the heads of ALL videos of a row batch.  Returns
+    (G, full, levels) with levels = [(k, first unit, units)]; G = 0: not used."""
+    G = 256
+    units = -(-R // 128) * heads
+    if units <= G or -(-S // 32) < 2 * STREAMK_MIN_TILES:
+        return 0, 0, []
+    rounds = -(-units // G)
+    if units / (rounds * G) >= 0.95:
+        return 0, 0, []
+    full, rem = divmod(units, G)
+    base, levels = full * G, []
+    for k in range(1, 5):
+        if rem >= (G >> k):
+            levels.append((k, base, G >> k))
+            base += G >> k
+            rem -= G >> k
+    while rem > 0:
+        n = min(rem, G >> 5)
+        levels.append((5, base, n))
+        base += n
+        rem -= n
+    return G, full, levels
+
+
+def streamk_split_tiles_wide(R: int, S: int, heads: int):
+    """{(global head, query block): [(tile_lo, tile_hi), ...]} for the 128-query units the wide-head stream-K plan cuts (32-key
+    tiles; empty ranges dropped).  Unit order: head-major, then query block."""
+    G, _, levels = streamk_plan_wide(R, S, heads)
+    out: Dict[Tuple[int, int], List[Tuple[int, int]]] = {}
+    if not G:
+        return out
+    nqb, nt = -(-R // 128), -(-S // 32)
+    for k, base, n in levels:
+        for ul in range(n):
+            u = base + ul
+            rng = [((p * nt) >> k, ((p + 1) * nt) >> k) for p in range(1 << k)]
+            out[(u // nqb, u % nqb)] = [(a, b) for a, b in rng if b > a]
+    return out
 
 
 ROW_BLOCK_ELEMS = 1 << 28   # score elements per (head, query block) above which the queries are processed in blocks
@@ -591,7 +636,14 @@ def _attention_heads(Q: np.ndarray, K: np.ndarray, V: np.ndarray, heads: int, mo
                 if streamk_wgs(plan_rows or R, Lk, heads * nb):
                     ns, tps = 1, 0
             elif kv_tile == 32:               # attention_hd.hip
-                ns, tps = split_plan_wide(plan_rows or R, Lk, heads)
+                vb, nb = ROW_BATCH
+                ns, tps = split_plan_wide(plan_rows or R, Lk, heads) if nb == 1 else (1, 0)
+                if wave_rows == 32 and d == 448:      # attn_fwd_hd2_kernel: stream-K over the (video, head) pairs
+                    sk_qb = 128
+                    sk_all = streamk_split_tiles_wide(plan_rows or R, Lk, heads * nb)
+                    sk_cuts = {qb: a for (hh_, qb), a in sk_all.items() if hh_ == vb * heads + h}
+                    if streamk_plan_wide(plan_rows or R, Lk, heads * nb)[0]:
+                        ns, tps = 1, 0
             else:
                 ns, tps = 1, 0
             if sk_cuts:

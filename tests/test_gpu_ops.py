@@ -2,6 +2,7 @@
 
 Gates (SURVEY.md §8c): exact for integer-valued data (fp32 accumulation of small integers is exact);
 rel-L2 <= 1e-3 against the oracle in operand-rounding-emulation mode for random data."""
+import ctypes
 import math
 
 import numpy as np
@@ -456,6 +457,51 @@ def _wide_heads_vs_oracle(mode, hd, R, S, H, wave_rows):
     part = ops.attention_colsum(to_dev(q, mode), to_dev(k, mode), lse, H, head_dim=hd, wide_kernel=True)
     assert O.rel_l2(to_np(part), col) < TOL
     assert abs(float(part.sum()) - H * R) < 1e-3 * H * R
+
+
+@pytest.mark.parametrize("mode,R,S,H", [("bf16", 4224, 1024 + 17, 8), ("fp16", 6100, 800, 8), ("bf16", 1500, 700, 23)])
+def test_attention_wide_heads_stream_k(mode, R, S, H, monkeypatch, request):
+    """head_dim 448 with more 128-query units than the 256 workgroups of one-per-CU (the OneVision-7B row batch: 416): the
+    levelled stream-K plan of attn_fwd_hd2_kernel - whole units first, the remainder in binary levels whose units are cut into
+    2^k key ranges (normalised fp32 partials, merged by attn_combine_hd_sk_kernel).  The oracle mirrors the cuts
+    (streamk_split_tiles_wide); ragged query blocks / key tiles, a 32-way level (264 units), a 2-way level (384 units) and a
+    mixed one (276 units) included; deterministic; agrees with the plain grid within rounding."""
+    lib = capi.lib()
+    info = (ctypes.c_int32 * 4)()
+    capi.check(lib.mavlm_attention_hd_plan_info(12544, 6272, 8, 448, info), "plan info")
+    assert list(info) == [256, 3, 1, 1]                                   # 784 units: 3 whole rounds + 16 units cut 16-way
+    capi.check(lib.mavlm_attention_hd_plan_info(1568, 6272, 32, 448, info), "plan info")
+    assert list(info)[:3] == [256, 1, 2]                                  # the OneVision-7B batch of four: 416 units
+    capi.check(lib.mavlm_attention_hd_plan_info(1568, 6272, 8, 448, info), "plan info")
+    assert info[0] == 0 and info[3] > 1                                   # a single video: small grid, keys split
+    capi.check(lib.mavlm_set_attention_streamk_min_tiles(8), "min tiles")  # (the default needs 4 096 keys)
+    monkeypatch.setattr(O, "STREAMK_MIN_TILES", 8)
+    request.addfinalizer(lambda: lib.mavlm_set_attention_streamk_min_tiles(64))
+    capi.check(lib.mavlm_attention_hd_plan_info(R, S, H, 448, info), "plan info")
+    G, full, levels = O.streamk_plan_wide(R, S, H)
+    assert info[0] == 256 == G and info[1] == full and info[2] == len(levels) and len(O.streamk_split_tiles_wide(R, S, H)) >= 8
+    assert lib.mavlm_attention_hd_ws_floats(R, S, H, 448) == 256 * len(levels) * (128 * 448 + 128)
+    r = O.rounder(mode)
+    W = H * 448
+    q = r(O.hash_normal_like((R, W), 131))
+    k = r(O.hash_normal_like((S, W), 132))
+    v = r(O.hash_normal_like((S, W), 133))
+    q[5] *= 8.0                                       # a few rows whose maximum jumps (deferred-rescale branch);
+    k[S // 2 + 3] *= 4.0                              # powers of two: the data stay on the 16-bit grid
+    ctx, lse2, _, _ = O.attention_heads(q, k, v, H, mode, kv_tile=32, wave_rows=32)
+    dq, dk, dv = to_dev(q, mode), to_dev(k, mode), to_dev(v, mode)
+    got, lse = ops.attention(dq, dk, dv, H, want_lse=True, head_dim=448, wide_kernel=True)
+    assert O.rel_l2(to_np(got), r(ctx)) < TOL
+    np.testing.assert_allclose(to_np(lse), lse2, rtol=0, atol=3e-3)
+    again, lse_again = ops.attention(dq, dk, dv, H, want_lse=True, head_dim=448, wide_kernel=True)
+    assert torch.equal(again, got) and torch.equal(lse_again, lse)       # static schedule, no atomics: deterministic
+    plain = torch.empty_like(got)
+    lse_p = torch.empty_like(lse)
+    capi.check(lib.mavlm_attention_hd(dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(), dv.stride(0),
+                                      plain.data_ptr(), plain.stride(0), lse_p.data_ptr(), R, S, H, 448, 1.0 / math.sqrt(448.0),
+                                      ops.dtype_code(dq.dtype), ops.stream_ptr()), "mavlm_attention_hd")
+    assert O.rel_l2(to_np(got), to_np(plain)) < (3e-3 if mode == "bf16" else 5e-4)
+    np.testing.assert_allclose(to_np(lse), to_np(lse_p), rtol=0, atol=1e-4)
 
 
 @pytest.mark.parametrize("groups", [2, 1])

@@ -39,13 +39,32 @@ def test_attention_plans_match_the_oracle(lib):
             assert need == G * len(levels) * (QB * 128 + QB), (R, S, H)
 
 
-def test_wide_head_splits_match_the_oracle(lib):
-    for R, S, H in itertools.product(ROWS, KEYS, [1, 2, 8]):
+def test_wide_head_plans_match_the_oracle(lib):
+    """head_dim 448: the levelled stream-K plan of the 32-query-wave kernel (more 128-query units than 256 workgroups; H up to
+    the heads of a row batch) and the key splits of the small single-video grids; head_dim 256 (16-query kernel): splits only."""
+    info = (ctypes.c_int32 * 4)()
+    for R, S, H in itertools.product(ROWS, KEYS, [1, 2, 8, 32, 64]):
+        G, full, levels = O.streamk_plan_wide(R, S, H)
         ns, _ = O.split_plan_wide(R, S, H)
+        capi.check(lib.mavlm_attention_hd_plan_info(R, S, H, 448, info), "plan info")
+        assert info[0] == G, (R, S, H)
         need = lib.mavlm_attention_hd_ws_floats(R, S, H, 448)
-        assert (need > 0) == (ns > 1), (R, S, H)
-        if ns > 1:
-            assert need == ns * (R * H * 448 + H * R), (R, S, H)
+        if G:
+            assert info[1] == full and info[2] == len(levels) and info[3] == 1, (R, S, H)
+            assert need == G * len(levels) * (128 * 448 + 128), (R, S, H)
+            cuts = O.streamk_split_tiles_wide(R, S, H)
+            assert len(cuts) == sum(n for _, _, n in levels), (R, S, H)
+            nt = -(-S // 32)
+            for rng in cuts.values():                         # a cut unit's ranges tile its keys exactly, in order
+                assert rng[0][0] == 0 and rng[-1][1] == nt and all(a[1] == b[0] for a, b in zip(rng, rng[1:])), (R, S, H)
+        else:
+            assert info[3] == ns, (R, S, H)
+            assert (need > 0) == (ns > 1), (R, S, H)
+            if ns > 1:
+                assert need == ns * (R * H * 448 + H * R), (R, S, H)
+        capi.check(lib.mavlm_attention_hd_plan_info(R, S, H, 256, info), "plan info")
+        assert info[0] == 0 and info[3] == ns, (R, S, H)
+        assert lib.mavlm_attention_hd_ws_floats(R, S, H, 256) == (ns * (R * H * 256 + H * R) if ns > 1 else 0), (R, S, H)
 
 
 def test_frame_score_rule_matches_the_oracle(lib):
