@@ -290,9 +290,9 @@ struct hd_sk_plan {
 // HALF the MFMAs (56 per tile, 32 clocks each, 8 of them holding the issue port): six free issue slots per MFMA instead of
 // two, conflict-free K reads; with ~165 / ~145 other instructions in the two phases of a tile (K pieces in [A], V pieces in
 // [B]; sub-image offsets as instruction immediates; accumulator read + fma + exp as one asm statement; the ragged-tail mask a
-// real branch) it runs 0.94-0.96 PFLOP/s at that shape - a 784-workgroup grid that fills 3.06 rounds of 256 CUs - the matrix
+// real branch) it runs 0.94-0.96 PFLOP/s at that shape as a plain grid - 784 workgroups, 3.06 rounds of 256 CUs - the matrix
 // pipe 59 % busy inside the loop (profiles/r03_wide_head_pmc.txt), the rest waits (SQ_WAIT_ANY 27 %: an exposed LDS round trip
-// when phase [A] opens, the barrier per tile) and issue stalls.
+// when phase [A] opens, the barrier per tile) and issue stalls; 1.07 PFLOP/s on the levelled stream-K plan below.
 //
 // Mapping = attn_fwd3_kernel's, a 128-column sub-image standing where its head stood:
 //   S^T[key][query] = K.Q^T : 28 k-steps of 16 dims, one ds_read_b128 K row fragment per MFMA (lane = key row, half = lane>>5);
