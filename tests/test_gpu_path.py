@@ -456,9 +456,13 @@ def test_pool_two_videos_in_flight_bit_identical():
         assert torch.equal(a, b)
 
 
-def test_graph_capture_replay_bit_identical():
-    """The whole per-video launch sequence captured into one hipGraph replays to the same bits as eager launches."""
-    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=8, depth=2)
+@pytest.mark.parametrize("M", [8, 64])
+def test_graph_capture_replay_bit_identical(M):
+    """The whole per-video launch sequence captured into one hipGraph replays to the same bits as eager launches - at the
+    checkpoint's 8 memory tokens and at the metric's 64, where the Residual blocks run as the fused kernel whose workgroups
+    exchange row statistics through memory (launch-counter epochs: nothing is re-zeroed between replays) and the attention
+    runs its stream-K schedule."""
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=M, depth=2)
     w = O.make_weights(cfg, seed=14)
     model, _ = _tiny_host(cfg, w)
     T = 70
@@ -471,8 +475,14 @@ def test_graph_capture_replay_bit_identical():
         eager, _ = arch.video_memory_tokens(model, x, idx, mp, fp, model.image_newline)
         out = g(x, mp, fp, model.image_newline)
         torch.cuda.synchronize()
-        assert out.shape == eager.shape == (10 + 3 * 1568 + 1 + 9 + 32 * 196 + 1, 1024)
+        assert out.shape == eager.shape == (10 + 3 * M * 196 + 1 + 9 + 32 * 196 + 1, 1024)
         assert torch.equal(out, eager)
+    for eng in (model.recurrent_memory_transformer._engine, g.view.recurrent_memory_transformer._engine):
+        st = eng.ln_exchange_status() if eng is not None else None
+        if M == 64:
+            assert st is not None and st[0] > 0           # the fused Residual kernel did run (launch counter advanced)
+        if st is not None:
+            assert st[1] == 0                             # no workgroup ever gave up waiting for a partner
 
 
 @pytest.mark.parametrize("T", [1, 5, 33])
