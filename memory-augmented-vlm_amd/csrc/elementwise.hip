@@ -137,6 +137,88 @@ __global__ __launch_bounds__(256) void layernorm8_kernel(const float* __restrict
   }
 }
 
+// Wide rows (D > 2048, e.g. 3584 at the OneVision-7B width): ONE ROW PER WORKGROUP instead of per wave.  With a wave per row a
+// lane holds 7-8 chunks (~110 VGPRs, 4 waves per SIMD) and 6 272 rows are 1.5 rounds of the chip's wave slots: 2.4 TB/s
+// algorithmic.  Four waves per row hold <= 2 chunks per lane (~40 VGPRs); the two row reductions go through LDS (fixed order:
+// lanes by butterfly, then the four waves in order).
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void layernorm8_block_kernel(const float* __restrict__ x, const uint16_t* __restrict__ res,
+                                                               int ldr, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, uint16_t* __restrict__ out,
+                                                               int rows, int D, float eps) {
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int row = blockIdx.x;
+  const int nch = D >> 3;
+  const f32x4* xr = (const f32x4*)(x + (size_t)row * D);
+  f32x4 v[NC][2];
+  u32x4 rv[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int j = i * 256 + tid;
+    if (j < nch) {
+      v[i][0] = xr[2 * j];
+      v[i][1] = xr[2 * j + 1];
+      if (res != nullptr) rv[i] = *(const u32x4*)(res + (size_t)row * ldr + 8 * j);
+    } else {
+      v[i][0] = v[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int j = i * 256 + tid;
+    if (j < nch) {
+      if (res != nullptr) {      // residual add of the Residual block, in fp32 (MemoryController.py:28)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[i][e >> 1][2 * (e & 1)] += T::to_f32((uint16_t)(rv[i][e] & 0xffffu));
+          v[i][e >> 1][2 * (e & 1) + 1] += T::to_f32((uint16_t)(rv[i][e] >> 16));
+        }
+      }
+      s += ((v[i][0][0] + v[i][0][1]) + (v[i][0][2] + v[i][0][3])) + ((v[i][1][0] + v[i][1][1]) + (v[i][1][2] + v[i][1][3]));
+    }
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[0][wave] = s;
+  __syncthreads();
+  const float mean = (((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]) / (float)D;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int j = i * 256 + tid;
+    if (j < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[i][e >> 2][e & 3] - mean;
+        ss += d * d;
+      }
+    }
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[1][wave] = ss;
+  __syncthreads();
+  const float rstd = rsqrtf((((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]) / (float)D + eps);
+  uint16_t* orow = out + (size_t)row * D;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int j = i * 256 + tid;
+    if (j < nch) {
+      u32x4 o;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const f32x4 g = ((const f32x4*)gamma)[2 * j + hf];
+        const f32x4 b = ((const f32x4*)beta)[2 * j + hf];
+        const u32x2 w = pack4<T>((v[i][hf][0] - mean) * rstd * g[0] + b[0], (v[i][hf][1] - mean) * rstd * g[1] + b[1],
+                                 (v[i][hf][2] - mean) * rstd * g[2] + b[2], (v[i][hf][3] - mean) * rstd * g[3] + b[3]);
+        o[2 * hf] = w[0];
+        o[2 * hf + 1] = w[1];
+      }
+      *(u32x4*)(orow + 8 * j) = o;
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void row_add_kernel(const uint16_t* __restrict__ x, const int64_t* __restrict__ src,
                                                       const uint16_t* __restrict__ table,
@@ -225,7 +307,9 @@ hipError_t ln_dispatch(const float* x, const void* res, int ldr, const float* g,
     if (nc <= 1) ln8_launch<T, 1>(x, res, ldr, g, b, out, rows, D, eps, s);
     else if (nc <= 2) ln8_launch<T, 2>(x, res, ldr, g, b, out, rows, D, eps, s);
     else if (nc <= 4) ln8_launch<T, 4>(x, res, ldr, g, b, out, rows, D, eps, s);
-    else ln8_launch<T, 8>(x, res, ldr, g, b, out, rows, D, eps, s);
+    else       // D > 2048: a workgroup per row (<= 2 chunks per lane; the wave-per-row form needs 246 VGPRs there: 1 wave per SIMD)
+      hipLaunchKernelGGL((layernorm8_block_kernel<T, 2>), dim3(rows), dim3(256), 0, s, x, (const uint16_t*)res, ldr, g, b,
+                         (uint16_t*)out, rows, D, eps);
     return hipGetLastError();
   }
   const int nv = (D / 4 + 63) / 64;
