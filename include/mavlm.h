@@ -226,7 +226,7 @@ int mavlm_attention_hd(const void* Q, int32_t ldq, const void* K, int32_t ldk, c
                        int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, int32_t head_dim, float scale,
                        int32_t dtype, void* stream);
 /* mavlm_attention_hd with the split-KV path for small grids (ceil(R/128)*H < 200 workgroups, >= 32 key tiles of 32: e.g.
- * 8 memory tokens at the OneVision-7B width); ws = mavlm_attention_hd_ws_floats(...) floats (0 = no split).  Same
+ * 8 memory tokens at the OneVision-7B width: 104 units, 2 splits); ws = mavlm_attention_hd_ws_floats(...) floats (0 = no split).  Same
  * scheme and merge kernel as mavlm_attention_ws; mavlm_step uses the same plan. */
 int64_t mavlm_attention_hd_ws_floats(int32_t R, int32_t S, int32_t H, int32_t head_dim);
 /* schedule of the wide-head forward for this shape (H = heads of ALL videos of a row batch): info[0] = workgroups of the

@@ -989,16 +989,25 @@ hipError_t launch_colsum_hd(const mavlm_colsum_args& a, hipStream_t s) {
 
 }  // namespace
 
-// Split-KV plan of the wide-head kernel (128-query workgroups of 8 waves, at most 2 per CU; 32-key tiles)
+// Split-KV plan of the wide-head kernels (128-query workgroups, ONE per CU - 128 KiB of LDS; 32-key tiles).  Small grids
+// (fewer than 200 units, at least 32 key tiles) cut every unit into ns equal key ranges: ns = the count (2 .. 8, at least 16
+// tiles per range) that minimises  rounds(units x ns on 256 CUs) / ns  + a charge of 2 % of a unit per split for the fp32
+// partials and their merge; ties -> fewer splits.  (Rounds 1-2 used ns = min(8, 400 / units): at the OneVision-7B shape - 104
+// units - that is 3 splits = 312 workgroups = TWO rounds of a third each; 2 splits = 208 workgroups finish in ONE round of a
+// half.)  Pure function of the shape, mirrored by oracle/memory_path.py split_plan_wide.
 int mavlm_attention_hd_splits(int R, int S, int H, int* tiles_per_split) {
   const int items = ((R + 127) / 128) * H;
   const int nt = (S + KTH - 1) / KTH;
   int ns = 1;
   if (items < 200 && nt >= 32) {
-    ns = 400 / items;
-    if (ns > 8) ns = 8;
-    if (ns > nt / 16) ns = nt / 16;
-    if (ns < 2) ns = 1;
+    int cap = nt / 16;
+    if (cap > 8) cap = 8;
+    long best = 5040 + 0;                                   // ns = 1: one round of whole units (items < 256), no charge
+    for (int c = 2; c <= cap; ++c) {
+      const long rounds = ((long)items * c + 255) / 256;
+      const long score = rounds * 5040 / c + 100L * c;      // 5040 = lcm(1..8): exact
+      if (score < best) { best = score; ns = c; }
+    }
   }
   int tps = (nt + ns - 1) / ns;
   ns = (nt + tps - 1) / tps;

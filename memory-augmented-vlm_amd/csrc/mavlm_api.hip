@@ -106,7 +106,7 @@ void carve(mavlm_ctx* x) {
     if (B == 1) {
       size_t cap;
       if (!wide_heads(c)) cap = items < 320 ? (512 / items > 8 ? 8 : 512 / items) : 0;      // mavlm_attention_splits
-      else cap = items < 200 ? (400 / items > 8 ? 8 : 400 / items) : 0;                      // mavlm_attention_hd_splits
+      else cap = (size_t)mavlm_attention_hd_splits((int)R1, 1 << 20, (int)H, nullptr);       // (its maximum over the key count)
       fl = cap >= 2 ? cap * (R1 * Dp + H * R1) : 0;
     }
     const int s_long = 1 << 20;          // (the stream-K schedules only depend on "enough key tiles")

@@ -428,15 +428,20 @@ def frame_scores_fused(R: int, S: int, heads: int, patches: int, head_dim: int =
 
 
 def split_plan_wide(R: int, S: int, heads: int) -> Tuple[int, int]:
-    """(number of key splits, tiles per split) of the wide-head kernel (32-key tiles) - mirrors
-    mavlm_attention_hd_splits (csrc/attention_hd.hip)."""
+    """(number of key splits, tiles per split) of the wide-head kernels (32-key tiles, one 128-query workgroup per CU) - mirrors
+    mavlm_attention_hd_splits (csrc/attention_hd.hip): small grids take the split count that minimises
+    rounds(units x ns on 256 CUs) / ns + 2 % of a unit per split."""
     items = -(-R // 128) * heads
     nt = -(-S // 32)
     ns = 1
     if items < 200 and nt >= 32:
-        ns = min(8, 400 // items, nt // 16)
-        if ns < 2:
-            ns = 1
+        cap = min(8, nt // 16)
+        best = 5040
+        for c in range(2, cap + 1):
+            rounds = (items * c + 255) // 256
+            score = rounds * 5040 // c + 100 * c
+            if score < best:
+                best, ns = score, c
     tps = -(-nt // ns)
     ns = -(-nt // tps)
     return ns, (tps if ns > 1 else 0)
