@@ -477,7 +477,7 @@ def run_replica(args, rank, world, local, device, dist_info):
     traffic, tnote = None, None
     for tp in ("r03_attn_fwd_hbm_traffic.json",):
         tpath = os.path.join(ROOT, "profiles", tp)
-        if os.path.exists(tpath):      # PMC summary committed from a separate rocprofv3 --pmc run (tests/pmc_traffic.sh)
+        if os.path.exists(tpath):      # PMC summary committed from a separate rocprofv3 --pmc run (tools/pmc_traffic.sh)
             tj = json.load(open(tpath))
             traffic = tj.get("bench_avg_bytes_per_launch")
             tnote = (f"NOT measured in this run: constant from profiles/{tp} (separate rocprofv3 --pmc passes over the same "

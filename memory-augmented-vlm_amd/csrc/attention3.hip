@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
   const int nseg = plan.wgs > 0 ? plan.full + plan.nlev : 1;
   // static priority for the second-dispatched half of an 8-wave workgroup (MI355X_MICROARCH.md "Two waves per SIMD", item 4:
   // waves 4-7 are the arbitration losers of every segment otherwise): + 0.2-0.4 % measured, same box, interleaved
-  // (tests/diag_ab_attn_prio.sh)
+  // (tools/diag_ab_attn_prio.sh)
   if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
   for (int si = 0; si < nseg; ++si) {
   // ---- this segment: unit (h, q-block), key tiles [t_lo, t_lo + nt)

@@ -51,12 +51,16 @@ constexpr int STAGE2 = 4 * HALF;             // A0 A1 B0 B1
 constexpr int GEMM256_LDS = 2 * STAGE2;      // 128 KiB
 
 // raw workgroup barrier fenced against compiler motion of memory operations (s_barrier itself is IntrNoMem)
+#ifdef MAVLM_GEMM_ABLATE_BAR
+#define MAVLM_BAR() do { asm volatile("" ::: "memory"); } while (0)
+#else
 #define MAVLM_BAR()                          \
   do {                                       \
     asm volatile("" ::: "memory");           \
     __builtin_amdgcn_s_barrier();            \
     asm volatile("" ::: "memory");           \
   } while (0)
+#endif
 // all LDS reads of this phase retired before its MFMAs (WAR rule above); sched_barrier: hipcc may hoist a
 // register-only MFMA above an inline-asm wait (cdna_hip_programming.md rule 18)
 #define MAVLM_LGKM0()                                          \
@@ -80,8 +84,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
                                                          const uint16_t* __restrict__ W, int ldw,
                                                          const float* __restrict__ bias,
                                                          const uint16_t* __restrict__ res, int ldr,
-                                                         void* __restrict__ Cout, int ldc, int M, int N, int K,
-                                                         int c_rpb, int c_nb, long long c_bs, mavlm_ln_epilogue ln) {
+                                                         void* __restrict__ Cout, int ldc, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -124,6 +127,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   const unsigned lds_wave = (unsigned)(uintptr_t)(MAVLM_LDS char*)smem + wave * 2048;
   // half-tile ids: 0 = A0, 1 = A1, 2 = B0, 3 = B1
   auto dma = [&](int stage, int half_id, int kt) {
+#ifdef MAVLM_GEMM_ABLATE_DMA
+    if (kt > 1) return;                       // (diagnostic build: results are wrong, timing only)
+#endif
     unsigned base = lds_wave;
     asm volatile("" : "+s"(base));            // M0 = base + constant stays a one-instruction recompute (no SGPR hoisting)
     const unsigned dst = base + stage * STAGE2 + half_id * HALF;
@@ -147,6 +153,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifdef MAVLM_GEMM_ABLATE_READS
+  int ablate_kt = 0;
+#endif
   typename T::vec8 af[4][2];      // [m-tile of the current 64-row slice][k-step]
   typename T::vec8 bf[4][2];      // [n-tile of the wave's 64 columns][k-step]
 
@@ -164,6 +173,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   MAVLM_BAR();
 
   auto read_a = [&](const char* st, int mh) {
+#ifdef MAVLM_GEMM_ABLATE_READS
+    if (ablate_kt > 0) return;
+#endif
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       if (mh == 1 && mt >= MT1) continue;     // (mh is a literal at every call site)
@@ -171,7 +183,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
       af[mt][1] = *(const typename T::vec8*)(st + offA + mh * 8192 + mt * 2048 + ck1);
     }
   };
+#ifdef MAVLM_GEMM_ABLATE_MFMA
+#define MAVLM_QUADRANT(MH, NH) { asm volatile("" : "+v"(af[0][0]), "+v"(bf[0][0])); }
+#else
   auto read_b_half = [&](const char* st, int nh) {
+#ifdef MAVLM_GEMM_ABLATE_READS
+    if (ablate_kt > 0) return;
+#endif
 #pragma unroll
     for (int nt = 2 * nh; nt < 2 * nh + 2; ++nt) {
       bf[nt][0] = *(const typename T::vec8*)(st + offB + nt * 2048 + ck0);
@@ -187,6 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
       acc[MH * 4 + mt][NH * 2 + nt] = T::mfma16(bf[NH * 2 + nt][ks], af[mt][ks], acc[MH * 4 + mt][NH * 2 + nt]); \
     __builtin_amdgcn_s_setprio(0);                                                          \
   }
+#endif
 
 
   if (trailing) MAVLM_BAR();           // ping-pong skew: pairs with the leading group's first in-loop barrier
@@ -194,6 +213,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   for (int kt = 0; kt < nk; ++kt) {
     const int s = kt & 1;
     const char* st = smem + s * STAGE2;
+#ifdef MAVLM_GEMM_ABLATE_READS
+    ablate_kt = kt;
+#endif
     // -------- phase 1
     read_a(st, 0);
     read_b_half(st, 0);
@@ -230,172 +252,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   if (!trailing) MAVLM_BAR();          // matches the trailing group's last barrier
 #undef MAVLM_QUADRANT
 
-  if constexpr (EPI == MAVLM_EPI_LN) {
-    // ---- fused Residual epilogue (MemoryController.py:26-29): out = LayerNorm(acc + bias + res) * gamma + beta, 16-bit.
-    // A row's N columns belong to the ntn workgroups of its row block; each computes the mean and the centred sum of squares
-    // of ITS 256 columns (exact fp32, two passes over registers), the workgroups exchange those 2 floats per row through
-    // global memory and merge them (Chan's parallel variance: exact, order fixed -> all workgroups get the same bits).
-    // Exchange = the "data is the flag" granule form (cdna_hip_programming.md Guideline 16, R2): 8-byte {epoch, value}
-    // granules stored and polled with agent-scope relaxed atomics (sc1: no fence, no separate flag).  The epoch comes
-    // from a launch counter in memory that the LAST workgroup of a launch advances - nothing is re-zeroed between launches
-    // and a hipGraph replay sees fresh epochs.  Spins are bounded (a timeout sets ln.ctl[2] and lets the launch drain).
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    MAVLM_BAR();                                            // every wave is out of the K loop: the LDS stages are free
-    float* red = (float*)smem;                              // [4 wave columns][256 rows]
-    float* peer = (float*)(smem + 4096);                    // [ntn][256 rows][2]
-    const int rb = wg / ntn, ct = wg - rb * ntn;
-    const unsigned epoch = __hip_atomic_load(ln.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    constexpr int NI = 4 + MT1;
-    // 1. v = acc + bias + residual (fp32), in place
-    {
-      f32x4 bv[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(bias + n0 + wn * 64 + j * 16 + fq * 4);
-      u32x2 rr[NI][4];
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int m = m0 + wm * MHALF + i * 16 + fr;
-        const int mc = m < M ? m : M - 1;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          rr[i][j] = *(const u32x2*)(res + (size_t)mc * ldr + n0 + wn * 64 + j * 16 + fq * 4);
-      }
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int m = m0 + wm * MHALF + i * 16 + fr;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f32x4 o = acc[i][j] + bv[j];
-          if (ln.pre_out != nullptr && m < M)               // training: the dense output before the residual (for the backward)
-            *(f32x4*)(ln.pre_out + (size_t)m * N + n0 + wn * 64 + j * 16 + fq * 4) = o;
-          o[0] += T::to_f32((uint16_t)(rr[i][j][0] & 0xffffu)); o[1] += T::to_f32((uint16_t)(rr[i][j][0] >> 16));
-          o[2] += T::to_f32((uint16_t)(rr[i][j][1] & 0xffffu)); o[3] += T::to_f32((uint16_t)(rr[i][j][1] >> 16));
-          acc[i][j] = o;
-        }
-      }
-    }
-    // 2. mean and centred sum of squares over this workgroup's 256 columns, per row
-    auto row_reduce = [&](float (&v)[NI]) {                 // in: per-lane partials; out: the 256-column sums, on every lane
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        float s_ = v[i];
-        s_ += __shfl_xor(s_, 16);
-        s_ += __shfl_xor(s_, 32);
-        if (fq == 0) red[wn * 256 + wm * MHALF + i * 16 + fr] = s_;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      MAVLM_BAR();
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int r_ = wm * MHALF + i * 16 + fr;
-        v[i] = ((red[r_] + red[256 + r_]) + red[512 + r_]) + red[768 + r_];
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      MAVLM_BAR();                                          // (red is reused)
-    };
-    float mk[NI], qk[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      float s_ = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s_ += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
-      mk[i] = s_;
-    }
-    row_reduce(mk);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      mk[i] *= (1.0f / 256.0f);
-      float s_ = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float d_ = acc[i][j][e] - mk[i];
-          s_ += d_ * d_;
-        }
-      qk[i] = s_;
-    }
-    row_reduce(qk);
-    // 3. publish (mean, M2) of every row of the tile - also of rows past M: the peers poll all of them
-    unsigned long long* gran = ln.gran + ((size_t)rb * ntn) * (256 * 2);     // [ntn][256][2] granules of this row block
-    if (fq == 0 && wn == 0) {
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int r_ = wm * MHALF + i * 16 + fr;
-        unsigned long long* g_ = gran + ((size_t)ct * 256 + r_) * 2;
-        __hip_atomic_store(g_, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, mk[i]), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(g_ + 1, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, qk[i]), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        peer[(ct * 256 + r_) * 2] = mk[i];
-        peer[(ct * 256 + r_) * 2 + 1] = qk[i];
-      }
-    }
-    // 4. collect the peers' granules into LDS: thread t polls granules t, t + 512, ... of the other ntn - 1 tiles
-    {
-      const int per = BMT * 2, total = (ntn - 1) * per;
-      for (int g0 = tid; g0 < total; g0 += 512) {
-        int k_ = g0 / per;
-        const int w_ = g0 - k_ * per;                       // row * 2 + {mean, M2}
-        k_ += k_ >= ct;                                     // skip our own tile
-        const unsigned long long* g_ = gran + (size_t)k_ * 512 + w_;
-        unsigned long long x_ = 0;
-        unsigned spins = 0;
-        for (;;) {
-          x_ = __hip_atomic_load(g_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((unsigned)(x_ >> 32) == epoch) break;
-          if (++spins > (1u << 22)) {                       // bounded: never hang the chip on a lost partner
-            __hip_atomic_store(ln.ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-          __builtin_amdgcn_s_sleep(2);
-        }
-        peer[k_ * 512 + w_] = __builtin_bit_cast(float, (unsigned)x_);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    MAVLM_BAR();
-    // 5. merge in tile order (every workgroup of the row block adds the same numbers in the same order), normalise, store
-    const float inv_n = 1.0f / (float)N;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int r_ = wm * MHALF + i * 16 + fr;
-      float msum = 0.f;
-      for (int k_ = 0; k_ < ntn; ++k_) msum += peer[(k_ * 256 + r_) * 2];
-      const float mean = msum / (float)ntn;
-      float m2 = 0.f;
-      for (int k_ = 0; k_ < ntn; ++k_) {
-        const float d_ = peer[(k_ * 256 + r_) * 2] - mean;
-        m2 += peer[(k_ * 256 + r_) * 2 + 1] + 256.0f * d_ * d_;
-      }
-      const float rstd = rsqrtf(m2 * inv_n + ln.eps);
-      const int m = m0 + wm * MHALF + i * 16 + fr;
-#pragma unroll
-      for (int j = 0; j < 4; j += 2) {
-        const int nx = n0 + wn * 64 + j * 16 + fq * 4, ny = nx + 16;
-        const f32x4 gx = *(const f32x4*)(ln.gamma + nx), gy = *(const f32x4*)(ln.gamma + ny);
-        const f32x4 bx = *(const f32x4*)(ln.beta + nx), by = *(const f32x4*)(ln.beta + ny);
-        const f32x4 x = acc[i][j], y = acc[i][j + 1];
-        const u32x4 w = widen_pair(pack4<T>((x[0] - mean) * rstd * gx[0] + bx[0], (x[1] - mean) * rstd * gx[1] + bx[1],
-                                            (x[2] - mean) * rstd * gx[2] + bx[2], (x[3] - mean) * rstd * gx[3] + bx[3]),
-                                   pack4<T>((y[0] - mean) * rstd * gy[0] + by[0], (y[1] - mean) * rstd * gy[1] + by[1],
-                                            (y[2] - mean) * rstd * gy[2] + by[2], (y[3] - mean) * rstd * gy[3] + by[3]));
-        const int n = n0 + wn * 64 + 16 * (j + (fq & 1)) + 8 * (fq >> 1);
-        if (m < M) *(u32x4*)((uint16_t*)Cout + (size_t)m * ldc + n) = w;
-      }
-    }
-    // 6. the last workgroup of the launch to get here advances the launch counter (the next launch's epoch) and clears
-    // the arrival counter; both are read / written again only by later launches of the same stream
-    MAVLM_BAR();
-    if (tid == 0) {
-      const unsigned old = __hip_atomic_fetch_add(ln.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old == (unsigned)(ntm * ntn) - 1u) {
-        __hip_atomic_store(ln.ctl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(ln.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    return;
-  }
   // ---- epilogue: lane holds C[m][n..n+3], m = m0 + wm*MHALF + 16 i + fr, n = n0 + wn*64 + 16 j + 4 fq.
   // 16-bit outputs: column blocks (j, j+1) are exchanged between lane groups (widen_pair) so that every lane stores
   // 16 contiguous bytes - half the store instructions, 64-byte instead of 32-byte row segments.
@@ -404,20 +260,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
     if (EPI == MAVLM_EPI_GELU) return gelu_erf_fast(v);
     return v;
   };
-  // element offset of output row m.  Row-batched outputs (mavlm_gemm_args::c_rpb): block q = m / c_rpb of c_rpb rows goes
-  // to batch element q % c_nb, as its (q / c_nb)-th block
-  auto crow = [&](int m) -> size_t {
-    if (c_rpb <= 0) return (size_t)m * ldc;
-    const int q = m / c_rpb, r = m - q * c_rpb;
-    return (size_t)(q % c_nb) * (size_t)c_bs + ((size_t)(q / c_nb) * c_rpb + r) * ldc;
-  };
   f32x4 bv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(bias + n0 + wn * 64 + j * 16 + fq * 4);
 #pragma unroll
   for (int i = 0; i < 4 + MT1; ++i) {
     const int m = m0 + wm * MHALF + i * 16 + fr;
-    const size_t co = crow(m < M ? m : M - 1);
     if (EPI == MAVLM_EPI_RES_F32 || EPI == MAVLM_EPI_F32) {
       if (m >= M) continue;
 #pragma unroll
@@ -428,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
           const u16x4 rv = *(const u16x4*)(res + (size_t)m * ldr + n);
           o[0] += T::to_f32(rv[0]); o[1] += T::to_f32(rv[1]); o[2] += T::to_f32(rv[2]); o[3] += T::to_f32(rv[3]);
         }
-        *(f32x4*)((float*)Cout + co + n) = o;
+        *(f32x4*)((float*)Cout + (size_t)m * ldc + n) = o;
       }
     } else {
 #pragma unroll
@@ -437,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
         const u32x4 w = widen_pair(pack4<T>(act(x[0]), act(x[1]), act(x[2]), act(x[3])),
                                    pack4<T>(act(y[0]), act(y[1]), act(y[2]), act(y[3])));
         const int n = n0 + wn * 64 + 16 * (j + (fq & 1)) + 8 * (fq >> 1);
-        if (m < M) *(u32x4*)((uint16_t*)Cout + co + n) = w;
+        if (m < M) *(u32x4*)((uint16_t*)Cout + (size_t)m * ldc + n) = w;
       }
     }
   }
@@ -454,8 +302,7 @@ hipError_t launch256h(const mavlm_gemm_args& g, hipStream_t s) {
   }
   const int ntm = (g.M + BMT - 1) / BMT, ntn = g.N / BN2;
   hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(512), GEMM256_LDS, s, (const uint16_t*)g.A, g.lda, (const uint16_t*)g.W,
-                     g.ldw, g.bias, (const uint16_t*)g.res, g.ldr, g.C, g.ldc, g.M, g.N, g.K, g.c_rpb, g.c_nb > 0 ? g.c_nb : 1,
-                     (long long)g.c_bstride, g.ln);
+                     g.ldw, g.bias, (const uint16_t*)g.res, g.ldr, g.C, g.ldc, g.M, g.N, g.K);
   return hipGetLastError();
 }
 
@@ -472,32 +319,11 @@ hipError_t launch256_epi(const mavlm_gemm_args& g, hipStream_t s) {
     case MAVLM_EPI_GELU: return launch256<T, MAVLM_EPI_GELU>(g, s);
     case MAVLM_EPI_RES_F32: return launch256<T, MAVLM_EPI_RES_F32>(g, s);
     case MAVLM_EPI_F32: return launch256<T, MAVLM_EPI_F32>(g, s);
-    case MAVLM_EPI_LN: return launch256<T, MAVLM_EPI_LN>(g, s);
   }
   return hipErrorInvalidValue;
 }
 
 }  // namespace
-
-int g_mavlm_gemm_ln_wide = 0;     // test hook (mavlm_set_fused_layernorm(2)): admit up to 16 partners per row block
-// Fused dense + residual + LayerNorm epilogue (EPI_LN): the N / 256 workgroups of a row block exchange 2 floats per row
-// through `gran`.  Scratch: 64 bytes of control words (arrivals, launch counter, timeout flag; FIRST, so that their place does
-// not depend on the shape: a scratch reused for another shape keeps counting epochs upward) + [ceil(M / rows)][N / 256][256][2]
-// 8-byte granules - zero-filled ONCE before the first launch, then owned by the launches of ONE stream.
-bool mavlm_gemm_ln_supported(int M, int N, int K) {
-  // N <= 1024: up to 4 partners per row block.  The kernel is correct for up to 16 (N = 3584 is tested through
-  // mavlm_set_fused_layernorm(2)), but with 14 partners every thread polls 11 granules one after the other and the row
-  // blocks of a grid larger than the chip straddle its rounds (workgroups spin on CUs their partners are waiting for):
-  // measured 730 TFLOP/s against 1 290 for the plain GEMM at the OneVision-7B width - the two-kernel form wins there.
-  if (M <= 0 || N % BN2 != 0 || N / BN2 > (g_mavlm_gemm_ln_wide ? 16 : 4) || N / BN2 < 1 || K % BK2 != 0 || K <= 0) return false;
-  // (the same "fills the chip" rule as the plain 256-column-tile kernels: below it the 128-tile / split-K kernels + the
-  // row LayerNorm kernel are faster)
-  return (long)((M + 255) / 256) * (N / BN2) >= 192;
-}
-size_t mavlm_gemm_ln_ws_bytes(int M, int N) {
-  const size_t rbs = (size_t)((M + 223) / 224);             // (224-row tiles give the most row blocks)
-  return rbs * (size_t)(N / BN2) * 512 * 8 + 64;
-}
 
 // (operand tiles are addressed through 32-bit buffer offsets: 256 rows x leading dimension must stay below 2 GiB)
 bool mavlm_gemm256_supported(const mavlm_gemm_args& g) {
