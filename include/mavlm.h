@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MAVLM_ABI_VERSION 2
+#define MAVLM_ABI_VERSION 3
 #define MAVLM_MAX_DEPTH 8
 #define MAVLM_MAX_BATCH 64
 
@@ -58,7 +58,22 @@ typedef struct mavlm_config {
                              * mavlm_step (the evolution reads ALL rows of every cached memory as keys).  mem0 = the owned
                              * rows [q_tokens*P, D]; frame scores = this shard's partial sums (all-reduce them).
                              * q_tokens = 0: all tokens (no shard).  Not combined with batch > 1. */
+  int32_t fused_ln;         /* Residual blocks (dense + residual + LayerNorm) as ONE kernel: MAVLM_LN_AUTO (0) = wherever the
+                             * shape takes it (the value of the process-wide hook mavlm_set_fused_layernorm at mavlm_create is
+                             * snapshotted into the context: a context's schedule never changes under it), MAVLM_LN_NEVER (1) =
+                             * this context always runs GEMM + row LayerNorm kernel.  See MAVLM_LN_MAX_STREAMS. */
 } mavlm_config;
+#define MAVLM_LN_AUTO 0
+#define MAVLM_LN_NEVER 1
+/* Forward progress of the fused Residual kernel.  Its workgroups WAIT (bounded spin) for the row statistics of the other
+ * N / 256 workgroups of their row block, in an ordinary launch.  Progress rests on one property of the hardware dispatcher:
+ * the workgroups of a launch are handed out in id order, so that at any moment at most ONE row block per XCD is incomplete
+ * and at most N / 256 - 1 <= 3 waiting workgroups per launch hold a CU of an XCD (32 CUs).  With n launches running
+ * concurrently on n streams that is 3 n CUs: the library's contract is n <= MAVLM_LN_MAX_STREAMS (8: 24 of 32 CUs; never
+ * approached by a waiter-only XCD).  A host that runs more streams creates their contexts with fused_ln = MAVLM_LN_NEVER
+ * (the Python MemoryPathPool does).  If the property ever failed, the bounded spin turns the stall into a wrong result of
+ * that launch plus the timeout word (mavlm_ln_status_async) - never a hang. */
+#define MAVLM_LN_MAX_STREAMS 8
 
 /* One `Attention` block (MemoryController.py:31-57) minus its K/V projections.  Weights [out,in] 16-bit
  * (nn.Linear layout), biases and LayerNorm affine parameters fp32.
@@ -108,7 +123,17 @@ size_t mavlm_workspace_bytes(const mavlm_config* cfg);
  * parity tests read the intermediates of the last sub-layer after a step (stage-wise checks) */
 int mavlm_workspace_layout(const mavlm_config* cfg, size_t* offsets, int32_t n);
 int mavlm_bind_weights(mavlm_ctx* ctx, const mavlm_weights* w);
+/* (the exchange scratch of the fused Residual kernel inside the workspace is zero-filled by the library itself: an
+ * asynchronous memset on the stream of the first step after the bind - which therefore must not be inside a hipGraph
+ * capture, MAVLM_E_STATE -; mavlm_bind_weights / mavlm_bind_buffers / mavlm_reset discard a mavlm_project_chunk prefetch) */
 int mavlm_bind_buffers(mavlm_ctx* ctx, const mavlm_buffers* b);
+/* Health of the fused Residual kernel's exchange in this context's workspace, without a synchronisation: enqueues a 16-byte
+ * device-to-host copy of the control words {arrivals, launch counter, timeout flag, -} into `host16` (pinned host memory the
+ * caller owns) on `stream`; the caller reads host16[2] once an event recorded behind the copy has completed.  Non-zero =
+ * some launch since the last clear gave up waiting for a partner (its output is wrong).  clear != 0 also enqueues a reset of
+ * the flag behind the copy.  Returns 1 when the configuration never takes the fused form (nothing enqueued).  The Python
+ * engine posts one probe per video (at `memory_cache = []`) and raises MavlmError at the next one. */
+int mavlm_ln_status_async(mavlm_ctx* ctx, void* host16, int32_t clear, void* stream);
 
 /* --- per-video protocol ------------------------------------------------------------------------------ */
 /* replaces `recurrent_model.memory_cache = []` (llava_arch.py:532) */
@@ -172,13 +197,14 @@ int mavlm_attention_frames(const void* Q, int32_t ldq, const void* K, int32_t ld
                            int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, int32_t patches,
                            float* ws, int64_t ws_floats, float* frame_scores, int32_t dtype, void* stream);
 /* The whole Residual block (MemoryController.py:20-29) in ONE kernel: out = LayerNorm(A . W^T + bias + res) * gamma + beta,
- * 16-bit out [M, ldo]; res 16-bit [M, ldr]; N % 256 == 0, N <= 1024 (wider rows: correct - hook value 2 - but slower than
- * the two-kernel form), and a grid that fills the chip
+ * 16-bit out [M, ldo]; res 16-bit [M, ldr]; N % 256 == 0, N <= 1024 (wider rows - up to 4096 columns - only under the test
+ * hook mavlm_set_fused_layernorm(2): correct but slower than the two-kernel form), and a grid that fills the chip
  * (mavlm_linear_ln_ws_bytes > 0; 0 = this shape takes mavlm_linear(epilogue 4) + mavlm_layernorm).  The N / 256 workgroups
  * of a 224/256-row block exchange their per-row (mean, centred sum of squares) through `ws` and merge them in a fixed order;
  * the fp32 dense output never goes through HBM.  pre_out: null, or [M, N] fp32 = A . W^T + bias (what the backward needs).
- * ws: mavlm_linear_ln_ws_bytes(M,N,K) bytes, 16-B aligned, zero-filled ONCE before its first use and then left to the
- * launches of one stream (it carries a launch counter: nothing is re-zeroed per call, hipGraph replays are fine).
+ * ws: mavlm_linear_ln_ws_bytes(M,N,K) bytes, 16-B aligned, zero-filled ONCE by the caller before its first use and then
+ * left to the launches of ONE stream (it carries a launch counter: nothing is re-zeroed per call, hipGraph replays are
+ * fine; two streams need two scratches - the Python operator keeps one per (device, stream)).
  * mavlm_step uses the same kernel wherever it applies (mavlm_set_fused_layernorm(0): the two-kernel form). */
 int64_t mavlm_linear_ln_ws_bytes(int32_t M, int32_t N, int32_t K);
 int mavlm_linear_ln(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const void* res, int32_t ldr,
@@ -193,6 +219,8 @@ int mavlm_set_fused_layernorm(int32_t on);
  * workgroup gave up waiting for a partner's statistics (bounded spin; the output of that launch is then wrong): 0 after any
  * correct run - the tests and bench.py read it. */
 int64_t mavlm_workspace_ln_ctl_offset(const mavlm_config* cfg);
+/* the same for an existing context (which snapshotted the hook mavlm_set_fused_layernorm when it was created) */
+int64_t mavlm_ln_ctl_offset(const mavlm_ctx* ctx);
 /* ctx[R,H*128] = softmax(Q K^T / sqrt(128)) V per head; lse2 [H,R] fp32 optional.  MemoryController.py:51-54 */
 int mavlm_attention(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                     int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, int32_t dtype, void* stream);
@@ -320,13 +348,17 @@ int mavlm_gru_sequence(const float* xg, const void* whh, const float* bhh, void*
 /* tuning hook: 1 = attention backward computes dK and dV in ONE kernel (7 instead of 8 recompute products, 512-register
  * waves at one workgroup per CU); 0 = separate dK / dV kernels.  Same rounding points. */
 int mavlm_set_attention_bwd_fused(int32_t on);
-/* tuning hook: force the GEMM kernel (128 = 128^2 tile, 256 = 256^2 non-persistent, 257 = 256^2 persistent;
+/* tuning hook: force the GEMM kernel (128 = 128^2 tile, 129 = 128x256 tile with two workgroups per CU, 256 = 256^2
+ * non-persistent, 257 = 256^2 persistent;
  * 0 = automatic choice by grid size and epilogue).  Results are identical
  * up to fp32 summation order. */
 int mavlm_set_gemm_tile(int32_t tile);
 /* tuning hook: height of the 256-column GEMM workgroup tile - 256, 224 (= 7 x 32: divides M_tokens x 196 rows when
  * M_tokens % 8 == 0), or 0 = automatic (fewer row-rounds on 256 CUs).  Results are bit-identical. */
 int mavlm_set_gemm_rows(int32_t rows);
+/* tuning hook: tile order of the persistent GEMM for N >= 2048 (1 = 8 x 4 tile blocks per XCD, default; 0 = consecutive
+ * tiles).  Speed only. */
+int mavlm_set_gemm_order(int32_t order);
 /* tuning hook: attention forward kernel - 2 = register-staged (attention.hip), 3 = software-pipelined LDS-DMA
  * (attention3.hip), 0 = default (3).  Same rounding points; results equal up to fp32 summation order. */
 int mavlm_set_attention_impl(int32_t impl);

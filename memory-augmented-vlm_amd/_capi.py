@@ -20,7 +20,11 @@ i32 = C.c_int32
 class Config(C.Structure):
     _fields_ = [("hidden", i32), ("heads", i32), ("patches", i32), ("mem_tokens", i32), ("depth", i32),
                 ("inter", i32), ("cache_cap", i32), ("max_chunk_frames", i32), ("dtype", i32), ("eps", C.c_float),
-                ("batch", i32), ("q_token0", i32), ("q_tokens", i32)]
+                ("batch", i32), ("q_token0", i32), ("q_tokens", i32), ("fused_ln", i32)]
+
+
+LN_AUTO, LN_NEVER = 0, 1      # mavlm_config.fused_ln
+LN_MAX_STREAMS = 8            # MAVLM_LN_MAX_STREAMS: streams that may run the fused Residual kernel concurrently (include/mavlm.h)
 
 
 class AttnWeights(C.Structure):
@@ -50,6 +54,7 @@ SIGNATURES = {
     "mavlm_workspace_layout": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_size_t), i32]),
     "mavlm_bind_weights": (C.c_int, [vp, C.POINTER(Weights)]),
     "mavlm_bind_buffers": (C.c_int, [vp, C.POINTER(Buffers)]),
+    "mavlm_ln_status_async": (C.c_int, [vp, vp, i32, vp]),
     "mavlm_reset": (C.c_int, [vp]),
     "mavlm_cache_len": (C.c_int, [vp]),
     "mavlm_newest_slot": (C.c_int, [vp]),
@@ -71,6 +76,7 @@ SIGNATURES = {
                                   i32, vp]),
     "mavlm_set_fused_layernorm": (C.c_int, [i32]),
     "mavlm_workspace_ln_ctl_offset": (C.c_int64, [C.POINTER(Config)]),
+    "mavlm_ln_ctl_offset": (C.c_int64, [vp]),
     "mavlm_linear_ws_floats": (C.c_int64, [i32, i32, i32, i32, i32]),
     "mavlm_linear_ws": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, C.c_int64, i32, vp]),
     "mavlm_attention_ws_floats": (C.c_int64, [i32, i32, i32]),
@@ -101,6 +107,7 @@ SIGNATURES = {
     "mavlm_set_attention_bwd_fused": (C.c_int, [i32]),
     "mavlm_set_gemm_tile": (C.c_int, [i32]),
     "mavlm_set_gemm_rows": (C.c_int, [i32]),
+    "mavlm_set_gemm_order": (C.c_int, [i32]),
     "mavlm_set_attention_impl": (C.c_int, [i32]),
     "mavlm_attention_plan": (C.c_int, [i32, i32, i32, C.POINTER(i32)]),
     "mavlm_set_attention_streamk_min_tiles": (C.c_int, [i32]),
@@ -146,7 +153,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.mavlm_abi_version() != 2:
+        if l.mavlm_abi_version() != 3:
             raise MavlmError("libmavlm.so ABI version mismatch - rebuild")
         _lib = l
     return _lib

@@ -175,7 +175,8 @@ def layernorm(x_f32, gamma_f32, beta_f32, eps, out_dtype, out=None, residual=Non
     return out
 
 
-_LN_WS = {}
+_LN_WS = {}          # (device, stream) -> scratch of the fused dense + residual + LayerNorm operator
+_LN_WS_KEEP = []     # outgrown scratches (kept alive: captured graphs may still point at them)
 
 
 def linear_residual_layernorm(x, weight, bias_f32, residual, gamma_f32, beta_f32, eps, want_pre=False, out=None):
@@ -193,16 +194,20 @@ def linear_residual_layernorm(x, weight, bias_f32, residual, gamma_f32, beta_f32
     if nws == 0:
         pre = linear(x, weight, bias_f32, capi.EPI_F32)
         return layernorm(pre, gamma_f32, beta_f32, eps, x.dtype, out=out, residual=residual), (pre if want_pre else None)
-    # scratch with a launch counter: zero-filled ONCE per device and then reused (operator-level calls are single-stream:
-    # the training path, the tests; the fused engine has its own scratch in its workspace).  Never (re-)created inside a
-    # hipGraph capture: a replayed memset would reset the launch counter under the granules of the previous replay.
-    key = x.device.index
+    # Scratch with a launch counter: ONE per (device, stream) - the kernel's exchange assumes that the launches sharing a
+    # scratch are ordered (one stream): two streams on one scratch would read the same epoch and publish into the same
+    # granules.  Zero-filled once, then reused; never freed or shrunk (a hipGraph captured around the operator keeps the
+    # pointer it was captured with: a larger shape gets a NEW scratch, the old one stays alive in _LN_WS_KEEP).  Never
+    # created inside a capture: a replayed memset would reset the launch counter under the previous replay's granules.
+    key = (x.device.index, stream_ptr())
     ws = _LN_WS.get(key)
     if ws is None or ws.numel() < nws:
         if torch.cuda.is_current_stream_capturing():
             raise capi.MavlmError("linear_residual_layernorm: first use inside a graph capture - warm the operator up "
                                   "outside the capture (its scratch carries a launch counter)")
-        ws = _LN_WS[key] = torch.zeros(max(nws, 1 << 22), device=x.device, dtype=torch.uint8)
+        if ws is not None:
+            _LN_WS_KEEP.append(ws)
+        ws = _LN_WS[key] = torch.zeros(max(nws, 1 << 23), device=x.device, dtype=torch.uint8)
     if out is None:
         out = torch.empty((M, N), device=x.device, dtype=x.dtype)
     pre = torch.empty((M, N), device=x.device, dtype=torch.float32) if want_pre else None

@@ -255,12 +255,20 @@ static bool use_256(const mavlm_gemm_args& g) {
   // the 256^2 kernels store 16 bytes per lane (fp32: always; 16-bit: widened pairs): C rows must be 16-byte aligned
   const bool f32out = g.epilogue == MAVLM_EPI_RES_F32 || g.epilogue == MAVLM_EPI_F32;
   if (((uintptr_t)g.C & 15) || (f32out ? (g.ldc & 3) : (g.ldc & 7))) return false;
-  if (g_mavlm_gemm_tile == 256 || g_mavlm_gemm_tile == 257) return true;
+  if (g_mavlm_gemm_tile == 256 || g_mavlm_gemm_tile == 257 || g_mavlm_gemm_tile == 129) return true;
   if (g_mavlm_gemm_tile == 128) return false;
   const long tiles = (long)((g.M + 255) / 256) * (g.N / 256);
   return tiles >= 192;
 }
 
+
+// 128x256 tiles, two workgroups per CU (gemm128.hip) instead of the 256-row kernels.  Pure speed choice: every output
+// element sums its K products in the same order in all three kernels (bit-identical results).
+static bool use_128x256(const mavlm_gemm_args& g) {
+  if (!mavlm_gemm128_supported(g)) return false;
+  if (g_mavlm_gemm_tile == 129) return true;
+  return false;
+}
 
 int mavlm_gemm_splits(int M, int N, int K, int epilogue, int ldc) {
   if (M <= 0 || N % BN || K % BK || ldc != N || epilogue == MAVLM_EPI_RES_F32) return 1;
@@ -284,11 +292,12 @@ hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s)
   if (g.epilogue == MAVLM_EPI_LN) {
     // dense + residual + LayerNorm in one kernel: the non-persistent 256-column-tile kernel only (its row-block exchange
     // needs the N / 256 workgroups of a row block in flight together)
-    if (!mavlm_gemm_ln_supported(g.M, g.N, g.K) || !mavlm_gemm256_supported(g) || g.c_rpb > 0 || !g.res || (g.ldr & 3) ||
+    if (!mavlm_gemm_ln_supported(g.M, g.N, g.K, g.ln.wide) || !mavlm_gemm256_supported(g) || g.c_rpb > 0 || !g.res || (g.ldr & 3) ||
         !g.ln.gamma || !g.ln.beta || !g.ln.gran || !g.ln.ctl || ((uintptr_t)g.C & 15) || (g.ldc & 7) || (g.lda & 7) || (g.ldw & 7))
       return hipErrorInvalidValue;
     mavlm_prof_scope prof(MAVLM_K_GEMM_LN, 2.0 * g.M * (double)g.N * g.K,
                           2.0 * ((double)g.M * g.K + (double)g.N * g.K) + 4.0 * g.M * (double)g.N, s);
+    if (use_128x256(g)) return mavlm_launch_gemm128(g, dtype, s);
     return mavlm_launch_gemm256(g, dtype, s);
   }
   if (g.c_rpb > 0) {
@@ -300,6 +309,7 @@ hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s)
     const double osz = g.epilogue == MAVLM_EPI_F32 ? 4.0 : 2.0;
     mavlm_prof_scope prof(MAVLM_K_GEMM, 2.0 * g.M * (double)g.N * g.K,
                           2.0 * ((double)g.M * g.K + (double)g.N * g.K) + osz * g.M * (double)g.N, s);
+    if (use_128x256(g)) return mavlm_launch_gemm128(g, dtype, s);
     const int rows = mavlm_gemm_tile_rows(g.M, g.N);
     const long tiles = (long)((g.M + rows - 1) / rows) * (g.N / 256);
     if (tiles > 256 && mavlm_gemm256p_supported(g)) return mavlm_launch_gemm256p(g, dtype, s);
@@ -331,6 +341,7 @@ hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s)
   mavlm_prof_scope prof(MAVLM_K_GEMM, 2.0 * g.M * (double)g.N * g.K,
                         2.0 * ((double)g.M * g.K + (double)g.N * g.K) + osz * g.M * (double)g.N, s);
   if (use_256(g)) {
+    if (use_128x256(g)) return mavlm_launch_gemm128(g, dtype, s);
     // persistent kernel when workgroups get more than one tile each (its pipeline never drains between tiles);
     // with at most one tile per CU the plain kernel is the same work with less code in flight
     const int rows = mavlm_gemm_tile_rows(g.M, g.N);

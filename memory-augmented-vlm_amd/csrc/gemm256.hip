@@ -399,9 +399,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   // ---- epilogue: lane holds C[m][n..n+3], m = m0 + wm*MHALF + 16 i + fr, n = n0 + wn*64 + 16 j + 4 fq.
   // 16-bit outputs: column blocks (j, j+1) are exchanged between lane groups (widen_pair) so that every lane stores
   // 16 contiguous bytes - half the store instructions, 64-byte instead of 32-byte row segments.
-  auto act = [&](float v) {
-    if (EPI == MAVLM_EPI_RELU) return fmaxf(v, 0.f);
-    if (EPI == MAVLM_EPI_GELU) return gelu_erf_fast(v);
+  auto act4 = [&](f32x4 v) -> f32x4 {
+    if (EPI == MAVLM_EPI_RELU) return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+    if (EPI == MAVLM_EPI_GELU) return gelu_erf_fast4(v);      // packed fp32 math (mavlm_common.h)
     return v;
   };
   // element offset of output row m.  Row-batched outputs (mavlm_gemm_args::c_rpb): block q = m / c_rpb of c_rpb rows goes
@@ -434,8 +434,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
 #pragma unroll
       for (int j = 0; j < 4; j += 2) {                     // (all lanes take part in the swaps; the store is masked)
         const f32x4 x = acc[i][j] + bv[j], y = acc[i][j + 1] + bv[j + 1];
-        const u32x4 w = widen_pair(pack4<T>(act(x[0]), act(x[1]), act(x[2]), act(x[3])),
-                                   pack4<T>(act(y[0]), act(y[1]), act(y[2]), act(y[3])));
+        const f32x4 xa = act4(x), ya = act4(y);
+        const u32x4 w = widen_pair(pack4<T>(xa[0], xa[1], xa[2], xa[3]), pack4<T>(ya[0], ya[1], ya[2], ya[3]));
         const int n = n0 + wn * 64 + 16 * (j + (fq & 1)) + 8 * (fq >> 1);
         if (m < M) *(u32x4*)((uint16_t*)Cout + co + n) = w;
       }
@@ -484,12 +484,13 @@ int g_mavlm_gemm_ln_wide = 0;     // test hook (mavlm_set_fused_layernorm(2)): a
 // through `gran`.  Scratch: 64 bytes of control words (arrivals, launch counter, timeout flag; FIRST, so that their place does
 // not depend on the shape: a scratch reused for another shape keeps counting epochs upward) + [ceil(M / rows)][N / 256][256][2]
 // 8-byte granules - zero-filled ONCE before the first launch, then owned by the launches of ONE stream.
-bool mavlm_gemm_ln_supported(int M, int N, int K) {
+bool mavlm_gemm_ln_supported(int M, int N, int K, int wide) {
+  if (wide < 0) wide = g_mavlm_gemm_ln_wide;
   // N <= 1024: up to 4 partners per row block.  The kernel is correct for up to 16 (N = 3584 is tested through
   // mavlm_set_fused_layernorm(2)), but with 14 partners every thread polls 11 granules one after the other and the row
   // blocks of a grid larger than the chip straddle its rounds (workgroups spin on CUs their partners are waiting for):
   // measured 730 TFLOP/s against 1 290 for the plain GEMM at the OneVision-7B width - the two-kernel form wins there.
-  if (M <= 0 || N % BN2 != 0 || N / BN2 > (g_mavlm_gemm_ln_wide ? 16 : 4) || N / BN2 < 1 || K % BK2 != 0 || K <= 0) return false;
+  if (M <= 0 || N % BN2 != 0 || N / BN2 > (wide ? 16 : 4) || N / BN2 < 1 || K % BK2 != 0 || K <= 0) return false;
   // (the same "fills the chip" rule as the plain 256-column-tile kernels: below it the 128-tile / split-K kernels + the
   // row LayerNorm kernel are faster)
   return (long)((M + 255) / 256) * (N / BN2) >= 192;

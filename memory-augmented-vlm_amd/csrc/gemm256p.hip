@@ -36,6 +36,8 @@
 #include "mavlm_common.h"
 #include "mavlm_kernels.h"
 
+extern int g_mavlm_gemm_order;
+
 namespace {
 
 constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
                                                           const uint16_t* __restrict__ W, int ldw,
                                                           const float* __restrict__ bias, void* __restrict__ Cout,
                                                           int ldc, int M, int N, int K, int total_tiles, int c_rpb,
-                                                          int c_nb, long long c_bs) {
+                                                          int c_nb, long long c_bs, int g_order) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -90,8 +92,21 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
   int m0c = 0, n0c = 0;
   auto tile_origin = [&](int it, int& m0, int& n0) {
     int lin = (int)blockIdx.x + it * G;
-    // XCD-aware order inside every full window of G tiles (blocks b, b+8 share an XCD)
-    if ((it + 1) * G <= total_tiles && (G & 7) == 0) lin = it * G + xcd_remap((int)blockIdx.x, G);
+    // XCD-aware order inside every full window of G tiles (blocks b, b+8 share an XCD): the 32 tiles an XCD works on at a
+    // time should share operands through its L2.  N = 1024 (4 column tiles): 32 consecutive tiles = 8 row blocks x 4 column
+    // tiles.  N = 4096 (round 4): a window of 256 tiles is 16 row blocks x 16 column tiles; an XCD takes an
+    // 8 x 4 block of it instead of 2 x 16 consecutive tiles - per K-tile its 32 workgroups stage 8 A + 4 B
+    // half-operands from L2 instead of 2 + 16 (measured +0.7 ... +1.8 %; the 4 x 8 form of N = 2048 measured -1 %: not taken).
+    // Speed only: any bijection of the window is correct.
+    if ((it + 1) * G <= total_tiles && (G & 7) == 0) {
+      if (g_order == 1 && G == 256 && ntn == 16) {
+        const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;       // XCD label, index inside the XCD (0..31)
+        const int xc = x % (ntn >> 2), xr = x / (ntn >> 2);
+        lin = it * G + (xr * 8 + (j >> 2)) * ntn + xc * 4 + (j & 3);
+      } else {
+        lin = it * G + xcd_remap((int)blockIdx.x, G);
+      }
+    }
     m0 = (lin / ntn) * BMT;
     n0 = (lin % ntn) * BN2;
   };
@@ -244,9 +259,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
     f32x4 bv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(bl + j * 16);
-    auto act = [&](float v) {
-      if (EPI == MAVLM_EPI_RELU) return fmaxf(v, 0.f);
-      if (EPI == MAVLM_EPI_GELU) return gelu_erf_fast(v);
+      auto act4 = [&](f32x4 v) -> f32x4 {
+      if (EPI == MAVLM_EPI_RELU) return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+      if (EPI == MAVLM_EPI_GELU) return gelu_erf_fast4(v);      // packed fp32 math (mavlm_common.h)
       return v;
     };
     // element offset of output row m; row-batched outputs: see gemm256_kernel / mavlm_gemm_args::c_rpb
@@ -273,8 +288,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const uint16_t* __rest
           const f32x4 x = acc[i][j] + bv[j], y = acc[i][j + 1] + bv[j + 1];
           acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
           acc[i][j + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-          const u32x4 w = widen_pair(pack4<T>(act(x[0]), act(x[1]), act(x[2]), act(x[3])),
-                                     pack4<T>(act(y[0]), act(y[1]), act(y[2]), act(y[3])));
+          const f32x4 xa = act4(x), ya = act4(y);
+          const u32x4 w = widen_pair(pack4<T>(xa[0], xa[1], xa[2], xa[3]), pack4<T>(ya[0], ya[1], ya[2], ya[3]));
           const int n = n0c + wn * 64 + 16 * (j + (fq & 1)) + 8 * (fq >> 1);
           if (m < M) *(u32x4*)((uint16_t*)Cout + co + n) = w;
         }
@@ -318,7 +333,8 @@ hipError_t launch256ph(const mavlm_gemm_args& g, hipStream_t s) {
   const int tiles = ((g.M + BMT - 1) / BMT) * (g.N / BN2);
   const int grid = tiles < cus ? tiles : cus;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), GEMM256P_LDS, s, (const uint16_t*)g.A, g.lda, (const uint16_t*)g.W,
-                     g.ldw, g.bias, g.C, g.ldc, g.M, g.N, g.K, tiles, g.c_rpb, g.c_nb > 0 ? g.c_nb : 1, (long long)g.c_bstride);
+                     g.ldw, g.bias, g.C, g.ldc, g.M, g.N, g.K, tiles, g.c_rpb, g.c_nb > 0 ? g.c_nb : 1, (long long)g.c_bstride,
+                     g_mavlm_gemm_order);
   return hipGetLastError();
 }
 
@@ -328,6 +344,8 @@ hipError_t launch256p(const mavlm_gemm_args& g, hipStream_t s) {
 }
 
 }  // namespace
+
+int g_mavlm_gemm_order = 1;     // tuning hook: 1 = 8 x 4 tile blocks per XCD for N >= 2048 (persistent kernel), 0 = consecutive tiles
 
 // persistent kernel: bias / ReLU / GELU / fp32-out epilogues (no residual: see the header), K >= 128,
 // operands addressable with 32-bit element offsets

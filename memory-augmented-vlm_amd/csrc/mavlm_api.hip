@@ -21,8 +21,14 @@ struct mavlm_ctx {
   size_t o_lnx = 0, lnx_bytes = 0; // scratch of the fused dense + residual + LayerNorm GEMM epilogue (0 = not used for this config)
   const void* pre_seg = nullptr;   // mavlm_project_chunk: the chunk whose K/V already sit in the workspace (0 = none)
   int pre_F = 0;
+  void* pre_stream = nullptr;      // ... and the stream the projection was enqueued on (mavlm_step must use the same one)
   int fuse_mems = 1;   // cached memories the Memory-Fuser MLP takes per GEMM launch (mavlm_fuse_emit)
+  int fused_ln = 1;    // snapshot of the process-wide hook at mavlm_create (0 = two-kernel form, 1 / 2 = fused where supported)
+  int ln_wide = 0;     // ... and of its "rows of up to 4096 columns" test mode
+  bool lnx_clean = false;   // the exchange scratch of this workspace has been zero-filled since the last mavlm_bind_buffers
 };
+
+int g_mavlm_fused_ln = 1;   // process-wide hook (mavlm_set_fused_layernorm); contexts snapshot it at mavlm_create
 
 namespace {
 
@@ -38,6 +44,7 @@ bool cfg_ok(const mavlm_config* c) {
   if (c->q_tokens < 0 || c->q_token0 < 0 || c->q_token0 + c->q_tokens > c->mem_tokens || (c->q_tokens == 0 && c->q_token0 != 0))
     return false;
   if (c->q_tokens > 0 && c->batch > 1) return false;           // a row shard of ONE video, or a row batch of whole videos
+  if (c->fused_ln != MAVLM_LN_AUTO && c->fused_ln != MAVLM_LN_NEVER) return false;
   return true;
 }
 inline int nbatch(const mavlm_config& c) { return c.batch > 1 ? c.batch : 1; }
@@ -152,10 +159,13 @@ void carve(mavlm_ctx* x) {
   // blocks + control words.  MUST be zero when the workspace is bound (mavlm_buffers.workspace).
   x->o_lnx = 0;
   x->lnx_bytes = 0;
-  {
+  // the process-wide hook is SNAPSHOTTED here (carve runs once per context, at mavlm_create): a live context keeps its form
+  x->fused_ln = c.fused_ln == MAVLM_LN_NEVER ? 0 : g_mavlm_fused_ln;
+  x->ln_wide = g_mavlm_gemm_ln_wide;
+  if (x->fused_ln) {
     const int rows_[2] = {(int)R, (int)(R1 * B)};
     for (int r : rows_)
-      if (mavlm_gemm_ln_supported(r, (int)D, (int)Dp) || mavlm_gemm_ln_supported(r, (int)D, (int)I)) {
+      if (mavlm_gemm_ln_supported(r, (int)D, (int)Dp, x->ln_wide) || mavlm_gemm_ln_supported(r, (int)D, (int)I, x->ln_wide)) {
         const size_t b = mavlm_gemm_ln_ws_bytes(r, (int)D);
         if (b > x->lnx_bytes) x->lnx_bytes = b;
       }
@@ -195,15 +205,23 @@ inline hipError_t gemm_x(mavlm_ctx* x, hipStream_t s, const void* A, int lda, co
 // 256-column-tile GEMM fills the chip (EPI_LN: the fp32 dense output never goes through HBM), else the GEMM with its
 // fp32 epilogue + the row LayerNorm kernel.  Same fp32 values into the normalisation either way; the two forms add the
 // row statistics in different orders (a pure function of the shape which one runs: mavlm_linear_ln_fused).
-int g_mavlm_fused_ln = 1;
 int dense_ln(mavlm_ctx* x, hipStream_t s, const void* A, int lda, const void* W, int ldw, const float* bias, const void* res,
              const float* gamma, const float* beta, void* out, int rows, int N, int K) {
   const mavlm_config& c = x->cfg;
-  if (g_mavlm_fused_ln && x->lnx_bytes && mavlm_gemm_ln_supported(rows, N, K) && mavlm_gemm_ln_ws_bytes(rows, N) <= x->lnx_bytes) {
+  if (x->fused_ln && x->lnx_bytes && mavlm_gemm_ln_supported(rows, N, K, x->ln_wide) && mavlm_gemm_ln_ws_bytes(rows, N) <= x->lnx_bytes) {
+    if (!x->lnx_clean) {
+      // the library owns the "zero before the first launch" invariant of the exchange scratch: one asynchronous memset on
+      // the stream of the first step after mavlm_bind_buffers.  Not inside a capture: a replayed memset would reset the
+      // launch counter under the granules of the previous replay.
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return MAVLM_E_STATE;
+      MAVLM_TRY(hipMemsetAsync(ws(x, x->o_lnx), 0, x->lnx_bytes, s));
+      x->lnx_clean = true;
+    }
     mavlm_gemm_args g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.res = res; g.ldr = N; g.C = out; g.ldc = N;
     g.M = rows; g.N = N; g.K = K; g.epilogue = MAVLM_EPI_LN;
-    g.ln.gamma = gamma; g.ln.beta = beta; g.ln.eps = c.eps;
+    g.ln.gamma = gamma; g.ln.beta = beta; g.ln.eps = c.eps; g.ln.wide = x->ln_wide;
     // (control words FIRST: their place must not depend on the shape - the launch counter is what keeps epochs unique)
     g.ln.ctl = (unsigned*)ws(x, x->o_lnx);
     g.ln.gran = (unsigned long long*)(ws(x, x->o_lnx) + 64);
@@ -311,7 +329,7 @@ int step_impl(mavlm_ctx* x, const void* const* segs, int32_t F, void* frame_scor
   // does not depend on the memory rows: nothing to gain from stacking, and the videos' frames stay where they are)
   char* kvs = ws(x, x->o_kv);
   const int ldkv = 2 * L * Dp;
-  const bool pre = B == 1 && x->pre_seg == segs[0] && x->pre_F == F;       // mavlm_project_chunk ran for exactly this chunk
+  const bool pre = B == 1 && x->pre_seg == segs[0] && x->pre_F == F && x->pre_stream == (void*)s;       // mavlm_project_chunk ran for exactly this chunk
   x->pre_seg = nullptr;
   x->pre_F = 0;
   for (int b = 0; b < B && !pre; ++b)
@@ -384,7 +402,7 @@ int mavlm_set_attention_bwd_fused(int32_t on) {
 }
 
 int mavlm_set_gemm_tile(int32_t tile) {
-  if (tile != 0 && tile != 128 && tile != 256 && tile != 257) return MAVLM_E_ARG;
+  if (tile != 0 && tile != 128 && tile != 129 && tile != 256 && tile != 257) return MAVLM_E_ARG;
   g_mavlm_gemm_tile = tile;
   return 0;
 }
@@ -434,7 +452,7 @@ int mavlm_set_fused_layernorm(int32_t on) {
 }
 
 int64_t mavlm_linear_ln_ws_bytes(int32_t M, int32_t N, int32_t K) {
-  return (g_mavlm_fused_ln && mavlm_gemm_ln_supported(M, N, K)) ? (int64_t)mavlm_gemm_ln_ws_bytes(M, N) : 0;
+  return (g_mavlm_fused_ln && mavlm_gemm_ln_supported(M, N, K, -1)) ? (int64_t)mavlm_gemm_ln_ws_bytes(M, N) : 0;
 }
 
 int mavlm_linear_ln(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const void* res, int32_t ldr,
@@ -452,6 +470,13 @@ int mavlm_linear_ln(const void* A, int32_t lda, const void* W, int32_t ldw, cons
   g.ln.gran = (unsigned long long*)((char*)ws_ + 64);
   hipError_t e = mavlm_launch_gemm(g, dtype, (hipStream_t)stream);
   return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
+extern int g_mavlm_gemm_order;
+int mavlm_set_gemm_order(int32_t order) {
+  if (order != 0 && order != 1) return MAVLM_E_ARG;
+  g_mavlm_gemm_order = order;
+  return 0;
 }
 
 int mavlm_set_gemm_rows(int32_t rows) {
@@ -475,6 +500,8 @@ int64_t mavlm_workspace_ln_ctl_offset(const mavlm_config* cfg) {
   carve(&t);
   return t.lnx_bytes ? (int64_t)t.o_lnx : -1;
 }
+
+int64_t mavlm_ln_ctl_offset(const mavlm_ctx* x) { return x ? (x->lnx_bytes ? (int64_t)x->o_lnx : -1) : MAVLM_E_ARG; }
 
 int mavlm_workspace_layout(const mavlm_config* cfg, size_t* offsets, int32_t n) {
   if (!cfg_ok(cfg) || !offsets || n < 10) return MAVLM_E_ARG;
@@ -513,6 +540,8 @@ int mavlm_bind_weights(mavlm_ctx* x, const mavlm_weights* w) {
       return MAVLM_E_ARG;
   }
   x->w = *w;
+  x->pre_seg = nullptr;            // K/V projected with the previous weights are not this context's any more
+  x->pre_F = 0;
   x->has_w = true;
   return 0;
 }
@@ -522,6 +551,19 @@ int mavlm_bind_buffers(mavlm_ctx* x, const mavlm_buffers* b) {
   if (b->workspace_bytes < x->total || ((uintptr_t)b->workspace & 255)) return MAVLM_E_ARG;
   x->b = *b;
   x->has_b = true;
+  x->lnx_clean = false;            // a new workspace: its exchange scratch is zero-filled at the first step
+  x->pre_seg = nullptr;            // (a prefetched projection lived in the old workspace)
+  x->pre_F = 0;
+  return 0;
+}
+
+int mavlm_ln_status_async(mavlm_ctx* x, void* host16, int32_t clear, void* stream) {
+  if (!x || !host16) return MAVLM_E_ARG;
+  if (!x->has_b) return MAVLM_E_STATE;
+  if (!x->lnx_bytes || !x->lnx_clean) return 1;       // never fused / nothing launched yet: nothing to report
+  hipStream_t s = (hipStream_t)stream;
+  MAVLM_TRY(hipMemcpyAsync(host16, ws(x, x->o_lnx), 16, hipMemcpyDeviceToHost, s));
+  if (clear) MAVLM_TRY(hipMemsetAsync(ws(x, x->o_lnx) + 8, 0, 4, s));
   return 0;
 }
 
@@ -571,6 +613,7 @@ int mavlm_project_chunk(mavlm_ctx* x, const void* seg, int32_t F, void* stream) 
   MAVLM_TRY(gemm_x(x, (hipStream_t)stream, seg, D, x->w.w_kv_seg, D, x->w.b_kv_seg, ws(x, x->o_kv), ldkv, S, ldkv, D, MAVLM_EPI_BIAS));
   x->pre_seg = seg;
   x->pre_F = F;
+  x->pre_stream = stream;
   return 0;
 }
 

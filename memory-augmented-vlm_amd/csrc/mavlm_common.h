@@ -26,6 +26,7 @@ struct mavlm_per_device_once {
 
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -83,7 +84,6 @@ struct F16 {
   }
 };
 
-typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
@@ -137,15 +137,51 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // GELU(x) = x * Phi(x) with the exact-erf definition (nn.GELU() default, llava_arch.py:134).  Phi through the
-// complementary error function in Abramowitz-Stegun 7.1.26 form, erfc(a) ~ (a1 t + ... + a5 t^5) exp(-a^2),
-// t = 1/(1 + p a): |erf error| <= 6e-7 in fp32, |GELU error| <= 3e-7 absolute (checked against float64 on a dense
-// grid) - four orders below the 16-bit output grid - at ~12 VALU instead of libm erff's ~40.
+// complementary error function in Abramowitz-Stegun 7.1.26 form, q = 0.5 erfc(a) ~ 0.5 (a1 t + ... + a5 t^5) exp(-a^2),
+// a = |x| / sqrt2, t = 1/(1 + p a): |erf error| <= 6e-7 in fp32, |GELU error| <= 3.5e-7 absolute (checked against float64 on a
+// dense grid, |x| <= 8) - four orders below the 16-bit output grid.  GELU(x) = max(x, 0) - |x| q (x < 0: x q; x >= 0: x - x q): no
+// compare / select.  Round 4: constants folded so that the whole evaluation is 2 transcendentals (rcp, exp2) + 9 fma / mul
+// + abs + max, written with explicit fma so that the scalar form and the PACKED form (two values per v_pk_fma_f32 /
+// v_pk_mul_f32: the epilogues are VALU-bound, packed math halves the non-transcendental part) give the same bits:
+//   a' = |x| k, k = sqrt(log2(e) / 2)  ->  exp(-a^2) = exp2(-a'^2);  t = 1 / (1 + (p / sqrt(log2 e)) a');
+//   q' = q / k = t (b1 + t (b2 + ...)) exp2(-a'^2), b_i = 0.5 a_i / k;  GELU = fma(-a', q', max(x, 0)).
+#define MAVLM_GELU_K 0.8493218002880191f        /* sqrt(log2(e) / 2) */
+#define MAVLM_GELU_P 0.2727374808792225f        /* 0.3275911 / sqrt(log2 e) */
+#define MAVLM_GELU_B1 0.1500194578271646f          /* 0.5 * 0.254829592 / k */
+#define MAVLM_GELU_B2 (-0.1674846541696695f)       /* 0.5 * -0.284496736 / k */
+#define MAVLM_GELU_B3 0.8367933923973075f          /* 0.5 * 1.421413741 / k */
+#define MAVLM_GELU_B4 (-0.8554778804142388f)       /* 0.5 * -1.453152027 / k */
+#define MAVLM_GELU_B5 0.6248546950284685f          /* 0.5 * 1.061405429 / k */
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-  const float a = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * a);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float q = 0.5f * poly * __builtin_amdgcn_exp2f(-a * a * 1.44269504088896340736f);   // 0.5*erfc(|x|/sqrt2)
-  return x * (x < 0.f ? q : 1.0f - q);
+  const float a = fabsf(x) * MAVLM_GELU_K;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(a, MAVLM_GELU_P, 1.0f));
+  float p = __builtin_fmaf(t, MAVLM_GELU_B5, MAVLM_GELU_B4);
+  p = __builtin_fmaf(t, p, MAVLM_GELU_B3);
+  p = __builtin_fmaf(t, p, MAVLM_GELU_B2);
+  p = __builtin_fmaf(t, p, MAVLM_GELU_B1);
+  p = t * p;
+  const float e = __builtin_amdgcn_exp2f(-(a * a));
+  return __builtin_fmaf(-a, p * e, fmaxf(x, 0.f));
+}
+// the same, two values per instruction (bit-identical per element to gelu_erf_fast)
+__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
+  const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+  const f32x2 a = ax * MAVLM_GELU_K;
+  const f32x2 d = __builtin_elementwise_fma(a, (f32x2)(MAVLM_GELU_P), (f32x2)(1.0f));
+  const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  f32x2 p = __builtin_elementwise_fma(t, (f32x2)(MAVLM_GELU_B5), (f32x2)(MAVLM_GELU_B4));
+  p = __builtin_elementwise_fma(t, p, (f32x2)(MAVLM_GELU_B3));
+  p = __builtin_elementwise_fma(t, p, (f32x2)(MAVLM_GELU_B2));
+  p = __builtin_elementwise_fma(t, p, (f32x2)(MAVLM_GELU_B1));
+  p = t * p;
+  const f32x2 na2 = -(a * a);
+  const f32x2 e = {__builtin_amdgcn_exp2f(na2[0]), __builtin_amdgcn_exp2f(na2[1])};
+  const f32x2 r = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+  return __builtin_elementwise_fma(-a, p * e, r);
+}
+__device__ __forceinline__ f32x4 gelu_erf_fast4(f32x4 x) {
+  const f32x2 lo = gelu_erf_fast2(f32x2{x[0], x[1]}), hi = gelu_erf_fast2(f32x2{x[2], x[3]});
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
 // Widened 16-bit epilogue store (after cdna_hip_programming.md T21, with the 16-lane-row swap):

@@ -15,6 +15,7 @@ struct mavlm_ln_epilogue {
   unsigned long long* gran = nullptr;   // [row blocks][N/256][256][2] {epoch, value} granules
   unsigned* ctl = nullptr;              // {arrivals of this launch, launch counter, timeout flag, -}
   float* pre_out = nullptr;             // optional [M, N] fp32: dense + bias (before the residual), for the training path
+  int wide = -1;                        // mavlm_gemm_ln_supported's `wide` of the caller (a context's snapshot; -1 = the hook)
 };
 
 struct mavlm_gemm_args {
@@ -34,7 +35,8 @@ struct mavlm_gemm_args {
   long long c_bstride = 0;
   mavlm_ln_epilogue ln;          // EPI_LN only
 };
-bool mavlm_gemm_ln_supported(int M, int N, int K);
+// wide: 1 = rows of up to 4096 columns (test mode), 0 = up to 1024, -1 = the process-wide hook g_mavlm_gemm_ln_wide
+bool mavlm_gemm_ln_supported(int M, int N, int K, int wide = -1);
 extern int g_mavlm_gemm_ln_wide;
 size_t mavlm_gemm_ln_ws_bytes(int M, int N);
 hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s);
@@ -48,10 +50,13 @@ hipError_t mavlm_launch_gemm256(const mavlm_gemm_args& g, int dtype, hipStream_t
 // persistent 256x256x64 kernel (gemm256p.hip): no residual epilogue, K >= 128
 bool mavlm_gemm256p_supported(const mavlm_gemm_args& g);
 hipError_t mavlm_launch_gemm256p(const mavlm_gemm_args& g, int dtype, hipStream_t s);
+// 128x256x64 4-wave kernel, two workgroups per CU (gemm128.hip): all epilogues incl. EPI_LN and row-batched outputs
+bool mavlm_gemm128_supported(const mavlm_gemm_args& g);
+hipError_t mavlm_launch_gemm128(const mavlm_gemm_args& g, int dtype, hipStream_t s);
 // split-K form for the long contractions of the backward (gemm.hip); ws = [splits][M][N] fp32, ldc must equal N
 hipError_t mavlm_launch_gemm_splitk(const mavlm_gemm_args& g, int splits, float* ws, const float* zero_bias, int dtype,
                                     hipStream_t s);
-extern int g_mavlm_gemm_tile;   // 0 = auto, 128 / 256 = forced non-persistent, 257 = forced persistent (tuning hook)
+extern int g_mavlm_gemm_tile;   // 0 = auto, 128 / 256 = forced non-persistent, 257 = forced persistent, 129 = forced 128x256 two-per-CU (tuning hook)
 // height of the 256-column workgroup tile for an M x N output: 256 or 224 rows (gemm256.hip); same results either way
 int mavlm_gemm_tile_rows(int M, int N);
 extern int g_mavlm_gemm_rows;   // 0 = auto, 224 / 256 = forced (tuning hook)

@@ -321,9 +321,17 @@ class MemoryPathPool:
     def __init__(self, model, n: int = 2, batch: int = 1):
         rm = model.recurrent_memory_transformer
         self.model = model
-        self.slots = [model] + [_ReplicaView(model, rm.spawn_replica()) for _ in range(n - 1)]
+        # More than LN_MAX_STREAMS streams: the forward-progress argument of the fused dense + residual + LayerNorm kernel
+        # (waiting workgroups per XCD, include/mavlm.h MAVLM_LN_MAX_STREAMS) no longer covers the pool - every slot of such
+        # a pool runs the two-kernel form (GEMM + row LayerNorm; same fp32 inputs, statistics added in another order), on
+        # recurrent states of its own (the model's own engine keeps the fused form for serial use).
+        self.fused_ln_never = n > capi.LN_MAX_STREAMS
+        if self.fused_ln_never:
+            self.slots = [_ReplicaView(model, rm.spawn_replica(fused_ln_never=True)) for _ in range(n)]
+        else:
+            self.slots = [model] + [_ReplicaView(model, rm.spawn_replica()) for _ in range(n - 1)]
         self.batch = int(batch)
-        self.bslots = [BatchedProjector(rm, self.batch) for _ in range(n)] if self.batch > 1 else []
+        self.bslots = [BatchedProjector(rm, self.batch, fused_ln_never=self.fused_ln_never) for _ in range(n)] if self.batch > 1 else []
         self.streams = None
 
     @torch.no_grad()           # inference feature: the replicas' FIFOs are ring views, not autograd tensors

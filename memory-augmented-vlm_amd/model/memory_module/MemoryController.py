@@ -154,7 +154,8 @@ class TransformerLayer(nn.Module):
 class _Engine:
     """Owns the C handle, the packed parameter views and the device buffers of one TransformerProjector."""
 
-    def __init__(self, proj: "TransformerProjector", device, dtype, max_chunk_frames, batch: int = 1, shard=None):
+    def __init__(self, proj: "TransformerProjector", device, dtype, max_chunk_frames, batch: int = 1, shard=None,
+                 fused_ln_never: bool = False):
         cfg = proj.config
         self.device, self.dtype = device, dtype
         self.batch = int(batch)
@@ -163,7 +164,8 @@ class _Engine:
                              mem_tokens=cfg.num_memory_tokens, depth=cfg.depth, inter=cfg.mm_intermediate_size,
                              cache_cap=getattr(cfg, "cache_cap", 10), max_chunk_frames=max_chunk_frames,
                              dtype=ops.dtype_code(dtype), eps=cfg.mm_layer_norm_eps, batch=self.batch,
-                             q_token0=self.shard[0] if self.shard else 0, q_tokens=self.shard[1] if self.shard else 0)
+                             q_token0=self.shard[0] if self.shard else 0, q_tokens=self.shard[1] if self.shard else 0,
+                             fused_ln=capi.LN_NEVER if fused_ln_never else capi.LN_AUTO)
         lib = capi.lib()
         h = capi.vp()
         capi.check(lib.mavlm_create(self.c, h), "mavlm_create")
@@ -181,8 +183,8 @@ class _Engine:
             self.mem_ring = torch.empty((self.c.cache_cap, self.c.mem_tokens, self.c.patches, D), device=device, dtype=dtype)
             self.evo_kv = torch.empty((self.c.cache_cap, R, 2 * self.Dp), device=device, dtype=dtype)
         nbytes = lib.mavlm_workspace_bytes(self.c)
-        # zero-filled: the workspace carries the launch counter / exchange granules of the fused LayerNorm epilogue (mavlm.h)
-        self.workspace = torch.zeros(nbytes + 256, device=device, dtype=torch.uint8)
+        # (the exchange scratch of the fused LayerNorm epilogue inside it is zero-filled by the library at the first step)
+        self.workspace = torch.empty(nbytes + 256, device=device, dtype=torch.uint8)
         base = (self.workspace.data_ptr() + 255) & ~255
         self.workspace_base_offset = base - self.workspace.data_ptr()
         b = capi.Buffers(mem_ring=self.mem_ring.data_ptr(), evo_kv_ring=self.evo_kv.data_ptr(), workspace=base,
@@ -190,6 +192,44 @@ class _Engine:
         capi.check(lib.mavlm_bind_buffers(self.ctx, b), "mavlm_bind_buffers")
         self.keep = {}
         self.version = None
+        self._probe = None            # pinned host copy of the exchange control words (mavlm_ln_status_async)
+        self._probe_evt = None
+        self.ln_timeouts_seen = 0
+
+    # -- health of the fused Residual kernel's exchange (include/mavlm.h: MAVLM_LN_MAX_STREAMS) ----------------------------
+    def check_ln_probe(self, wait: bool = False):
+        """Looks at the last posted probe if its copy has landed (never blocks unless `wait`); raises MavlmError when a launch
+        of the fused dense + residual + LayerNorm kernel gave up waiting for a partner workgroup since the probe before."""
+        evt = self._probe_evt
+        if evt is None:
+            return
+        if wait:
+            evt.synchronize()
+        elif not evt.query():
+            return
+        self._probe_evt = None
+        t = int(self._probe[2])
+        if t:
+            self.ln_timeouts_seen += t
+            raise capi.MavlmError("fused dense + residual + LayerNorm kernel: a workgroup timed out waiting for its row block's "
+                                  "partners - the memory computed since the previous video is wrong (more than "
+                                  f"{capi.LN_MAX_STREAMS} streams on the fused form, or a stalled device); the flag has been "
+                                  "cleared, re-run the video")
+
+    def post_ln_probe(self):
+        """One asynchronous 16-byte read of the control words per video (called at `memory_cache = []`), checked at the next
+        one: the product path notices a timed-out exchange without ever synchronising."""
+        self.check_ln_probe()
+        if self._probe_evt is not None or torch.cuda.is_current_stream_capturing():
+            return                                        # previous copy still in flight / never inside a graph capture
+        if self._probe is None:
+            self._probe = torch.zeros(4, dtype=torch.int32).pin_memory()
+        rc = capi.lib().mavlm_ln_status_async(self.ctx, self._probe.data_ptr(), 1, ops.stream_ptr())
+        if rc == 0:
+            self._probe_evt = torch.cuda.Event()
+            self._probe_evt.record()
+        elif rc < 0:
+            capi.check(rc, "mavlm_ln_status_async")
 
     def __del__(self):
         try:
@@ -279,11 +319,15 @@ class _Engine:
         """(launches, timeouts) of the fused dense + residual + LayerNorm epilogue in this engine's workspace, or None when the
         config never takes the fused form.  timeouts != 0: a workgroup gave up waiting for a partner (bounded spin) and the
         result of that launch is wrong - never seen; the tests and bench.py assert 0.  Synchronises (a D2H read)."""
-        off = int(capi.lib().mavlm_workspace_ln_ctl_offset(self.c))
+        off = int(capi.lib().mavlm_ln_ctl_offset(self.ctx))
         if off < 0:
             return None
         w = self.workspace[self.workspace_base_offset + off:self.workspace_base_offset + off + 16].view(torch.int32).cpu()
-        return int(w[1]), int(w[2])
+        if self._probe_evt is not None:                   # a posted probe clears the device flag: fold it in
+            self._probe_evt.synchronize()
+            self._probe_evt = None
+            self.ln_timeouts_seen += int(self._probe[2])
+        return int(w[1]), int(w[2]) + self.ln_timeouts_seen
 
     def workspace_views(self):
         """Typed views of the workspace regions (contents = intermediates of the most recent sub-layer).  For the
@@ -376,6 +420,7 @@ class TransformerProjector(nn.Module):
             capi.check(capi.lib().mavlm_reset(self._engine.ctx), "mavlm_reset")
             if self._weights_maybe_stale():
                 self._engine.version = None          # re-pack on the first step of this video
+            self._engine.post_ln_probe()             # raises if the previous videos' fused LayerNorm exchange timed out
 
     def train(self, mode: bool = True):
         st = self.__dict__.get("_train_state")
@@ -414,7 +459,7 @@ class TransformerProjector(nn.Module):
         if e is None or e.device != device or e.dtype != dtype or e.c.max_chunk_frames < need:
             if e is not None and e.steps:
                 raise capi.MavlmError("device / dtype / chunk size changed in the middle of a video")
-            e = self._engine = _Engine(self, device, dtype, need)
+            e = self._engine = _Engine(self, device, dtype, need, fused_ln_never=self._fused_ln_never)
             self._memory_cache = []
         v = self._param_version()
         if e.version != v:
@@ -436,7 +481,9 @@ class TransformerProjector(nn.Module):
             self._evo_kv = []
         return out
 
-    def spawn_replica(self) -> "TransformerProjector":
+    _fused_ln_never = False       # replicas of a pool with more than LN_MAX_STREAMS streams: GEMM + row LayerNorm kernels only
+
+    def spawn_replica(self, fused_ln_never: bool = False) -> "TransformerProjector":
         """A second recurrent state over the SAME parameters: shares every Parameter / sub-module object with this
         module (no weight copy) but owns its own engine, FIFO ring and workspace.  Used to keep several videos in
         flight on different HIP streams (MemoryPathPool in llava_arch.py): one video's partial-wave kernel tails
@@ -447,6 +494,7 @@ class TransformerProjector(nn.Module):
         r._memory_cache = []
         r._evo_kv = []
         r.frame_attn_scores = []
+        r._fused_ln_never = bool(fused_ln_never)
         return r
 
     # -- forward -----------------------------------------------------------------------------------------
@@ -554,7 +602,8 @@ class BatchedProjector:
     Inference only (no autograd path).  Same kernels and rounding points as the single-video engine; the attention's fp32
     summation order follows the schedule of the stacked grid."""
 
-    def __init__(self, proj: TransformerProjector, batch: int):
+    def __init__(self, proj: TransformerProjector, batch: int, fused_ln_never: bool = False):
+        self.fused_ln_never = bool(fused_ln_never)
         if batch < 2:
             raise capi.MavlmError("BatchedProjector: batch >= 2 (a single video runs through TransformerProjector itself)")
         self.proj, self.batch = proj, int(batch)
@@ -570,7 +619,7 @@ class BatchedProjector:
         if e is None or e.device != device or e.dtype != dtype or e.c.max_chunk_frames < need:
             if e is not None and e.steps:
                 raise capi.MavlmError("device / dtype / chunk size changed in the middle of a video batch")
-            e = self._engine = _Engine(proj, device, dtype, need, batch=self.batch)
+            e = self._engine = _Engine(proj, device, dtype, need, batch=self.batch, fused_ln_never=self.fused_ln_never)
         v = proj._param_version()
         if e.version != v:
             fuser, temb = proj._fuser_refs if proj._fuser_refs is not None else (None, None)
@@ -586,6 +635,7 @@ class BatchedProjector:
             capi.check(capi.lib().mavlm_reset(self._engine.ctx), "mavlm_reset")
             if self.proj._weights_maybe_stale():
                 self._engine.version = None
+            self._engine.post_ln_probe()
 
     @torch.no_grad()
     def step(self, segs):

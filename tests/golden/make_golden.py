@@ -334,6 +334,7 @@ def g7():
 
 
 G7_FIFO_FRAMES = (2, 1, 2, 2, 1, 2, 1, 1, 2, 2, 1, 2, 2)      # 13 steps: the FIFO (cap 10) is full after 10, evicts 3 times
+G7_WIDE_FRAMES = (2, 1, 2)                                    # OneVision-7B width: formation, 2 x (evolution + formation)
 
 
 def g7_fifo():
@@ -361,6 +362,29 @@ def g7_fifo():
                 if t == len(G7_FIFO_FRAMES) - 1:          # the whole FIFO after the last step: oldest entry = step 3's memory
                     res["final_cache_samples"] = np.stack([c.numpy().reshape(-1)[::499] for c in cache])
     save("g7_fifo_fullsize.npz", meta=meta(hidden=1024, wseed=72, segseed0=7200, stride=499, frames=list(G7_FIFO_FRAMES)), **res)
+
+
+def g7_wide():
+    """The OneVision-7B width (round 4): hidden 3584, 8 heads -> head_dim 448 (llava_arch.py:117-122 with the 7B backbone's
+    hidden size), the checkpoint's 8 memory tokens, depth 2; 3 recurrent steps of 2 / 1 / 2 frames (formation, then evolution +
+    formation twice).  Per step: strided samples + norm of the new memory and the frame scores of the reference's fp32 run, the
+    samples of its bf16 run.  Pins the wide-head kernels (attention_hd.hip) to the REFERENCE, not just to the emulation oracle."""
+    res = {}
+    cfg = O.PathConfig(hidden=3584, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=73)
+    for dtype, sfx in ((torch.float32, ""), (torch.bfloat16, "_refbf16")):
+        m = ref_projector(cfg, w, dtype)
+        m.memory_cache = []
+        m.frame_attn_scores = []
+        for t, F in enumerate(G7_WIDE_FRAMES):
+            seg = O.bf16_round(O.hash_normal_like((F, 196, 3584), 7300 + t))
+            cache, scores = m(T(seg).to(dtype))
+            mem = cache[-1].float().numpy().reshape(-1)
+            res[f"s{t}_sample{sfx}"] = mem[::997].copy()
+            if not sfx:
+                res[f"s{t}_norm"] = np.array(np.linalg.norm(mem.astype(np.float64)))
+                res[f"s{t}_scores"] = scores[-1].numpy().copy()
+    save("g7_wide_fullsize.npz", meta=meta(hidden=3584, wseed=73, segseed0=7300, stride=997, frames=list(G7_WIDE_FRAMES)), **res)
 
 
 # --------------------------------------------------------------------------- G8 (gradients, SURVEY.md §8f rank 3)
@@ -469,7 +493,7 @@ def g9():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g56", "g7", "g7fifo", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g56", "g7", "g7fifo", "g7wide", "g8", "g9"]
     if "g9" in which:
         g9()
     if "g8" in which:
@@ -484,5 +508,7 @@ if __name__ == "__main__":
         g5_g6()
     if "g7" in which:
         g7()
+    if "g7wide" in which:
+        g7_wide()
     if "g7fifo" in which:
         g7_fifo()

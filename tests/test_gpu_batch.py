@@ -374,12 +374,15 @@ def test_fused_layernorm_in_the_step_training_equals_inference():
     lib = capi.lib()
     try:
         capi.check(lib.mavlm_set_fused_layernorm(0), "hook")
+        proj._engine = None                   # a context snapshots the hook at mavlm_create: a new engine takes the new form
         proj.memory_cache = []
         for s_ in segs:
             cache, _ = proj(s_)
         two = [c.clone() for c in cache]
     finally:
         lib.mavlm_set_fused_layernorm(1)
+    assert proj._engine.ln_exchange_status() is None            # that engine never fuses, whatever the hook says now
+    proj._engine = None
     for a, b in zip(infer, two):
         assert O.rel_l2(to_np(a), to_np(b)) < 3e-3
     with torch.enable_grad():
@@ -393,3 +396,170 @@ def test_fused_layernorm_in_the_step_training_equals_inference():
         sum((c.float() ** 2).mean() for c in cache).backward()
     assert all(p_.grad is not None and torch.isfinite(p_.grad.float()).all() for p_ in proj.parameters())
     proj.memory_cache = []
+
+
+def test_bench_launch_configuration_vs_reference_golden():
+    """bench.py's own launch configuration against the REFERENCE: the G7 `m64f32` video (= the bench workload:
+    64 memory tokens, two 32-frame chunks, D = 1024) through `BatchedProjector(rm, 2)` inside `MemoryPathPool(model, 2, batch=2)`
+    with BOTH streams busy - 16 (video, head) pairs per attention launch on the 1-level stream-K plan with the frame masses on
+    the cut units, the fused Residual kernel over 25 088 rows, row-scattered GEMM outputs, two launch sequences interleaving
+    on the chip.  Every one of the 4 videos passes the G7 gates (at least as close to the reference's fp32 run as the
+    reference's own bf16 run, unbiased, no faster drift, frame scores), no exchange timeout, and the 2-stream run equals the
+    1-stream run bit for bit (streams only interleave independent launch sequences)."""
+    import math
+    from test_gpu_path import load_golden, _g7_gates
+    z, m = load_golden("g7_fullsize.npz")
+    tag, M, F, steps = "m64f32", 64, 32, 2
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=M, depth=2)
+    w = O.make_weights(cfg, seed=m["wseed"])
+    model = _host(cfg, w)
+    model.positional_encoding.frame_embed.zero_()              # PE add = identity: the chunks reach the projector as G7's
+    mp, fp = _prompts(1024)
+    x = to_dev(np.concatenate([O.bf16_round(O.hash_normal_like((F, 196, 1024), m["segseed0"] + t)) for t in range(steps)]))
+    vids = [(x.clone(), torch.arange(F * steps)) for _ in range(4)]
+    pool2 = arch.MemoryPathPool(model, 2, batch=2)
+    outs2 = pool2.run(vids, mp, fp, model.image_newline)
+    torch.cuda.synchronize()
+    assert len(pool2.bslots) == 2 and all(bs._n == steps for bs in pool2.bslots)        # both streams stepped a batch
+    mems2 = []
+    for k, bs in enumerate(pool2.bslots):
+        launches, timeouts = bs._engine.ln_exchange_status()
+        assert timeouts == 0 and launches == 9, (launches, timeouts)    # 2 x 2 x 2 formation + 1 evolution Residual blocks
+        for b in range(2):
+            cache = bs.memory_cache(b)
+            assert len(cache) == steps
+            errs, ref_errs = [], []
+            for t in range(steps):
+                mem = to_np(cache[t]).reshape(-1)
+                e, r = _g7_gates(mem[::m["stride"]], mem, to_np(bs.frame_scores[t][b]), z, tag + "_", t, m,
+                                 f"bench config, stream {k} video {b}")
+                errs.append(e)
+                ref_errs.append(r)
+            assert errs[1] / errs[0] <= 1.25 * ref_errs[1] / ref_errs[0] + 0.05
+            mems2.append([c.clone() for c in cache])
+    pool1 = arch.MemoryPathPool(model, 1, batch=2)
+    outs1 = pool1.run(vids, mp, fp, model.image_newline)
+    torch.cuda.synchronize()
+    for a, b in zip(outs1, outs2):
+        assert torch.equal(a, b)
+    for b in range(2):                                          # (pool1's one slot ran both groups: it holds the last one)
+        for t in range(steps):
+            assert torch.equal(pool1.bslots[0].memory_cache(b)[t], mems2[2 + b][t])
+    assert torch.equal(outs2[0], outs2[2]) and torch.equal(outs2[1], outs2[3])          # same video, other stream
+
+
+def test_fused_layernorm_operator_on_two_streams():
+    """the operator-level fused dense + residual + LayerNorm keeps ONE exchange scratch per (device, stream) - two
+    streams launching it concurrently (same epoch, same granule slots on a shared scratch) would cross-contaminate the row
+    statistics.  Two streams, different inputs, interleaved launches: each stream's results equal its own serial result bit
+    for bit and agree with the two-kernel form; a larger shape later gets a new scratch, the outgrown one stays alive."""
+    from gpu_util import f32_dev
+    lib = capi.lib()
+    cases = []
+    for i in range(2):
+        x, w, b, res, g, be = _ln_case(12544, 1024, 1024, "bf16", 900 + 10 * i)
+        cases.append((to_dev(x), to_dev(w), f32_dev(b), to_dev(res), f32_dev(g), f32_dev(be)))
+    serial = [ops.linear_residual_layernorm(*c, 1e-12)[0].clone() for c in cases]
+    try:
+        lib.mavlm_set_fused_layernorm(0)
+        two = [ops.linear_residual_layernorm(*c, 1e-12)[0].clone() for c in cases]
+    finally:
+        lib.mavlm_set_fused_layernorm(1)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for rep in range(12):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs[i].append(ops.linear_residual_layernorm(*cases[i], 1e-12)[0])
+    torch.cuda.synchronize()
+    keys = [k for k in ops._LN_WS if k[0] == torch.cuda.current_device()]
+    assert len({k[1] for k in keys}) >= 3                       # default stream + the two side streams: a scratch each
+    for i in range(2):
+        for o in outs[i]:
+            assert torch.equal(o, serial[i])
+        assert O.rel_l2(to_np(serial[i]), to_np(two[i])) < 5e-4
+    # a shape that outgrows the scratch: a new one, the old tensor is kept (captured graphs may hold its pointer)
+    kept = len(ops._LN_WS_KEEP)
+    x, w, b, res, g, be = _ln_case(150016, 1024, 64, "bf16", 990)
+    big = ops.linear_residual_layernorm(to_dev(x), to_dev(w), f32_dev(b), to_dev(res), f32_dev(g), f32_dev(be), 1e-12)[0]
+    ref = O.rounder("bf16")(O.layernorm(O.linear(x, w, b) + res, g, be, 1e-12))
+    assert O.rel_l2(to_np(big), ref) < TOL and len(ops._LN_WS_KEEP) == kept + 1
+    assert torch.equal(ops.linear_residual_layernorm(*cases[0], 1e-12)[0], serial[0])
+
+
+def test_fused_layernorm_timeout_is_raised_by_the_product_path():
+    """the product path notices a timed-out exchange.  The timeout word of the engine's workspace is set by
+    hand; the next `memory_cache = []` posts the asynchronous probe (mavlm_ln_status_async: no synchronisation) and the one
+    after it raises MavlmError; the flag is cleared by the probe, so the video after that runs again."""
+    from test_gpu_path import make_projector
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=64, depth=2)
+    proj = make_projector(cfg, O.make_weights(cfg, seed=65))
+    seg = to_dev(O.bf16_round(O.hash_normal_like((2, 196, 1024), 6500)))
+    proj.memory_cache = []
+    proj(seg)
+    eng = proj._engine
+    assert eng.ln_exchange_status() == (4, 0)
+    off = eng.workspace_base_offset + int(capi.lib().mavlm_ln_ctl_offset(eng.ctx))
+    eng.workspace[off + 8:off + 12].view(torch.int32).fill_(1)          # a workgroup gave up (never seen for real)
+    proj.memory_cache = []                                              # posts the probe
+    proj(seg)
+    torch.cuda.synchronize()
+    with pytest.raises(capi.MavlmError, match="timed out"):
+        proj.memory_cache = []                                          # looks at it
+    proj.memory_cache = []                                              # cleared by the probe: business as usual
+    proj(seg)
+    torch.cuda.synchronize()
+    proj.memory_cache = []
+    assert eng.ln_exchange_status()[1] == 1                             # (the count of what was seen stays visible)
+
+
+def test_pool_with_more_streams_than_the_fused_layernorm_admits():
+    """include/mavlm.h MAVLM_LN_MAX_STREAMS: a pool of 16 streams at 64 memory tokens must not run 16 fused Residual launches
+    side by side (3 waiting workgroups per launch and XCD).  Its slots are created with mavlm_config.fused_ln = NEVER: the
+    engines carve no exchange scratch and run GEMM + row LayerNorm; results within the rounding of the other summation order
+    of the serial (fused) path, identical videos identical across slots."""
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=64, depth=2)
+    w = O.make_weights(cfg, seed=66)
+    model = _host(cfg, w)
+    mp, fp = _prompts(1024)
+    x = to_dev(O.bf16_round(O.hash_normal_like((34, 196, 1024), 6600)))
+    vids = [(x.clone(), torch.arange(34)) for _ in range(3)]
+    serial = arch.video_memory_tokens(model, x, torch.arange(34), mp, fp, model.image_newline)[0].clone()
+    assert model.recurrent_memory_transformer._engine.ln_exchange_status() is not None       # the serial engine fuses
+    pool = arch.MemoryPathPool(model, 16)
+    assert pool.fused_ln_never and len(pool.slots) == 16
+    outs = pool.run(vids, mp, fp, model.image_newline)
+    torch.cuda.synchronize()
+    for k in range(3):
+        eng = pool.slots[k].recurrent_memory_transformer._engine
+        assert eng.c.fused_ln == capi.LN_NEVER and eng.ln_exchange_status() is None
+        assert torch.equal(outs[k], outs[0]) and O.rel_l2(to_np(outs[k]), to_np(serial)) < 6e-3
+    assert not arch.MemoryPathPool(model, capi.LN_MAX_STREAMS).fused_ln_never
+
+
+def test_project_chunk_prefetch_is_dropped_when_the_weights_change():
+    """mavlm_project_chunk leaves the chunk's K/V in the workspace for the next mavlm_step; mavlm_bind_weights (a
+    re-pack after a parameter update) must discard it - the step then projects again with the new weights."""
+    from test_gpu_path import make_projector
+    cfg = O.PathConfig(hidden=256, heads=2, mem_tokens=4, depth=2)
+    proj = make_projector(cfg, O.make_weights(cfg, seed=67))
+    seg = to_dev(O.bf16_round(O.hash_normal_like((3, 196, 256), 6700)))
+    lib = capi.lib()
+    proj.memory_cache = []
+    eng = proj.engine(seg.device, seg.dtype, 3)
+    capi.check(lib.mavlm_project_chunk(eng.ctx, seg.data_ptr(), 3, ops.stream_ptr()), "project")
+    with torch.no_grad():
+        proj.layers[0].memory_segment_fusion_attention.k_proj.weight.mul_(1.5)         # bumps the parameter version
+    got = proj(seg)[0][-1].clone()                                     # engine() re-packs -> mavlm_bind_weights -> step
+    proj.memory_cache = []
+    fresh = proj(seg)[0][-1].clone()
+    assert torch.equal(got, fresh)
+    # ... and a prefetch on ANOTHER stream is not reused either (the cache is tied to the stream that produced it)
+    proj.memory_cache = []
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        capi.check(lib.mavlm_project_chunk(eng.ctx, seg.data_ptr(), 3, ops.stream_ptr()), "project")
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(proj(seg)[0][-1], fresh)

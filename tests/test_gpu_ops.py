@@ -83,6 +83,50 @@ def test_gemm_tile_height_is_a_pure_speed_choice():
         assert torch.equal(o, outs[1])
 
 
+def test_gemm_128x256_two_workgroups_per_cu_kernel():
+    """gemm128.hip (round 4: 4 waves on a 128x256 tile, two independent workgroups per CU, a 3-slot ring per operand recycled
+    at sub-piece granularity) - selected through the tuning hook mavlm_set_gemm_tile(129).  Exact against numpy on integer data
+    (ragged M, 1 / 2 / 3 / many K-tiles: the prologue and the counted waits of the last K-tiles), bit-identical to the 256-row
+    kernels on random data for every epilogue, both dtypes, repeated launches (LDS-DMA hazards), and the fused dense + residual
+    + LayerNorm epilogue bit-identical to the 256-row fused kernel (same statistics, same merge order)."""
+    lib = capi.lib()
+    try:
+        for (M, N, K) in [(100, 256, 64), (129, 256, 128), (777, 512, 192), (1568, 1024, 1024), (3000, 256, 4096)]:
+            A = _int_mat((M, K), 31 + K)
+            W = _int_mat((N, K), 32 + K)
+            b = _int_mat((N,), 33).astype(np.float32)
+            ref = A @ W.T + b
+            lib.mavlm_set_gemm_tile(129)
+            for _ in range(3):
+                np.testing.assert_array_equal(to_np(ops.linear(to_dev(A), to_dev(W), f32_dev(b), capi.EPI_F32)), ref)
+        for mode in ("bf16", "fp16"):
+            M, N, K = 12544 + 37, 1024, 320
+            a = to_dev(O.bf16_round(O.hash_normal_like((M, K), 71)), mode)
+            w = to_dev(O.bf16_round(O.hash_uniform((N, K), 72, -0.1, 0.1)), mode)
+            b = f32_dev(O.hash_uniform((N,), 73, -0.1, 0.1))
+            for epi in (capi.EPI_BIAS, capi.EPI_RELU, capi.EPI_GELU, capi.EPI_F32):
+                lib.mavlm_set_gemm_tile(256)
+                ref = ops.linear(a, w, b, epi).clone()
+                lib.mavlm_set_gemm_tile(129)
+                for _ in range(3):
+                    assert torch.equal(ops.linear(a, w, b, epi), ref), (mode, epi)
+        # the Residual block in one kernel, on the 128-row tiles (row blocks of 128 rows, N / 256 partners)
+        for (M, N, K) in [(25088, 1024, 256), (12544 + 5, 1024, 1024), (24576, 512, 128)]:
+            a = to_dev(O.bf16_round(O.hash_normal_like((M, K), 81)))
+            w = to_dev(O.bf16_round(O.hash_uniform((N, K), 82, -0.1, 0.1)))
+            b = f32_dev(O.hash_uniform((N,), 83, -0.1, 0.1))
+            res = to_dev(O.bf16_round(O.hash_normal_like((M, N), 84)))
+            g = f32_dev(O.hash_uniform((N,), 85, 0.5, 1.5))
+            be = f32_dev(O.hash_uniform((N,), 86, -0.5, 0.5))
+            lib.mavlm_set_gemm_tile(0)
+            ref = ops.linear_residual_layernorm(a, w, b, res, g, be, 1e-12)[0].clone()
+            lib.mavlm_set_gemm_tile(129)
+            for _ in range(3):
+                assert torch.equal(ops.linear_residual_layernorm(a, w, b, res, g, be, 1e-12)[0], ref), (M, N, K)
+    finally:
+        lib.mavlm_set_gemm_tile(0)
+
+
 def test_gemm_256_tile_kernels_with_l2_resident_weights():
     """The 256-column-tile kernels re-stage a B half-tile (LDS-DMA) in the barrier interval in which the other wave group
     retires its last reads of it; the margin is the DMA's latency (gemm256.hip, hazard table: WAR).  The shortest latency

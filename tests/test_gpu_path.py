@@ -245,6 +245,54 @@ def test_golden_g7_reference_fullsize(tag, M, F, steps):
         assert errs[t] / errs[t - 1] <= 1.25 * ref_errs[t] / ref_errs[t - 1] + 0.05, (errs, ref_errs)
 
 
+def _g7_gates(got, mem, scores, z, pfx, t, m, label):
+    """the gates of the G7 tests for one step of one video; returns (err, reference's own bf16 err)"""
+    ref = z[f"{pfx}s{t}_sample"]
+    err, err_refbf16 = O.rel_l2(got, ref), O.rel_l2(z[f"{pfx}s{t}_sample_refbf16"], ref)
+    d = (got - ref).astype(np.float64)
+    bias, sem = d.mean(), d.std() / math.sqrt(d.size)
+    print(f"{label} step {t}: HIP-bf16 vs ref-fp32 {err:.2e}; reference-bf16 vs ref-fp32 {err_refbf16:.2e}; "
+          f"mean signed error {bias:+.2e} (standard error {sem:.1e})")
+    assert err < TOL_REF_FP32 and err <= err_refbf16          # inside the reference's own bf16 envelope, no slack
+    assert abs(bias) < 4.0 * sem + 1e-6                       # unbiased
+    assert abs(np.linalg.norm(mem.astype(np.float64)) / float(z[f"{pfx}s{t}_norm"]) - 1) < 5e-3
+    assert O.rel_l2(scores, z[f"{pfx}s{t}_scores"]) < 1e-2
+    return err, err_refbf16
+
+
+def test_golden_g7_wide_reference_fullsize():
+    """The OneVision-7B width against the REFERENCE (round 4; tests/golden/g7_wide_fullsize.npz: hidden 3584, head_dim 448, 8
+    memory tokens, 3 steps of 2 / 1 / 2 frames of the imported reference, fp32 + its own bf16 run): the wide-head kernels
+    (attention_hd.hip, 32-query waves / split-KV at this row count, the column-sum pass for the frame scores) and the K = 3584 /
+    14336 GEMMs through the G7 gates - at least as close to the reference's fp32 result as its own bf16 run, unbiased, no
+    faster drift.  Then the same video twice through a ROW BATCH of two (`BatchedProjector`): every video passes the same
+    gates (the batch runs the wide-head attention per video and the stacked GEMMs / LayerNorms)."""
+    from memory_augmented_vlm_amd.model.memory_module.MemoryController import BatchedProjector
+    z, m = load_golden("g7_wide_fullsize.npz")
+    cfg = O.PathConfig(hidden=3584, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=m["wseed"])
+    proj = make_projector(cfg, w)
+    segs = [to_dev(O.bf16_round(O.hash_normal_like((F, 196, 3584), m["segseed0"] + t))) for t, F in enumerate(m["frames"])]
+    proj.memory_cache = []
+    errs, ref_errs = [], []
+    with torch.no_grad():
+        for t, seg in enumerate(segs):
+            cache, scores = proj(seg)
+            mem = to_np(cache[-1]).reshape(-1)
+            e, r = _g7_gates(mem[::m["stride"]], mem, to_np(scores[-1]), z, "", t, m, "7B width")
+            errs.append(e)
+            ref_errs.append(r)
+        for t in range(1, len(errs)):
+            assert errs[t] / errs[t - 1] <= 1.25 * ref_errs[t] / ref_errs[t - 1] + 0.05, (errs, ref_errs)
+        bp = BatchedProjector(proj, 2)
+        bp.reset()
+        for t, seg in enumerate(segs):
+            sc = bp.step([seg, seg.clone()])
+            for b in range(2):
+                mem = to_np(bp.memory_cache(b)[-1]).reshape(-1)
+                _g7_gates(mem[::m["stride"]], mem, to_np(sc[b]), z, "", t, m, f"7B width, row batch video {b}")
+
+
 def test_golden_g7_fifo_wrap_fullsize():
     """The reference-pinned chain PAST the FIFO's capacity at full width (round 3): checkpoint shape (8 memory tokens,
     D = 1024), 13 steps of 1-2 frames, cap 10 - eviction at steps 10-12 (MemoryController.py:152-154), the evolution attends

@@ -34,7 +34,7 @@ def test_header_symbols_exported(built_lib):
     l = ctypes.CDLL(built_lib)
     for name in declared:
         assert hasattr(l, name), name
-    assert capi.lib().mavlm_abi_version() == 2
+    assert capi.lib().mavlm_abi_version() == 3
 
 
 def test_config_validation_without_gpu(built_lib):

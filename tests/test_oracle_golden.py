@@ -163,6 +163,23 @@ def test_g7_fifo_wrap_fullsize_samples():
     assert got.shape == z["final_cache_samples"].shape and O.rel_l2(got, z["final_cache_samples"]) < 2 * TOL
 
 
+def test_g7_wide_fullsize_samples():
+    """The OneVision-7B width (hidden 3584, head_dim 448; round 4): the oracle's fp32 mode against the reference's own fp32 run
+    of 3 recurrent steps (formation, 2 x evolution + formation) - the pin of the wide-head path outside D = 1024."""
+    z, m = load_golden("g7_wide_fullsize.npz")
+    cfg = O.PathConfig(hidden=3584, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=m["wseed"])
+    rm = O.RecurrentMemory(cfg, w, "fp32")
+    rm.reset()
+    for t, F in enumerate(m["frames"]):
+        seg = O.bf16_round(O.hash_normal_like((F, 196, 3584), m["segseed0"] + t))
+        cache, scores = rm.step(seg)
+        mem = cache[-1].reshape(-1)
+        assert O.rel_l2(mem[::m["stride"]], z[f"s{t}_sample"]) < 2 * TOL, t
+        assert abs(np.linalg.norm(mem.astype(np.float64)) / float(z[f"s{t}_norm"]) - 1) < 1e-5
+        assert O.rel_l2(scores[-1], z[f"s{t}_scores"]) < 2 * TOL
+
+
 def test_g9_transformer_fuser_variant_matches_reference():
     """Inactive MemoryFuser variant (MemoryFuser.py:4-30): oracle/variants.py against the imported reference class."""
     from oracle import variants as V
