@@ -164,6 +164,8 @@ int mavlm_batch(const mavlm_ctx* ctx);      /* B = max(config.batch, 1) */
  * overlap it with an exchange the step has to wait for - the all-gather of the previous memory's rows in the row-sharded
  * mode.  The next mavlm_step with the same (seg, F) skips the projection; any other call discards it. */
 int mavlm_project_chunk(mavlm_ctx* ctx, const void* seg, int32_t F, void* stream);
+/* number of mavlm_step calls of this context that found (and used) a projection left by mavlm_project_chunk */
+int mavlm_prefetch_hits(const mavlm_ctx* ctx);
 
 /* replaces memory_fuser(cat(memory_cache)) + token_type add + fine-frame gather/add + prompt/newline concat
  * (llava_arch.py:513-524,545-554,620-629,708-731).  Writes
@@ -244,6 +246,14 @@ int mavlm_linear_ws(const void* A, int32_t lda, const void* W, int32_t ldw, cons
  * info[3] = split-KV planes (1 = none). */
 int64_t mavlm_attention_ws_floats(int32_t R, int32_t S, int32_t H);
 int mavlm_attention_plan(int32_t R, int32_t S, int32_t H, int32_t info[4]);
+/* Which unit (head-major index h * ceil(R / QB) + query block) the stream-K schedule runs at a position: level < 0: the unit
+ * of whole round `a` on virtual workgroup `b`; level >= 0: the b-th unit of that level (cut into 2^k key ranges).  The
+ * units are dealt XCD-major (every XCD walks a contiguous range of the head-major order: one head's K / V in its L2 at a
+ * time); which units are cut is part of a result's rounding, so the oracle mirrors this map.  -1 = no plan / out of range. */
+int mavlm_attention_plan_unit(int32_t R, int32_t S, int32_t H, int32_t level, int32_t a, int32_t b);
+/* tuning / test hook: 1 (default) = XCD-affine unit order of the stream-K schedule, 0 = position p runs unit p (the order of
+ * rounds 1-3).  Part of a result's rounding (which units are cut): the oracle mirrors it (STREAMK_AFFINE). */
+int mavlm_set_attention_unit_order(int32_t affine);
 int mavlm_attention_ws(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                        int32_t ldo, float* lse2, int32_t R, int32_t S, int32_t H, float scale, float* ws,
                        int64_t ws_floats, int32_t dtype, void* stream);

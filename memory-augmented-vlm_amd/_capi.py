@@ -64,6 +64,7 @@ SIGNATURES = {
     "mavlm_step_batch": (C.c_int, [vp, C.POINTER(vp), i32, vp, i32, vp]),
     "mavlm_batch": (C.c_int, [vp]),
     "mavlm_project_chunk": (C.c_int, [vp, vp, i32, vp]),
+    "mavlm_prefetch_hits": (C.c_int, [vp]),
     "mavlm_fuse_emit_batch": (C.c_int, [vp, C.POINTER(vp), vp, i32, vp, i32, vp, i32, vp, i32, vp, C.c_int64,
                                         C.POINTER(C.c_int64), vp]),
     "mavlm_fuse_emit": (C.c_int, [vp, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, C.c_int64,
@@ -110,6 +111,8 @@ SIGNATURES = {
     "mavlm_set_gemm_order": (C.c_int, [i32]),
     "mavlm_set_attention_impl": (C.c_int, [i32]),
     "mavlm_attention_plan": (C.c_int, [i32, i32, i32, C.POINTER(i32)]),
+    "mavlm_attention_plan_unit": (C.c_int, [i32, i32, i32, i32, i32, i32]),
+    "mavlm_set_attention_unit_order": (C.c_int, [i32]),
     "mavlm_set_attention_streamk_min_tiles": (C.c_int, [i32]),
     "mavlm_set_attention_streamk_waves": (C.c_int, [i32]),
     "mavlm_set_attention_colsum_wgs": (C.c_int, [i32]),

@@ -204,7 +204,8 @@ def linear_residual_layernorm(x, weight, bias_f32, residual, gamma_f32, beta_f32
     if ws is None or ws.numel() < nws:
         if torch.cuda.is_current_stream_capturing():
             raise capi.MavlmError("linear_residual_layernorm: first use inside a graph capture - warm the operator up "
-                                  "outside the capture (its scratch carries a launch counter)")
+                                  "outside the capture ON THE STREAM THAT CAPTURES (torch.cuda.graph(g, stream=warm_stream)): its scratch carries "
+                                  "a launch counter and there is one per (device, stream)")
         if ws is not None:
             _LN_WS_KEEP.append(ws)
         ws = _LN_WS[key] = torch.zeros(max(nws, 1 << 23), device=x.device, dtype=torch.uint8)

@@ -61,7 +61,57 @@ struct attn3_sk_plan {
   int base[6];       // first unit of the level
   int nun[6];        // units of the level (<= G >> k)
   int slot[6];       // first partial slot of the level (+ virtual workgroup id)
+  int affine;        // 1 = XCD-affine unit order (round 4, default), 0 = position p runs unit p (rounds 1-3; tuning hook)
 };
+
+// XCD-affine unit order (round 4).  The schedule hands out POSITIONS: whole-round position (si, v) = the v-th virtual workgroup's
+// unit of round si; level position (lv, ul) = the ul-th unit of level lv (cut into 2^k pieces, run by the virtual workgroups
+// [ul << k, (ul + 1) << k)).  Virtual ids are XCD-major (xcd_remap): XCD x owns v in [x W, (x + 1) W), W = G / 8.  Rounds 1-3
+// mapped position p to unit p (head-major order): the 32 units an XCD works on at a time then straddled two heads in 15 of
+// 24 (XCD, round) pairs of the bench launch - two heads' K / V (6.4 MB) against a 4 MiB L2, each head fetched by 2-3 XCDs
+// (253 MB of reads per launch for 103 MB of operands).  Now the units are dealt to the XCDs FIRST: XCD x owns the
+// contiguous unit range [C(x), C(x + 1)), C(x) = x full W + sum_lv min(nun_lv, x w_lv) (w_lv = W >> k_lv units of a level per
+// XCD), and walks it in the order of its positions - its rounds, then its units of level 0, 1, ...  Bench launch (784 units,
+// G = 256): C(x) = 98 x = two (video, head) pairs per XCD, one head at a time except in the round that crosses from the
+// first to the second.  A bijection of the positions onto the units: which unit is cut (and how) changes, the plan does
+// not; the merge kernel and the oracle (streamk_unit_of_position) apply the same map.
+__host__ __device__ __forceinline__ int attn3_xcd_first_unit(const attn3_sk_plan& p, int x) {
+  const int W = p.wgs >> 3;
+  int c = x * p.full * W;
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+    if (j < p.nlev) {
+      const int t = x * (W >> p.k[j]);
+      c += p.nun[j] < t ? p.nun[j] : t;
+    }
+  return c;
+}
+// whole-round position: round si, virtual workgroup v
+__host__ __device__ __forceinline__ int attn3_unit_of_round(const attn3_sk_plan& p, int si, int v) {
+  if (!p.affine) return si * p.wgs + v;
+  const int W = p.wgs >> 3, x = v / W;
+  return attn3_xcd_first_unit(p, x) + si * W + (v - x * W);
+}
+// level position: ul-th unit of level lv
+__host__ __device__ __forceinline__ int attn3_unit_of_level(const attn3_sk_plan& p, int lv, int ul) {
+  const int W = p.wgs >> 3;
+  int k = p.k[0], b0 = p.base[0];
+#pragma unroll
+  for (int j = 1; j < 6; ++j)
+    if (lv == j) { k = p.k[j]; b0 = p.base[j]; }
+  if (!p.affine) return b0 + ul;
+  const int w = W >> k, x = ul / w;
+  int u = attn3_xcd_first_unit(p, x) + p.full * W + (ul - x * w);
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+    if (j < lv) {                                              // this XCD's units of the earlier levels
+      const int wj = W >> p.k[j];
+      int n = p.nun[j] - x * wj;
+      n = n < 0 ? 0 : (n > wj ? wj : n);
+      u += n;
+    }
+  return u;
+}
 
 // NW = waves per workgroup: 4 (128 queries per unit, two workgroups per CU) or 8 (256 queries per unit, one workgroup per
 // CU, used with the stream-K schedule): the 32 KiB of K / V per tile are then staged once for eight waves instead of
@@ -120,20 +170,20 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
   if (plan.wgs > 0) {
     int u;
     if (si < plan.full) {
-      u = si * plan.wgs + sk_v;
+      u = attn3_unit_of_round(plan, si, sk_v);
       t_lo = 0;
       nt = nt_all;
       out_kind = 0;
     } else {
       const int lv = si - plan.full;
-      int lk = plan.k[0], lbase = plan.base[0], lnun = plan.nun[0], lslot = plan.slot[0];
+      int lk = plan.k[0], lnun = plan.nun[0], lslot = plan.slot[0];
 #pragma unroll
       for (int j = 1; j < 6; ++j)                              // (static indices: the plan lives in scalar registers)
-        if (lv == j) { lk = plan.k[j]; lbase = plan.base[j]; lnun = plan.nun[j]; lslot = plan.slot[j]; }
+        if (lv == j) { lk = plan.k[j]; lnun = plan.nun[j]; lslot = plan.slot[j]; }
       const int ul = sk_v >> lk;
       if (ul >= lnun) continue;                                // this workgroup has no unit on this (partial) level
       const int piece = sk_v & ((1 << lk) - 1);
-      u = lbase + ul;
+      u = attn3_unit_of_level(plan, lv, ul);
       t_lo = (int)(((long long)piece * nt_all) >> lk);
       nt = (int)(((long long)(piece + 1) * nt_all) >> lk) - t_lo;
       out_kind = 2;
@@ -746,19 +796,19 @@ __global__ __launch_bounds__(256) void attn_combine_sk_kernel(const float* __res
                                                               attn3_frames_args fa) {
   __shared__ float fsh[FR != 0 ? 512 : 1];
   const int wpu = QB / 32;                                     // workgroups per cut unit (32 query rows each)
-  int b = blockIdx.x / wpu, lk = 0, lbase = 0, lslot = 0;
+  int b = blockIdx.x / wpu, lk = 0, lv = 0, lslot = 0;
   const int quarter = blockIdx.x - b * wpu;
   bool found = false;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     if (!found && j < plan.nlev) {
-      if (b < plan.nun[j]) { lk = plan.k[j]; lbase = plan.base[j]; lslot = plan.slot[j]; found = true; }
+      if (b < plan.nun[j]) { lk = plan.k[j]; lv = j; lslot = plan.slot[j]; found = true; }
       else b -= plan.nun[j];
     }
   }
   if (!found) return;
   const int nqb = (R + QB - 1) / QB;
-  const int u = lbase + b;
+  const int u = attn3_unit_of_level(plan, lv, b);              // (the XCD-affine unit order of attn_fwd3_kernel)
   const int h = u / nqb, qblk = u - h * nqb;
   const size_t s0 = (size_t)lslot + ((size_t)b << lk);
   switch (lk) {
@@ -851,6 +901,7 @@ int mavlm_attention_splits(int R, int S, int H, int* tiles_per_split) {
 constexpr int ATTN3_SK_WGS = 512;
 int g_mavlm_attn_sk_min_tiles = 64;          // tuning / test hook (mavlm_set_attention_streamk_min_tiles)
 int g_mavlm_attn_sk_waves = 0;                // tuning hook: 0 = automatic, 4 / 8 = waves per stream-K workgroup
+int g_mavlm_attn_unit_order = 1;              // tuning hook: 1 = XCD-affine unit order, 0 = position order (rounds 1-3)
 static attn3_sk_plan attn3_plan_for(int R, int S, int H, int waves) {
   attn3_sk_plan p = {};
   const int QB = 32 * waves, G = ATTN3_SK_WGS * 4 / waves;    // 512 four-wave or 256 eight-wave workgroups fill 256 CUs
@@ -860,6 +911,7 @@ static attn3_sk_plan attn3_plan_for(int R, int S, int H, int waves) {
   if ((double)units / (double)(rounds * G) >= 0.95) return p;
   p.wgs = G;
   p.qb = QB;
+  p.affine = g_mavlm_attn_unit_order;
   p.full = (int)(units / G);
   int rem = (int)(units % G), base = p.full * G, slot = 0;
   for (int k = 1; k <= 4; ++k)
@@ -889,6 +941,15 @@ void mavlm_attention_plan_info(int R, int S, int H, int info[4]) {
   info[2] = pl.nlev;
   info[3] = pl.wgs > 0 ? 1 : mavlm_attention_splits(R, S, H, nullptr);
   if (info[3] < 1) info[3] = 1;
+}
+
+// unit (head-major index h * nqb + q-block) at a schedule position: lv < 0: whole round `a`, virtual workgroup `b`; lv >= 0:
+// the b-th unit of level lv.  -1 = no stream-K plan / out of range.  (CPU mirror test of the XCD-affine unit order.)
+int mavlm_attention_plan_unit_(int R, int S, int H, int lv, int a, int b) {
+  const attn3_sk_plan pl = attn3_plan(R, S, H);
+  if (pl.wgs <= 0) return -1;
+  if (lv < 0) return (a >= 0 && a < pl.full && b >= 0 && b < pl.wgs) ? attn3_unit_of_round(pl, a, b) : -1;
+  return (lv < pl.nlev && b >= 0 && b < pl.nun[lv]) ? attn3_unit_of_level(pl, lv, b) : -1;
 }
 
 size_t mavlm_attention_split_ws_floats(int R, int S, int H) {

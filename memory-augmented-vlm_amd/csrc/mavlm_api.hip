@@ -22,6 +22,7 @@ struct mavlm_ctx {
   const void* pre_seg = nullptr;   // mavlm_project_chunk: the chunk whose K/V already sit in the workspace (0 = none)
   int pre_F = 0;
   void* pre_stream = nullptr;      // ... and the stream the projection was enqueued on (mavlm_step must use the same one)
+  int pre_hits = 0;                // steps that reused a mavlm_project_chunk projection (mavlm_prefetch_hits: tests)
   int fuse_mems = 1;   // cached memories the Memory-Fuser MLP takes per GEMM launch (mavlm_fuse_emit)
   int fused_ln = 1;    // snapshot of the process-wide hook at mavlm_create (0 = two-kernel form, 1 / 2 = fused where supported)
   int ln_wide = 0;     // ... and of its "rows of up to 4096 columns" test mode
@@ -329,7 +330,8 @@ int step_impl(mavlm_ctx* x, const void* const* segs, int32_t F, void* frame_scor
   // does not depend on the memory rows: nothing to gain from stacking, and the videos' frames stay where they are)
   char* kvs = ws(x, x->o_kv);
   const int ldkv = 2 * L * Dp;
-  const bool pre = B == 1 && x->pre_seg == segs[0] && x->pre_F == F && x->pre_stream == (void*)s;       // mavlm_project_chunk ran for exactly this chunk
+  const bool pre = B == 1 && x->pre_seg == segs[0] && x->pre_F == F && x->pre_stream == (void*)s;
+  x->pre_hits += pre ? 1 : 0;       // mavlm_project_chunk ran for exactly this chunk
   x->pre_seg = nullptr;
   x->pre_F = 0;
   for (int b = 0; b < B && !pre; ++b)
@@ -408,6 +410,12 @@ int mavlm_set_gemm_tile(int32_t tile) {
 }
 
 extern int g_mavlm_attn_sk_waves;      // (g_mavlm_attn_sk_min_tiles: mavlm_kernels.h)
+extern int g_mavlm_attn_unit_order;
+int mavlm_set_attention_unit_order(int32_t affine) {
+  if (affine != 0 && affine != 1) return MAVLM_E_ARG;
+  g_mavlm_attn_unit_order = affine;
+  return 0;
+}
 int mavlm_set_attention_streamk_min_tiles(int32_t tiles) {
   if (tiles < 1) return MAVLM_E_ARG;
   g_mavlm_attn_sk_min_tiles = tiles;
@@ -575,6 +583,7 @@ int mavlm_reset(mavlm_ctx* x) {
   return 0;
 }
 
+int mavlm_prefetch_hits(const mavlm_ctx* x) { return x ? x->pre_hits : MAVLM_E_ARG; }
 int mavlm_cache_len(const mavlm_ctx* x) { return x ? (x->steps < x->cfg.cache_cap ? x->steps : x->cfg.cache_cap) : MAVLM_E_ARG; }
 int mavlm_newest_slot(const mavlm_ctx* x) { return x ? (x->steps ? (x->steps - 1) % x->cfg.cache_cap : -1) : MAVLM_E_ARG; }
 int mavlm_steps(const mavlm_ctx* x) { return x ? x->steps : MAVLM_E_ARG; }
@@ -775,6 +784,11 @@ int mavlm_attention_plan(int32_t R, int32_t S, int32_t H, int32_t info[4]) {
   mavlm_attention_plan_info(R, S, H, v);
   for (int i = 0; i < 4; ++i) info[i] = v[i];
   return 0;
+}
+
+int mavlm_attention_plan_unit(int32_t R, int32_t S, int32_t H, int32_t level, int32_t a, int32_t b) {
+  if (R <= 0 || S <= 0 || H <= 0) return MAVLM_E_ARG;
+  return mavlm_attention_plan_unit_(R, S, H, level, a, b);
 }
 
 int mavlm_attention_ws(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,

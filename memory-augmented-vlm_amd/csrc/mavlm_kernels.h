@@ -96,6 +96,7 @@ int mavlm_attention_splits(int R, int S, int H, int* tiles_per_split);
 // stream-K schedule of the head_dim-128 forward (more units than workgroup slots): persistent workgroups, 0 = not used
 int mavlm_attention_streamk_wgs(int R, int S, int H);
 void mavlm_attention_plan_info(int R, int S, int H, int info[4]);
+int mavlm_attention_plan_unit_(int R, int S, int H, int lv, int a, int b);   // unit at a schedule position (attention3.hip)
 size_t mavlm_attention_split_ws_floats(int R, int S, int H);
 size_t mavlm_attention_split_ws_floats_max(int R, int S, int H);   // ... over both stream-K workgroup shapes (4 / 8 waves)
 // the same for the wide-head kernel (attention_hd.hip) and the merge kernel both use (attention3.hip)

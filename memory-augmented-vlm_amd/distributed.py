@@ -86,6 +86,7 @@ class RowShardedMemory:
         self._engine = None
         self._pending = None
         self._n = 0
+        self._pre = None           # (the tensor given as `prefetch`, its contiguous form whose K/V sit in the workspace)
 
     # -- engine (a row shard of the projector's fused engine) ------------------------------------------------
     def _eng(self, device, dtype, frames):
@@ -108,10 +109,12 @@ class RowShardedMemory:
         from . import _capi as capi
         self.wait()
         self._n = 0
+        self._pre = None
         if self._engine is not None:
             capi.check(capi.lib().mavlm_reset(self._engine.ctx), "mavlm_reset")
             if self.p._weights_maybe_stale():
                 self._engine.version = None
+            self._engine.post_ln_probe()
 
     def wait(self):
         """the all-gather of the newest memory is complete (the compute stream is ordered behind it)"""
@@ -137,7 +140,15 @@ class RowShardedMemory:
         from . import _ops as ops
         p = self.p
         F, P, D = image_features.shape
-        x = image_features.contiguous()
+        # The prefetch cache of the C library matches on the POINTER of the chunk: when the chunk announced by the previous
+        # step's `prefetch` had to be made contiguous, that copy - not a second one - is what this step must run on.
+        pre, self._pre = self._pre, None
+        if pre is not None and (image_features is pre[0] or (image_features.data_ptr() == pre[0].data_ptr() and
+                                                               image_features.shape == pre[0].shape and
+                                                               image_features.stride() == pre[0].stride())):
+            x = pre[1]
+        else:
+            x = image_features.contiguous()
         e = self._eng(x.device, x.dtype, F)
         lib = capi.lib()
         self.wait()                                               # (normally already complete: see below)
@@ -153,6 +164,33 @@ class RowShardedMemory:
             if prefetch is not None:                              # overlaps the all-gather: needs nothing of the memory
                 nx = prefetch.contiguous()
                 capi.check(lib.mavlm_project_chunk(e.ctx, nx.data_ptr(), nx.shape[0], ops.stream_ptr()), "mavlm_project_chunk")
+                self._pre = (prefetch, nx)                        # keeps the contiguous copy alive until the next step
             swork.wait()
             self.wait()
         return self.cache, scores.to(x.dtype)
+
+    @torch.no_grad()
+    def fused_memory(self, memory_fuser, type_embedding_row0: Optional[torch.Tensor] = None):
+        """The Memory-Fuser MLP over the FIFO (llava_arch.py:545-554: `memory_fuser(cat(cache))` + token-type row 0), row
+        sharded as the steps are: rank g fuses its memory tokens of every cached memory ([n, M/W, P, D] rows: the MLP is
+        row-independent, two HIP GEMMs with the GELU in the first epilogue), ONE all-gather ([W, n, M/W, P, D]) completes
+        the block on every rank.  Returns [n*M, P, D], oldest memory first - the rows the single-GPU path feeds the LLM."""
+        from . import _capi as capi
+        from . import _ops as ops
+        self.wait()
+        cache = self.cache
+        n = len(cache)
+        if n == 0:
+            raise RuntimeError("fused_memory: no step since reset")
+        M, P, D = cache[0].shape
+        own = torch.stack([c[self.token0:self.token0 + self.tokens] for c in cache])          # [n, tokens, P, D]
+        b2 = memory_fuser[2].bias.float()
+        if type_embedding_row0 is not None:
+            b2 = b2 + type_embedding_row0.float()
+        h = ops.linear(own.view(-1, D), memory_fuser[0].weight, memory_fuser[0].bias.float(), capi.EPI_GELU)
+        y = ops.linear(h, memory_fuser[2].weight, b2, capi.EPI_BIAS).view(n, self.tokens, P, D)
+        if self.world == 1:
+            return y.reshape(n * M, P, D)
+        full = torch.empty((self.world, n, self.tokens, P, D), device=y.device, dtype=y.dtype)
+        dist.all_gather_into_tensor(full.view(-1), y.reshape(-1), group=self.group)
+        return full.permute(1, 0, 2, 3, 4).reshape(n * M, P, D)

@@ -397,6 +397,38 @@ def streamk_plan(R: int, S: int, heads: int):
     return _streamk_plan_for(R, S, heads, 4)
 
 
+STREAMK_AFFINE = True      # mirror of mavlm_set_attention_unit_order (1 = default: XCD-affine unit order)
+
+
+def _xcd_first_unit(G: int, full: int, levels, x: int) -> int:
+    W = G >> 3
+    return x * full * W + sum(min(n, x * (W >> k)) for k, _, n in levels)
+
+
+def streamk_unit_of_round(G: int, full: int, levels, si: int, v: int) -> int:
+    """Mirrors attn3_unit_of_round (csrc/attention3.hip): the unit the v-th virtual workgroup runs in whole round si.  The
+    units are dealt XCD-major: XCD x (virtual ids [x G/8, (x+1) G/8)) owns a contiguous range of the head-major unit order."""
+    if not STREAMK_AFFINE:
+        return si * G + v
+    W = G >> 3
+    x = v // W
+    return _xcd_first_unit(G, full, levels, x) + si * W + (v - x * W)
+
+
+def streamk_unit_of_level(G: int, full: int, levels, lv: int, ul: int) -> int:
+    """Mirrors attn3_unit_of_level: the ul-th unit of level lv (the one cut into 2^k key ranges)."""
+    if not STREAMK_AFFINE:
+        return levels[lv][1] + ul
+    W = G >> 3
+    w = W >> levels[lv][0]
+    x = ul // w
+    u = _xcd_first_unit(G, full, levels, x) + full * W + (ul - x * w)
+    for k, _, n in levels[:lv]:
+        wj = W >> k
+        u += min(max(n - x * wj, 0), wj)
+    return u
+
+
 def streamk_wgs(R: int, S: int, heads: int) -> int:
     return streamk_plan(R, S, heads)[0]
 
@@ -405,14 +437,14 @@ def streamk_split_tiles(R: int, S: int, heads: int):
     """(queries per unit, {(head, query block): [(tile_lo, tile_hi), ...]}) for the units the levelled stream-K schedule
     cuts: their keys are processed as 2^k ranges with independent online-softmax states and merged in key order like
     split-KV partials (empty ranges - fewer tiles than pieces - dropped).  Unit order: head-major, then query block."""
-    G, QB, _, levels = streamk_plan(R, S, heads)
+    G, QB, full, levels = streamk_plan(R, S, heads)
     out: Dict[Tuple[int, int], List[Tuple[int, int]]] = {}
     if not G:
         return QB, out
     nqb, nt = -(-R // QB), -(-S // KV_TILE)
-    for k, base, n in levels:
+    for lv, (k, base, n) in enumerate(levels):
         for ul in range(n):
-            u = base + ul
+            u = streamk_unit_of_level(G, full, levels, lv, ul)      # (XCD-affine unit order, round 4)
             rng = [((p * nt) >> k, ((p + 1) * nt) >> k) for p in range(1 << k)]
             out[(u // nqb, u % nqb)] = [(a, b) for a, b in rng if b > a]
     return QB, out

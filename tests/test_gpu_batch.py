@@ -341,7 +341,9 @@ def test_fused_layernorm_back_to_back_launches_and_graph_replay():
         ops.linear_residual_layernorm(sx, a0[1], a0[2], sres, a0[4], a0[5], 1e-12, out=sout)
     torch.cuda.current_stream().wait_stream(side)
     gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr):
+    # (torch.cuda.graph captures on a stream of its own by default, where the operator has no scratch yet - it would raise
+    # "first use inside a graph capture"; capture on the warmed-up stream: the scratch is per (device, stream))
+    with torch.cuda.graph(gr, stream=side):
         ops.linear_residual_layernorm(sx, a0[1], a0[2], sres, a0[4], a0[5], 1e-12, out=sout)
     for rep in range(6):
         src = cases[rep & 1]

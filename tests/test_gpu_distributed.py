@@ -42,10 +42,19 @@ def _worker(rank, world, port, out_dir, hidden=1024):
         for s_ in segs:
             cache, scores = proj(s_)
             ref.append((cache[-1].clone(), scores[-1].clone(), len(cache)))
+        # NON-contiguous chunks (strided views of a wider buffer): `step` makes them contiguous, and the copy made for the
+        # prefetch must be the one the next step runs on - the C library matches the prefetched chunk by pointer (round 4:
+        # the projection used to be discarded silently for such inputs)
+        wide = [torch.cat([s_, torch.zeros_like(s_)], dim=2) for s_ in segs]
+        nc = [w_[:, :, :hidden] for w_ in wide]
+        assert not nc[0].is_contiguous()
         sharded.reset()
-        for t, s_ in enumerate(segs):
+        n_pre = 0
+        for t, s_ in enumerate(nc):
             # (odd steps hand the next chunk over: its K/V projection runs under the all-gather, mavlm_project_chunk)
-            cache, scores = sharded.step(s_, prefetch=segs[t + 1] if t % 2 == 1 and t + 1 < len(segs) else None)
+            pre = nc[t + 1] if t % 2 == 1 and t + 1 < len(nc) else None
+            n_pre += pre is not None
+            cache, scores = sharded.step(s_, prefetch=pre)
             assert len(cache) == ref[t][2]
             err = float((cache[-1].float() - ref[t][0].float()).norm() / ref[t][0].float().norm())
             serr = float((scores.float() - ref[t][1].float()).norm() / ref[t][1].float().norm())
@@ -54,6 +63,22 @@ def _worker(rank, world, port, out_dir, hidden=1024):
                 o = torch.from_numpy(omem[t]).to(cache[-1].device)
                 oerr = float((cache[-1].float().reshape(-1) - o.reshape(-1)).norm() / o.norm())
             np.save(os.path.join(out_dir, f"err_{rank}_{t}.npy"), np.array([err, serr, oerr]))
+        from memory_augmented_vlm_amd import _capi as capi
+        assert capi.lib().mavlm_prefetch_hits(sharded._engine.ctx) == n_pre > 0        # every prefetched projection was used
+        # the Memory-Fuser MLP over the FIFO, row-sharded (each rank fuses its tokens, one all-gather): against the module
+        # applied to the whole FIFO on this rank (row-independent GEMMs: the same kernel per row block -> same bits)
+        from memory_augmented_vlm_amd.model import llava_arch as arch
+        torch.manual_seed(7)
+        fuser = arch.MemoryFuserMLP(hidden).to("cuda").to(torch.bfloat16)
+        e0 = torch.randn(hidden, device="cuda").bfloat16() * 0.02
+        got = sharded.fused_memory(fuser, e0)
+        whole = torch.cat(list(cache), 0)
+        b2 = fuser[2].bias.float() + e0.float()
+        from memory_augmented_vlm_amd import _ops as ops
+        want = ops.linear(ops.linear(whole.reshape(-1, hidden), fuser[0].weight, fuser[0].bias.float(), capi.EPI_GELU),
+                          fuser[2].weight, b2, capi.EPI_BIAS).view(-1, 196, hidden)
+        assert got.shape == want.shape
+        assert float((got.float() - want.float()).norm() / want.float().norm()) < 2e-3
         # every rank holds the same full FIFO
         mine = torch.stack(list(cache)).float().cpu()
         gathered = [torch.empty_like(mine) for _ in range(world)]
@@ -128,3 +153,51 @@ def test_bench_two_rank_rehearsal(mode, tmp_path):
         assert out["config"]["allgather_final_memory"] is True and out["scaling"] == "weak"
     else:
         assert out["scaling"] == "strong"
+
+
+_NCCL_SMOKE = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MAVLM_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MAVLM_ROOT"], "tests"))
+import memory_augmented_vlm_amd
+from memory_augmented_vlm_amd import distributed as D
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+# the in-place form of RowShardedMemory.step: the send buffer is this rank's slice of the receive buffer, async
+slot = torch.randn(8, 196, 1024, device="cuda").bfloat16()
+keep = slot.clone()
+work = dist.all_gather_into_tensor(slot.view(-1), slot[0:8].reshape(-1), async_op=True)
+sc = torch.arange(5, device="cuda", dtype=torch.float32)
+w2 = dist.all_reduce(sc, async_op=True)
+work.wait(); w2.wait(); torch.cuda.synchronize()
+assert torch.equal(slot, keep) and torch.equal(sc.cpu(), torch.arange(5, dtype=torch.float32))
+g, _ = D.all_gather_memory_state(slot)
+assert g.shape == (1, 8, 196, 1024) and torch.equal(g[0], keep)
+# a 1-rank row shard of a real projector over RCCL's group: the sharded step degenerates to the single-GPU step
+from oracle import memory_path as O
+from test_gpu_path import make_projector
+from gpu_util import to_dev
+cfg = O.PathConfig(hidden=256, heads=2, mem_tokens=4, depth=2)
+proj = make_projector(cfg, O.make_weights(cfg, seed=72))
+sh = D.RowShardedMemory(proj)
+seg = to_dev(O.bf16_round(O.hash_normal_like((2, 196, 256), 7200)))
+with torch.no_grad():
+    sh.reset(); c1, s1 = sh.step(seg)
+    proj.memory_cache = []; c2, s2 = proj(seg)
+assert torch.equal(c1[-1], c2[-1])
+dist.barrier(); dist.destroy_process_group()
+print("NCCL_SMOKE_OK", torch.cuda.nccl.version() if hasattr(torch.cuda, "nccl") else "")
+"""
+
+
+def test_rccl_one_rank_smoke(tmp_path):
+    """No multi-GPU node is available to the builder: every multi-rank test above talks gloo on one shared card.  This at
+    least LOADS RCCL (`backend="nccl"` is RCCL on ROCm) in a one-rank group on this box and runs the collective forms the
+    multi-GPU paths use - `all_gather_into_tensor` IN PLACE (send = this rank's slice of the receive buffer, async), an async
+    all-reduce, the final-memory all-gather helper - plus a 1-rank RowShardedMemory step.  Not a scaling measurement."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MAVLM_ROOT=root)
+    r = subprocess.run([sys.executable, "-c", _NCCL_SMOKE], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0 and "NCCL_SMOKE_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -39,6 +39,40 @@ def test_attention_plans_match_the_oracle(lib):
             assert need == G * len(levels) * (QB * 128 + QB), (R, S, H)
 
 
+def test_streamk_unit_order_is_a_bijection_and_matches_the_oracle(lib):
+    """Round 4: the levelled stream-K schedule deals its units XCD-major (every XCD walks a contiguous range of the head-major
+    unit order).  Positions -> units must be a bijection (every unit exactly once, whole or cut), the C map and the oracle's
+    must agree, and at the bench launch (2 videos x 8 heads x 49 blocks of 256 queries) an XCD owns exactly two heads."""
+    for R, S, H in [(12544, 6272, 16), (12544, 6272, 8), (12544, 12544, 16), (12544, 125440, 8), (1568, 6272, 64), (8320, 4096, 8),
+                    (25088, 6272, 8), (100000, 4096, 3), (1100, 6400, 64)]:
+        G, QB, full, levels = O.streamk_plan(R, S, H)
+        if not G:
+            continue
+        units = -(-R // QB) * H
+        seen = []
+        for si in range(full):
+            for v in range(G):
+                u = lib.mavlm_attention_plan_unit(R, S, H, -1, si, v)
+                assert u == O.streamk_unit_of_round(G, full, levels, si, v), (R, S, H, si, v)
+                seen.append(u)
+        for lv, (k, base, n) in enumerate(levels):
+            for ul in range(n):
+                u = lib.mavlm_attention_plan_unit(R, S, H, lv, 0, ul)
+                assert u == O.streamk_unit_of_level(G, full, levels, lv, ul), (R, S, H, lv, ul)
+                seen.append(u)
+        assert sorted(seen) == list(range(units)), (R, S, H)
+        # the workgroups of one XCD (virtual ids [x G/8, (x+1) G/8)) walk a contiguous unit range
+        W = G // 8
+        for x in range(8):
+            mine = [O.streamk_unit_of_round(G, full, levels, si, v) for si in range(full) for v in range(x * W, (x + 1) * W)]
+            for lv, (k, base, n) in enumerate(levels):
+                mine += [O.streamk_unit_of_level(G, full, levels, lv, ul) for ul in range(n) if (ul << k) // W == x]
+            assert sorted(mine) == list(range(min(mine), max(mine) + 1)), (R, S, H, x)
+    G, QB, full, levels = O.streamk_plan(12544, 6272, 16)
+    assert (G, QB, full) == (256, 256, 3)
+    assert [O.streamk_unit_of_round(G, full, levels, 0, 32 * x) for x in range(8)] == [98 * x for x in range(8)]
+
+
 def test_wide_head_plans_match_the_oracle(lib):
     """head_dim 448: the levelled stream-K plan of the 32-query-wave kernel (more 128-query units than 256 workgroups; H up to
     the heads of a row batch) and the key splits of the small single-video grids; head_dim 256 (16-query kernel): splits only."""
