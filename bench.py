@@ -432,19 +432,9 @@ def run_replica(args, rank, world, local, device, dist_info):
         # single-video latency (one video, one stream, no row batch): what a request waits for.  Its engine is created
         # here (the pools above run row batches), and the card has just idled through the read-back of the event table:
         # warm up for ~0.1 s, then the best of 3 blocks of 10
-        single_ms = None
+        single_ms = single_graph_ms = None
         if not args.no_latency:
-            for _ in range(30):
-                step(one_video=True)
-            blocks = []
-            for _ in range(3):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    step(one_video=True)
-                torch.cuda.synchronize()
-                blocks.append((time.perf_counter() - t0) / 10 * 1e3)
-            single_ms = min(blocks)
+            single_ms, single_graph_ms = single_video_latency(model, arch, x, idx_cpu, device)
     # the fused dense + residual + LayerNorm epilogue exchanges row statistics between workgroups with a bounded spin: a
     # timeout (never seen) would mean a wrong result - fail loudly rather than print a number
     ln_status = {}
@@ -528,12 +518,60 @@ def run_replica(args, rank, world, local, device, dist_info):
         "alg_tflop_per_video": round(flops / 1e12, 3),
         "path_mfma_frac": round(B * flops / (med / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4),
         "single_video_latency_ms": round(single_ms, 3) if single_ms is not None else None,
+        "single_video_latency_graph_ms": round(single_graph_ms, 3) if single_graph_ms is not None else None,
         "kernel_timing_note": f"per-kernel numbers from an instrumented pass with ONE stream (a row batch of {NB} video(s)) in flight",
         "kernels": kernels,
         "fused_layernorm_exchange": ln_status or None,
     }
     out.update(extras)
     return out
+
+
+def single_video_latency(model, arch, x, idx_cpu, device):
+    """(eager ms, hipGraph-replay ms) for ONE video on one stream, no row batch - what a request behind the reference's own
+    entry point (batch 1, llava_arch.py:436) waits for.  Eager = `video_memory_tokens` (~45 launches); graph = the same launch
+    sequence captured once (`GraphedVideoMemory` on the model's own engine: what `enable_memory_graphs()` replays for a
+    repeated shape; the replay includes the copies into / out of the graph's static buffers).  Warm-up ~0.1 s, best of 3
+    blocks of 10 each."""
+    import torch
+    mem_ids = torch.tensor(arch.MEMORY_PROMPT_IDS, device=device)
+    frame_ids = torch.tensor(arch.FRAME_PROMPT_IDS, device=device)
+    out = None
+
+    def prompts():
+        return (torch.nn.functional.embedding(mem_ids, model.embed_tokens.weight),
+                torch.nn.functional.embedding(frame_ids, model.embed_tokens.weight))
+
+    def eager():
+        mp, fp = prompts()
+        return arch.video_memory_tokens(model, x, idx_cpu, mp, fp, model.image_newline)[0]
+
+    def best(fn):
+        for _ in range(30):
+            fn()
+        blocks = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            blocks.append((time.perf_counter() - t0) / 10 * 1e3)
+        return min(blocks)
+
+    e_ms = best(eager)
+    ref = eager().clone()
+    g = arch.GraphedVideoMemory(model, x.shape[0], idx_cpu, slot=model)
+    dst = torch.empty_like(ref)
+
+    def graphed():
+        mp, fp = prompts()
+        dst.copy_(g(x, mp, fp, model.image_newline))
+        return dst
+    g_ms = best(graphed)
+    assert torch.equal(graphed(), ref)                 # replay = eager launches, bit for bit
+    del g
+    return e_ms, g_ms
 
 
 def run_m8_extra(args, device, arch):
@@ -568,7 +606,13 @@ def run_m8_extra(args, device, arch):
     ts.sort()
     med = ts[len(ts) // 2]
     fl = algorithmic_flops(M=8)
-    return {"frames_per_s": round(args.steps * B * FRAMES / med, 1), "ms_per_step": round(med / args.steps * 1e3, 4),
+    lat = (None, None)
+    if not args.no_latency:
+        with torch.no_grad():
+            lat = single_video_latency(model, arch, xs[0], idx_cpu, device)
+    return {"single_video_latency_ms": round(lat[0], 3) if lat[0] else None,
+            "single_video_latency_graph_ms": round(lat[1], 3) if lat[1] else None,
+            "frames_per_s": round(args.steps * B * FRAMES / med, 1), "ms_per_step": round(med / args.steps * 1e3, 4),
             "videos_per_step": B, "streams": NS, "row_batch": NB, "mem_tokens": 8, "alg_tflop_per_video": round(fl / 1e12, 4),
             "path_mfma_frac": round(B * fl / (med / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4), "this_rank_only": True}
 

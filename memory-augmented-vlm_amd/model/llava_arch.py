@@ -532,9 +532,47 @@ class LlavaMetaForCausalLM:
                                    attention_mask, past_key_values, labels)
         if direct is not None:
             return direct
-        tokens, _ = video_memory_tokens(model, pooled, idx_cpu, mem_prompt, frame_prompt, model.image_newline,
-                                        with_frames=not drop)
+        tokens = self._video_tokens(model, pooled, idx_cpu, mem_prompt, frame_prompt, not drop)
         return splice_into_text(self, model, [tokens], input_ids, position_ids, attention_mask, past_key_values, labels)
+
+    # -- hipGraph replay for repeated video shapes (round 4) -------------------------------------------------------------
+    def enable_memory_graphs(self, capacity: int = 4):
+        """Inference: serve videos of a shape seen before ((frames, frame indices, with_frames) of the sampled video) by replaying
+        a captured hipGraph of the whole per-video launch sequence (`GraphedVideoMemory` on the model's own engine: PE add,
+        every chunk step, fuser + emit) instead of ~45 launches; the first occurrence of a shape runs eagerly, the second
+        captures.  Bit-identical to the eager path (`test_graph_capture_replay_bit_identical`).  `capacity` graphs are kept
+        (least recently used out); 0 switches the cache off.  Each graph holds static copies of its input frames and of its
+        token block."""
+        self._mem_graph_capacity = int(capacity)
+        self._mem_graphs = {}
+        self._mem_graph_seen = {}
+
+    def _video_tokens(self, model, pooled, idx_cpu, mem_prompt, frame_prompt, with_frames, out=None):
+        """video_memory_tokens, through the graph cache when it applies (inference, shape seen before)"""
+        cap = getattr(self, "_mem_graph_capacity", 0)
+        if (cap <= 0 or path_wants_grad(model, mem_prompt, frame_prompt, getattr(model, "image_newline", None))
+                or torch.cuda.is_current_stream_capturing()):
+            return video_memory_tokens(model, pooled, idx_cpu, mem_prompt, frame_prompt, model.image_newline, with_frames, out=out)[0]
+        key = (pooled.shape[0], tuple(int(i) for i in idx_cpu.tolist()), bool(with_frames), pooled.dtype, pooled.device.index)
+        g = self._mem_graphs.pop(key, None)
+        if g is None:
+            n = self._mem_graph_seen.get(key, 0) + 1
+            self._mem_graph_seen[key] = n
+            if len(self._mem_graph_seen) > 64:
+                self._mem_graph_seen.pop(next(iter(self._mem_graph_seen)))
+            if n < 2:
+                return video_memory_tokens(model, pooled, idx_cpu, mem_prompt, frame_prompt, model.image_newline, with_frames,
+                                           out=out)[0]
+            with torch.no_grad():
+                g = GraphedVideoMemory(model, pooled.shape[0], idx_cpu, with_frames, slot=model)
+            while len(self._mem_graphs) >= cap:
+                self._mem_graphs.pop(next(iter(self._mem_graphs)))
+        self._mem_graphs[key] = g                          # (re-inserted last: most recently used)
+        tokens = g(pooled, mem_prompt, frame_prompt, model.image_newline)
+        if out is not None:
+            out.copy_(tokens)
+            return out
+        return tokens.clone()                              # (the graph's static buffer is overwritten by its next replay)
 
     def _direct_emit(self, model, pooled, idx_cpu, mem_prompt, frame_prompt, with_frames, input_ids, position_ids,
                      attention_mask, past_key_values, labels):
@@ -560,8 +598,7 @@ class LlavaMetaForCausalLM:
         emb = torch.empty((1, total, pooled.shape[-1]), device=pooled.device, dtype=pooled.dtype)
         emb[0, :p] = text[:p].to(emb.dtype)
         emb[0, p + rows:] = text[p:].to(emb.dtype)
-        video_memory_tokens(model, pooled, idx_cpu, mem_prompt, frame_prompt, model.image_newline, with_frames,
-                            out=emb[0, p:p + rows])
+        self._video_tokens(model, pooled, idx_cpu, mem_prompt, frame_prompt, with_frames, out=emb[0, p:p + rows])
         if text.dtype != emb.dtype:
             emb = emb.to(text.dtype)
         out_labels = None

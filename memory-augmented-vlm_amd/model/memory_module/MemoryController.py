@@ -201,7 +201,7 @@ class _Engine:
         """Looks at the last posted probe if its copy has landed (never blocks unless `wait`); raises MavlmError when a launch
         of the fused dense + residual + LayerNorm kernel gave up waiting for a partner workgroup since the probe before."""
         evt = self._probe_evt
-        if evt is None:
+        if evt is None or torch.cuda.is_current_stream_capturing():     # (an event query is illegal inside a graph capture)
             return
         if wait:
             evt.synchronize()

@@ -457,6 +457,26 @@ def test_prepare_inputs_end_to_end_vs_oracle():
     assert arch.video_token_rows(64, 8) == tokens2.shape[0]
     np.testing.assert_array_equal(labs.cpu().numpy(), lab)
     assert bool(mask.all())
+    # hipGraph replay behind the reference's entry point (round 4, `enable_memory_graphs`): the first occurrence of a video
+    # shape runs eagerly, the second captures the whole launch sequence on the model's own engine, later ones replay it -
+    # all bit-identical to the eager result, for changing frame CONTENTS (the graph reads its static input copy)
+    lm.enable_memory_graphs(2)
+    with torch.no_grad():
+        for rep in range(4):
+            table.copy_(to_dev(O.bf16_round(O.hash_normal_like((F0, side * side, D), 920 + rep))))
+            lm._mem_graph_capacity = 0
+            want = lm.prepare_inputs_labels_for_multimodal(ids, None, am, None, labels, images, modalities=["video"])[4].clone()
+            lm._mem_graph_capacity = 2
+            got = lm.prepare_inputs_labels_for_multimodal(ids, None, am, None, labels, images, modalities=["video"])[4]
+            assert torch.equal(got, want), rep
+            assert len(lm._mem_graphs) == (1 if rep >= 1 else 0)
+        # a second shape gets its own graph; the eager path of the first shape still works next to them
+        images2 = [torch.arange(33, dtype=torch.float32, device="cuda").reshape(33, 1, 1, 1)]
+        outs2 = [lm.prepare_inputs_labels_for_multimodal(ids, None, am, None, labels, images2, modalities=["video"])[4].clone()
+                 for _ in range(3)]
+        assert torch.equal(outs2[0], outs2[1]) and torch.equal(outs2[1], outs2[2]) and len(lm._mem_graphs) == 2
+        lm._mem_graph_capacity = 0
+        assert torch.equal(lm.prepare_inputs_labels_for_multimodal(ids, None, am, None, labels, images, modalities=["video"])[4], want)
 
 
 def test_baseline_size_properties():

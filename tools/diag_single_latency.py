@@ -30,6 +30,7 @@ with torch.no_grad():
     for rnd in range(3):
         for on in (1, 0):
             lib.mavlm_set_fused_layernorm(on)
+            model.recurrent_memory_transformer._engine = None      # a context snapshots the hook when it is created
             for _ in range(5):
                 step()
             torch.cuda.synchronize()
