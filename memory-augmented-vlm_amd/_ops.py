@@ -411,6 +411,17 @@ def gru_sequence(xg_f32, whh, bhh_f32, hidden, ndir):
     return out
 
 
+WIDE_BWD_STREAMS = 4        # heads of the GEMM-composed wide-head backward in flight (1 = rounds 1-3: one head after the other)
+_WIDE_BWD_POOL = {}
+
+
+def _wide_bwd_streams(dev, n):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n)
+    if key not in _WIDE_BWD_POOL:
+        _WIDE_BWD_POOL[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return _WIDE_BWD_POOL[key]
+
+
 def attention_bwd_wide(q, k, v, o, do, lse2, heads, head_dim, scale, need_dq=True, need_dk=True, need_dv=True):
     """Gradients of `attention` for wide heads (head_dim 448: LLaVA-OneVision-7B).  The flash-style backward kernels
     hold a 128-wide head in registers; a 448-wide one does not fit, so ONE head's [R,S] scores are materialised at a
@@ -443,27 +454,46 @@ def attention_bwd_wide(q, k, v, o, do, lse2, heads, head_dim, scale, need_dq=Tru
         out[:S] = t
         return out
 
+    # Round 4: the heads are independent chains of small, short kernels (K = 448: 7 K-tiles per GEMM, 1-1.3 rounds of
+    # tiles, ~30 launches per head): one after the other they leave most of the chip idle between and inside launches.  Head h
+    # runs on side stream h % WIDE_BWD_STREAMS; the streams fork from the current one and join it at the end.
+    cur = torch.cuda.current_stream()
+    zero_bias(Sp, dev), zero_bias(hp, dev)                    # (cached constants: created on the current stream, before the fork)
+    ns = max(1, min(WIDE_BWD_STREAMS, H))
+    pool = _wide_bwd_streams(dev, ns) if ns > 1 and not torch.cuda.is_current_stream_capturing() else [cur]
+    for st in pool:
+        if st is not cur:
+            st.wait_stream(cur)
     for h in range(H):
-        sl = slice(h * hd, (h + 1) * hd)
-        qh, doh = q[:, sl], do[:, sl]
-        kc, vc = rows_padded(k[:, sl]), rows_padded(v[:, sl])
-        s32 = linear(qh, kc, zero_bias(Sp, dev), capi.EPI_F32)                       # [R, Sp] raw scores
-        p16 = torch.empty((R, Sp), device=dev, dtype=dt)
-        capi.check(lib.mavlm_attention_probs(s32.data_ptr(), Sp, lse2[h].data_ptr(), p16.data_ptr(), Sp, R, Sp, S,
-                                             float(scale), code, stream_ptr()), "mavlm_attention_probs")
-        if need_dv:
-            dvh = linear(transpose(p16), transpose(doh, out_rows=hp), zero_bias(hp, dev))        # [Sp, hp]
-            dv[:, sl] = dvh[:S, :hd]
-        if need_dq or need_dk:
-            dp32 = linear(doh, vc, zero_bias(Sp, dev), capi.EPI_F32)
-            ds16 = torch.empty((R, Sp), device=dev, dtype=dt)      # from the UNROUNDED probability, as the flash kernels
-            capi.check(lib.mavlm_attention_dscores(s32.data_ptr(), Sp, dp32.data_ptr(), Sp, lse2[h].data_ptr(),
-                                                   delta[h].data_ptr(), ds16.data_ptr(), Sp, R, Sp, S, float(scale), code,
-                                                   stream_ptr()), "mavlm_attention_dscores")
-            if need_dq:
-                dqh = linear(ds16, transpose(kc, out_rows=hp), zero_bias(hp, dev))               # [R, hp]
-                dq[:, sl] = dqh[:, :hd]
-            if need_dk:
-                dkh = linear(transpose(ds16), transpose(qh, out_rows=hp), zero_bias(hp, dev))    # [Sp, hp]
-                dk[:, sl] = dkh[:S, :hd]
+      with torch.cuda.stream(pool[h % len(pool)]):
+          sl = slice(h * hd, (h + 1) * hd)
+          qh, doh = q[:, sl], do[:, sl]
+          kc, vc = rows_padded(k[:, sl]), rows_padded(v[:, sl])
+          s32 = linear(qh, kc, zero_bias(Sp, dev), capi.EPI_F32)                       # [R, Sp] raw scores
+          p16 = torch.empty((R, Sp), device=dev, dtype=dt)
+          capi.check(lib.mavlm_attention_probs(s32.data_ptr(), Sp, lse2[h].data_ptr(), p16.data_ptr(), Sp, R, Sp, S,
+                                               float(scale), code, stream_ptr()), "mavlm_attention_probs")
+          if need_dv:
+              dvh = linear(transpose(p16), transpose(doh, out_rows=hp), zero_bias(hp, dev))        # [Sp, hp]
+              dv[:, sl] = dvh[:S, :hd]
+          if need_dq or need_dk:
+              dp32 = linear(doh, vc, zero_bias(Sp, dev), capi.EPI_F32)
+              ds16 = torch.empty((R, Sp), device=dev, dtype=dt)      # from the UNROUNDED probability, as the flash kernels
+              capi.check(lib.mavlm_attention_dscores(s32.data_ptr(), Sp, dp32.data_ptr(), Sp, lse2[h].data_ptr(),
+                                                     delta[h].data_ptr(), ds16.data_ptr(), Sp, R, Sp, S, float(scale), code,
+                                                     stream_ptr()), "mavlm_attention_dscores")
+              if need_dq:
+                  dqh = linear(ds16, transpose(kc, out_rows=hp), zero_bias(hp, dev))               # [R, hp]
+                  dq[:, sl] = dqh[:, :hd]
+              if need_dk:
+                  dkh = linear(transpose(ds16), transpose(qh, out_rows=hp), zero_bias(hp, dev))    # [Sp, hp]
+                  dk[:, sl] = dkh[:S, :hd]
+    for st in pool:
+        if st is not cur:
+            cur.wait_stream(st)
+    if len(pool) > 1:                                          # (tensors of the current stream used on the side streams)
+        for t in (dq, dk, dv, q, k, v, do, lse2, delta):
+            if t is not None:
+                for st in pool:
+                    t.record_stream(st)
     return dq, dk, dv

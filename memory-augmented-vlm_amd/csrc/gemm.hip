@@ -266,8 +266,18 @@ static bool use_256(const mavlm_gemm_args& g) {
 // element sums its K products in the same order in all three kernels (bit-identical results).
 static bool use_128x256(const mavlm_gemm_args& g) {
   if (!mavlm_gemm128_supported(g)) return false;
+  const bool f32out = g.epilogue == MAVLM_EPI_RES_F32 || g.epilogue == MAVLM_EPI_F32;
+  if (((uintptr_t)g.C & 15) || (f32out ? (g.ldc & 3) : (g.ldc & 7))) return false;     // 16-byte stores per lane
   if (g_mavlm_gemm_tile == 129) return true;
-  return false;
+  if (g_mavlm_gemm_tile != 0) return false;
+  // Automatic choice (measured, tools/diag_gemm128_small.py): the mid-size grids - too few 256-row tiles to fill the chip
+  // (< 192: the 128^2 kernel's territory) but at least ~190 tiles of 128 x 256, i.e. most CUs busy with one 4-wave
+  // workgroup each - run 5-12 % faster here than on the 128^2 kernel (half the B traffic per flop); e.g. the MLP-up
+  // projection of a single video at 8 memory tokens (1568 x 4096 x 1024).  Everywhere else the 256-row kernels win: two
+  // 128 x 256 workgroups per CU stage 1.5 x the operand bytes of one 256 x 256 workgroup, and L2 -> LDS staging
+  // (~12.8 TB/s chip-wide under MFMA load) is what bounds these loops.
+  const long t256 = (long)((g.M + 255) / 256) * (g.N / 256), t128 = (long)((g.M + 127) / 128) * (g.N / 256);
+  return t256 < 192 && t128 >= 192;
 }
 
 int mavlm_gemm_splits(int M, int N, int K, int epilogue, int ldc) {
@@ -276,10 +286,26 @@ int mavlm_gemm_splits(int M, int N, int K, int epilogue, int ldc) {
   // at most one 128^2 tile per two CUs and a long contraction.  (Measured: extending this to grids of up to 448 tiles,
   // e.g. the 364-tile GEMMs of R = 1568 at the OneVision-7B width, LOSES 4 % end to end - the partial planes cost more
   // than the idle CUs.)
-  if (tiles > 128 || K < 2048) return 1;
+  if (tiles > 128 || K < 2048) {
+    // Round 4: a LONG contraction over a grid that fills 1/4 - 1/2 of the chip with 256-row tiles (the 4D -> D projection of
+    // a single video at the OneVision-7B width: 1568 x 3584 x 14336 = 98 tiles x 224 K-tiles): two (up to four) K ranges on
+    // the 256-row kernel, 196+ workgroups of 112 K-tiles each + one reduce pass, instead of 364 tiles of 128^2 walking all
+    // 224 K-tiles (measured 193 -> ~150 us).  Only from K = 8192: below, the reduce costs what the split saves.
+    const long t256 = (long)((M + 255) / 256) * (N / 256);
+    if (K >= 8192 && N % 256 == 0 && t256 >= 64 && t256 <= 128) {
+      const int s2 = (int)(256 / t256);
+      return s2 > 4 ? 4 : (s2 < 2 ? 1 : s2);
+    }
+    return 1;
+  }
   int splits = K / 1024;
   if (splits > 4) splits = 4;
   return splits < 2 ? 1 : splits;
+}
+// which kernel runs the split planes of mavlm_gemm_splits: the 256-row one for the round-4 rule, else the 128^2 one
+static bool splits_on_256(int M, int N, int K) {
+  const long tiles = (long)((M + BM - 1) / BM) * (N / BN);
+  return tiles > 128 || K < 2048;
 }
 
 size_t mavlm_gemm_split_ws_floats(int M, int N, int K, int epilogue, int ldc) {
@@ -329,7 +355,8 @@ hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s)
       mavlm_gemm_args p = g;
       p.C = g.splitk_ws;
       p.epilogue = MAVLM_EPI_F32;
-      hipError_t e = dtype == MAVLM_F16 ? launch_splitk<F16>(p, splits, ksplit, s) : launch_splitk<BF16>(p, splits, ksplit, s);
+      hipError_t e = splits_on_256(g.M, g.N, g.K) ? mavlm_launch_gemm256_splitk(p, splits, ksplit, dtype, s)
+                     : (dtype == MAVLM_F16 ? launch_splitk<F16>(p, splits, ksplit, s) : launch_splitk<BF16>(p, splits, ksplit, s));
       if (e != hipSuccess) return e;
       // the planes are pure partial products (the kernel skips its bias when ksplit > 0); bias + epilogue once, here
       return mavlm_launch_splitk_reduce(g.splitk_ws, splits, (size_t)g.M * g.N, g.C, dtype, s, g.bias, g.N, g.epilogue);
@@ -340,8 +367,8 @@ hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s)
   const double osz = g.epilogue == MAVLM_EPI_RES_F32 ? 6.0 : (g.epilogue == MAVLM_EPI_F32 ? 4.0 : 2.0);
   mavlm_prof_scope prof(MAVLM_K_GEMM, 2.0 * g.M * (double)g.N * g.K,
                         2.0 * ((double)g.M * g.K + (double)g.N * g.K) + osz * g.M * (double)g.N, s);
+  if (use_128x256(g)) return mavlm_launch_gemm128(g, dtype, s);
   if (use_256(g)) {
-    if (use_128x256(g)) return mavlm_launch_gemm128(g, dtype, s);
     // persistent kernel when workgroups get more than one tile each (its pipeline never drains between tiles);
     // with at most one tile per CU the plain kernel is the same work with less code in flight
     const int rows = mavlm_gemm_tile_rows(g.M, g.N);

@@ -1,39 +1,36 @@
 // 128x256x64 MFMA GEMM with TWO INDEPENDENT WORKGROUPS PER CU (round 4).
 // Same contract as gemm_tn_kernel (gemm.hip): C[M,N] = epi(A[M,K] . W[N,K]^T + bias), nn.Linear layout.
 //
-// Why (DESIGN.md "GEMM"): the 256x256 kernels (gemm256.hip, gemm256p.hip) run one 8-wave workgroup per CU and whole grids
-// in lock-step, so every prologue (first tiles from L2 / HBM) and every epilogue (bias / GELU / fused LayerNorm exchange /
-// stores) is exposed - 9-10 us per round at K = 1024 - and a grid of 1.53 or 1.75 rounds of tiles costs 2.  Here a
-// workgroup is 4 waves on a 128x256 tile at <= 80 KiB of LDS and <= 256 registers: two of them share a CU, one wave of
-// each per SIMD.  They are independent (no common barrier), so one workgroup's K loop runs under the other's prologue,
-// epilogue or exchange wait, and the grid is cut twice as fine (R = 12 544 = 98 x 128 rows: no ragged row block).
+// Why it exists, and what it turned out to be good for.  The 256x256 kernels (gemm256.hip, gemm256p.hip)
+// run one 8-wave workgroup per CU and whole grids in lock-step: prologues and epilogues (bias / GELU / the fused LayerNorm
+// exchange / stores) are exposed and a grid of 1.53 or 1.75 rounds of tiles costs 2.  Here a workgroup is 4 waves on a
+// 128x256 tile at 80 KiB of LDS and <= 256 registers: two of them share a CU (one wave of each per SIMD), independent of
+// each other, so one's K loop runs under the other's epilogue and the grid is cut twice as fine.  Both effects are real
+// (the GELU launch costs +7 % over ReLU here against +17 % on the 256-row kernel) - but two 128x256 tiles stage 1.5 x the
+// operand bytes of one 256x256 tile per flop, and L2 -> LDS staging (~12.8 TB/s chip-wide under MFMA load: 48-50 GB/s
+// per CU in every GEMM loop measured in this repository, the vendor library's included) is what bounds these loops: this
+// kernel tops out at ~1 120-1 165 TFLOP/s in its K loop where the 256-row one reaches ~1 430.  It is therefore the
+// automatic choice only for mid-size grids (gemm.hip: use_128x256) and a tuning hook (mavlm_set_gemm_tile(129))
+// elsewhere; its results are bit-identical to the other kernels' (same K order per output element).
 //
 // Structure:
 //   * 4 waves side by side along N: wave w owns all 128 rows x columns [64w, 64w+64) = 8x4 MFMA 16x16x32 tiles
 //     (128 accumulator registers).  A K-tile (64 deep) is 4 phases of 16 MFMAs in Gray order over (row half, column half):
-//     (lo,0) (lo,1) (hi,1) (hi,0) - one operand changes per phase.
+//     even K-tiles (lo,c0) (lo,c1) (hi,c1) (hi,c0), odd ones (lo,c1) (lo,c0) (hi,c0) (hi,c1) - one operand changes per
+//     phase, and the operand a phase needs NEXT always goes into the register set that died in the phase before:
+//         P1: read second B half of kt        P2: read A_hi(kt)        P3: read A_lo(kt+1)        P4: read first B half of kt+1
+//     every fragment read is issued one phase ahead of its MFMAs (in-wave software pipeline; the wave waits
+//     lgkmcnt(0) only AFTER its 16 MFMAs).  96 fragment registers: alo, ahi, two B halves.
 //   * The B operand of a wave (its 64 weight rows) is PRIVATE to the wave: it stages it itself (LDS-DMA) into its own
-//     12 KiB ring and needs no barrier for it - only its own counted vmcnt.  The A operand (128 rows) is shared: two
-//     64-row sub-pieces per K-tile in a 3-slot ring (24 KiB), each wave stages a quarter of every sub-piece.
-//     72 KiB per workgroup.
-//   * Rings are recycled at sub-piece granularity (idx = 2 kt + {0, 1}, slot = idx % 3), so a sub-piece is re-staged
-//     as soon as it is dead and every DMA has 4-6 phases to land:
-//         P1: wait own vmcnt(N1); read A_lo(kt), Bq0(kt), Bq1(kt);           MFMA (lo,0); barrier 1
-//         P2: DMA A_hi(kt+1) -> slot of A_lo(kt), Bq1(kt+1) -> slot of Bq0(kt); read A_hi(kt);   MFMA (lo,1)
-//         P3: DMA Bq0(kt+2) -> slot of Bq1(kt);                              MFMA (hi,1); wait own vmcnt(N2); barrier 2
-//         P4: DMA A_lo(kt+2) -> slot of A_hi(kt); [read A_lo(kt+1) ahead];   MFMA (hi,0)
-//     Two barriers per K-tile (64 MFMAs per wave), two counted waits, never vmcnt(0) inside the loop.
-//   * Hazards.  LDS-DMA data is ordered for a ds_read only by the issuing wave's vmcnt (+ a barrier for other waves).
-//       RAW A_hi(kt): issued in P2 of kt-1 (first in that phase).  Every wave waits vmcnt(N1) at the top of P1 of kt
-//            (the DMAs issued after it: Bq1(kt) in the same phase - needed as well, so it is included in the wait -, Bq0(kt+1)
-//            4, A_lo(kt+1) 2: N1 = 6), then passes barrier 1 before the read in P2.
-//       RAW A_lo(kt+1): issued in P4 of kt-1; waited vmcnt(N2) before barrier 2 of kt (after it: A_hi(kt+1) 2, Bq1(kt+1) 4,
-//            Bq0(kt+2) 4: N2 = 10), read in P4 of kt at the earliest.  Bq0(kt+1) (issued just before it) is covered too.
-//       RAW Bq1(kt): the wave's own data: covered by N1.
-//       WAR slot of A_lo(kt) (re-staged in P2): all its reads are retired by the lgkmcnt(0) before the MFMAs of P1, every
-//            wave passes barrier 1 after that.  Slot of A_hi(kt) (re-staged in P4): reads retired before the MFMAs of P3,
-//            barrier 2 after them.  B slots: own reads retired (lgkmcnt(0) in P1) before the own DMA in P2 / P3.
-//     The last K-tiles issue fewer DMAs; their waits count what is really behind (N1, N2 below).
+//     3-slot ring of 4 KiB column halves and needs no barrier for it - only its own counted vmcnt.  The A operand (128
+//     rows) is shared: {A_lo, A_hi} of two K-tiles = 4 slots of 8 KiB, each wave stages a quarter of every piece.
+//   * ONE barrier per K-tile (64 MFMAs per wave), at the top of P2: before it every wave has waited for its parts of
+//     A_hi(kt) and A_lo(kt+1) (RAW: both are read behind it) and has retired its reads of A_hi(kt-1) and A_lo(kt) (WAR:
+//     their slots are re-staged right behind it with A_hi(kt+1), A_lo(kt+2) - a whole K-tile of lead).  B slots: the
+//     wave's own reads are retired (end of the phase that issued them) before its own DMA re-stages the slot.
+//   * DMA issue per K-tile and wave: P1 4 (second half of kt+1), P2 2 + 2 (A), P3 4 (first half of kt+2); three counted
+//     waits, never vmcnt(0) inside the loop: P1 vmcnt(8), P2 vmcnt(8), P4 vmcnt(12) (the counts of the last two K-tiles
+//     follow what is really behind them, see ktile()).  8-12 KiB per wave in flight.
 //   * Operand images: rows of 128 B, XOR-swizzled through the per-lane SOURCE address (chunk c of row r is stored at chunk
 //     c ^ ((r >> 1) & 7)), conflict-free ds_read_b128 fragments; buffer-load DMA: one descriptor per operand, two lane
 //     offsets per operand (odd / even 8-row group), row group + K-tile in the scalar offset.
@@ -45,9 +42,12 @@ namespace {
 constexpr int BM1 = 128, BN1 = 256, BK1 = 64;
 constexpr int ASUB = 64 * BK1 * 2;                 // 8 KiB: 64 rows x 128 B
 constexpr int BSUB = 32 * BK1 * 2;                 // 4 KiB: 32 weight rows x 128 B
-constexpr int A_RING = 3 * ASUB;                   // 24 KiB
+constexpr int A_RING = 4 * ASUB;                   // 32 KiB: {A_lo, A_hi} of two K-tiles
 constexpr int B_RING = 3 * BSUB;                   // 12 KiB per wave
-constexpr int GEMM128_LDS = A_RING + 4 * B_RING;   // 72 KiB -> two workgroups per CU (160 KiB)
+constexpr int GEMM128_LDS = A_RING + 4 * B_RING;   // 80 KiB -> two workgroups per CU (160 KiB)
+
+template <int V>
+struct IC1 { static constexpr int value = V; };
 
 #define MAVLM_BAR1()                         \
   do {                                       \
@@ -55,9 +55,13 @@ constexpr int GEMM128_LDS = A_RING + 4 * B_RING;   // 72 KiB -> two workgroups p
     __builtin_amdgcn_s_barrier();            \
     asm volatile("" ::: "memory");           \
   } while (0)
+// lgkmcnt(0) through the BUILTIN (imm 0xC07F: vmcnt 63, expcnt 7, lgkmcnt 0): hipcc's own wait-count pass sees it.  With an
+// inline-asm wait the pass still believes the fragment reads of the previous phase outstanding and, across the loop's back
+// edge, puts an lgkmcnt(0) in front of the next phase's MFMAs - i.e. waits for the reads that phase has just issued for
+// a LATER phase (measured in the first build of this loop: every K-tile stalled on its own prefetch).
 #define MAVLM_LGKM0_1()                                        \
   do {                                                         \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                        \
     __builtin_amdgcn_sched_barrier(0);                         \
   } while (0)
 
@@ -171,53 +175,80 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const uint16_t* __restr
     __builtin_amdgcn_s_setprio(0);                                                          \
   }
 
-  // ---- prologue (the issue order of the steady state): Bq0(0) A_lo(0) | A_hi(0) Bq1(0) | Bq0(1) | A_lo(1)
-  // ring slots: sub-piece idx = 2 kt + {0, 1} -> slot idx % 3
-  dma_b(0, 0, 0);
-  dma_a(0, 0, 0);
-  dma_a(1, 1, 0);
-  dma_b(1, 1, 0);
+  // ---- software pipeline (see the header).  Register sets: alo / ahi = A rows 0-63 / 64-127, bf[0..1] = this wave's
+  // columns 0-31, bf[2..3] = columns 32-63 - always; an even K-tile walks (lo,c0) (lo,c1) (hi,c1) (hi,c0), an odd one
+  // (lo,c1) (lo,c0) (hi,c0) (hi,c1), so that the operand a phase loads for a later phase is always a dead register set.
+  // B pieces in CONSUMPTION order: first(kt) = column half (kt & 1), second(kt) = the other; ring index 2 kt + {0, 1}.
+  auto bq_first = [&](int kt) { return kt & 1; };
+  // wave-uniform waits with literal counts
+#define MAVLM_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+  // prologue: first(0) A_lo(0) | second(0) | A_hi(0) A_lo(1) | first(1)   (the issue order of the steady state)
+  dma_b(0, 0, 0);                               // idx 0 -> slot 0: columns 0-31 of K-tile 0
+  dma_a(0, 0, 0);                               // A_lo(0) -> A slot 0
+  dma_b(1, 1, 0);                               // idx 1 -> slot 1: columns 32-63 of K-tile 0
+  dma_a(1, 1, 0);                               // A_hi(0) -> A slot 1
   if (nk > 1) {
-    dma_b(2, 0, 1);
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");       // Bq0(0), A_lo(0) landed
+    dma_a(2, 0, 1);                             // A_lo(1) -> A slot 2
+    dma_b(2, 1, 1);                             // idx 2 = first(1) -> slot 2: columns 32-63 of K-tile 1
+    MAVLM_VMCNT(12);                            // first(0), A_lo(0) landed (behind them: 4 + 2 + 2 + 4)
   } else {
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    MAVLM_VMCNT(6);
   }
   MAVLM_BAR1();
-  if (nk > 1) dma_a(2, 0, 1);
+  read_a(alo, 0);
+  read_b(0, 0);
+  MAVLM_LGKM0_1();
 
-  int s0 = 0;                                   // slot of idx 2 kt (A_lo / Bq0 of this K-tile); idx 2 kt + 1 -> s0 + 1 mod 3
-  for (int kt = 0; kt < nk; ++kt) {
-    const int s1 = s0 == 2 ? 0 : s0 + 1;        // A_hi(kt), Bq1(kt)
-    const int s2 = s1 == 2 ? 0 : s1 + 1;        // A_lo(kt+1), Bq0(kt+1)
-    // -------- P1
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    read_a(alo, s0);
-    read_b(0, s0);
-    read_b(1, s1);
+  // one K-tile.  PAR = kt & 1 (compile time): which column half goes first.  sb = ring slot of idx 2 kt (first(kt)).
+  auto ktile = [&](auto par, int kt, int sb) {
+    constexpr int PAR = decltype(par)::value;
+    constexpr int C0 = PAR, C1 = PAR ^ 1;                   // column half of P1 / P4, and of P2 / P3
+    const int sb1 = sb == 2 ? 0 : sb + 1;                   // slot of idx 2 kt + 1 (second(kt))
+    const int sb2 = sb1 == 2 ? 0 : sb1 + 1;                 // slot of idx 2 kt + 2 (first(kt+1))
+    const int sa = 2 * PAR;                                 // A slots of this K-tile: sa (lo), sa + 1 (hi); the other pair: kt +- 1
+    const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+    // -------- P1: (lo, C0).  second(kt) landed (issued in P1 of kt-1; behind it A_hi(kt) [+ A_lo(kt+1), first(kt+1)])
+    if (n1) MAVLM_VMCNT(8);
+    else MAVLM_VMCNT(2);
+    if (n1) dma_b(sb, C0, kt + 1);                          // second(kt+1) = column half C0 -> slot of first(kt) (its reads retired)
+    read_b(C1, sb1);
+    if constexpr (C0 == 0) MAVLM_QUAD(alo, 0, 0) else MAVLM_QUAD(alo, 0, 1)
     MAVLM_LGKM0_1();
-    MAVLM_QUAD(alo, 0, 0)
+    // -------- P2: (lo, C1).  A_hi(kt), A_lo(kt+1) landed for every wave; all reads of A_hi(kt-1), A_lo(kt) retired
+    if (n1) MAVLM_VMCNT(8);
+    else MAVLM_VMCNT(0);
     MAVLM_BAR1();
-    // -------- P2
-    if (kt + 1 < nk) {
-      dma_a(s0, 1, kt + 1);                     // A_hi(kt+1): idx 2 kt + 3 -> slot of idx 2 kt
-      dma_b(s0, 1, kt + 1);                     // Bq1(kt+1)
+    if (n1) dma_a(3 - sa, 1, kt + 1);                       // A_hi(kt+1) -> slot of A_hi(kt-1)
+    if (n2) dma_a(sa, 0, kt + 2);                           // A_lo(kt+2) -> slot of A_lo(kt)
+    read_a(ahi, sa + 1);
+    if constexpr (C1 == 0) MAVLM_QUAD(alo, 0, 0) else MAVLM_QUAD(alo, 0, 1)
+    MAVLM_LGKM0_1();
+    // -------- P3: (hi, C1)
+    if (n2) dma_b(sb1, C0, kt + 2);                         // first(kt+2) = column half C0 -> slot of second(kt) (reads retired in P1)
+    if (n1) read_a(alo, 2 - sa);                            // A_lo(kt+1)
+    if constexpr (C1 == 0) MAVLM_QUAD(ahi, 1, 0) else MAVLM_QUAD(ahi, 1, 1)
+    MAVLM_LGKM0_1();
+    // -------- P4: (hi, C0).  first(kt+1) landed (issued in P3 of kt-1; behind it: P1 4, P2 2 [+ 2], P3 [4] of this K-tile)
+    if (n1) {
+      if (n2) MAVLM_VMCNT(12);
+      else MAVLM_VMCNT(6);
+      read_b(C1, sb2);                                      // first(kt+1) = column half C1 (dead since P3)
     }
-    read_a(ahi, s1);
-    MAVLM_QUAD(alo, 0, 1)
-    // -------- P3
-    if (kt + 2 < nk) dma_b(s1, 0, kt + 2);      // Bq0(kt+2): idx 2 kt + 4 -> slot of idx 2 kt + 1
+    if constexpr (C0 == 0) MAVLM_QUAD(ahi, 1, 0) else MAVLM_QUAD(ahi, 1, 1)
     MAVLM_LGKM0_1();
-    MAVLM_QUAD(ahi, 1, 1)
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    MAVLM_BAR1();
-    // -------- P4
-    if (kt + 2 < nk) dma_a(s1, 0, kt + 2);      // A_lo(kt+2)
-    MAVLM_QUAD(ahi, 1, 0)
-    s0 = s2;
+  };
+  {
+    int sb = 0;                                             // slot of idx 2 kt; + 2 per K-tile (mod 3)
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      ktile(IC1<0>{}, kt, sb);
+      sb = sb == 0 ? 2 : sb - 1;
+      ktile(IC1<1>{}, kt + 1, sb);
+      sb = sb == 0 ? 2 : sb - 1;
+    }
+    if (kt < nk) ktile(IC1<0>{}, kt, sb);
   }
+#undef MAVLM_VMCNT
 #undef MAVLM_QUAD
 
   const int wn = wave;

@@ -81,12 +81,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
                                                          const float* __restrict__ bias,
                                                          const uint16_t* __restrict__ res, int ldr,
                                                          void* __restrict__ Cout, int ldc, int M, int N, int K,
-                                                         int c_rpb, int c_nb, long long c_bs, mavlm_ln_epilogue ln) {
+                                                         int c_rpb, int c_nb, long long c_bs, mavlm_ln_epilogue ln,
+                                                         int ksplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+  // split-K (round 4; EPI_F32 only): blockIdx.y owns the K range [y ksplit, (y + 1) ksplit) and its own fp32 plane of the
+  // output - pure partial products, bias and epilogue are applied once by splitk_reduce_kernel.  For the long contractions
+  // over few 256-row tiles (the 4D -> D projection of a single video at the OneVision-7B width: 98 tiles x 224 K-tiles).
+  if (ksplit > 0) {
+    const int kz = (int)blockIdx.y * ksplit;
+    A += kz;
+    W += kz;
+    Cout = (void*)((float*)Cout + (size_t)blockIdx.y * (size_t)M * ldc);
+    K = (K - kz < ksplit) ? K - kz : ksplit;
+  }
   constexpr int MHALF = 64 + 16 * MT1;        // rows per wave group (= valid rows of an A half-tile slot)
   constexpr int BMT = 2 * MHALF;              // workgroup tile height
 
@@ -413,7 +424,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
   };
   f32x4 bv[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(bias + n0 + wn * 64 + j * 16 + fq * 4);
+  for (int j = 0; j < 4; ++j)
+    bv[j] = ksplit > 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(bias + n0 + wn * 64 + j * 16 + fq * 4);
 #pragma unroll
   for (int i = 0; i < 4 + MT1; ++i) {
     const int m = m0 + wm * MHALF + i * 16 + fr;
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
 }
 
 template <typename T, int EPI, int MT1>
-hipError_t launch256h(const mavlm_gemm_args& g, hipStream_t s) {
+hipError_t launch256h(const mavlm_gemm_args& g, hipStream_t s, int splits = 1, int ksplit = 0) {
   auto kern = gemm256_kernel<T, EPI, MT1>;
   constexpr int BMT = 2 * (64 + 16 * MT1);
   static mavlm_per_device_once once;
@@ -453,9 +465,9 @@ hipError_t launch256h(const mavlm_gemm_args& g, hipStream_t s) {
     if (e != hipSuccess) return e;
   }
   const int ntm = (g.M + BMT - 1) / BMT, ntn = g.N / BN2;
-  hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(512), GEMM256_LDS, s, (const uint16_t*)g.A, g.lda, (const uint16_t*)g.W,
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn, splits), dim3(512), GEMM256_LDS, s, (const uint16_t*)g.A, g.lda, (const uint16_t*)g.W,
                      g.ldw, g.bias, (const uint16_t*)g.res, g.ldr, g.C, g.ldc, g.M, g.N, g.K, g.c_rpb, g.c_nb > 0 ? g.c_nb : 1,
-                     (long long)g.c_bstride, g.ln);
+                     (long long)g.c_bstride, g.ln, ksplit);
   return hipGetLastError();
 }
 
@@ -515,6 +527,12 @@ int mavlm_gemm_tile_rows(int M, int N) {
   const long t256 = (long)((M + 255) / 256) * ntn, t224 = (long)((M + 223) / 224) * ntn;
   const long c256 = ((t256 + 255) / 256) * 256, c224 = ((t224 + 255) / 256) * 224;
   return c224 < c256 ? 224 : 256;
+}
+
+// split-K form: g.C = [splits][M][N] fp32 planes (ldc == N), g.epilogue ignored (EPI_F32, no bias); 256-row tiles
+hipError_t mavlm_launch_gemm256_splitk(const mavlm_gemm_args& g, int splits, int ksplit, int dtype, hipStream_t s) {
+  if (splits < 1 || ksplit <= 0 || ksplit % BK2 != 0 || g.ldc != g.N || (double)g.M * g.N * 4.0 * splits >= 1.7e10) return hipErrorInvalidValue;
+  return dtype == MAVLM_F16 ? launch256h<F16, MAVLM_EPI_F32, 4>(g, s, splits, ksplit) : launch256h<BF16, MAVLM_EPI_F32, 4>(g, s, splits, ksplit);
 }
 
 hipError_t mavlm_launch_gemm256(const mavlm_gemm_args& g, int dtype, hipStream_t s) {

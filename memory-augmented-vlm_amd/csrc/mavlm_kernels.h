@@ -47,6 +47,7 @@ size_t mavlm_gemm_split_ws_floats(int M, int N, int K, int epilogue, int ldc);
 // 256x256x64 8-wave kernel (gemm256.hip); mavlm_launch_gemm picks it when the grid fills the chip
 bool mavlm_gemm256_supported(const mavlm_gemm_args& g);
 hipError_t mavlm_launch_gemm256(const mavlm_gemm_args& g, int dtype, hipStream_t s);
+hipError_t mavlm_launch_gemm256_splitk(const mavlm_gemm_args& g, int splits, int ksplit, int dtype, hipStream_t s);
 // persistent 256x256x64 kernel (gemm256p.hip): no residual epilogue, K >= 128
 bool mavlm_gemm256p_supported(const mavlm_gemm_args& g);
 hipError_t mavlm_launch_gemm256p(const mavlm_gemm_args& g, int dtype, hipStream_t s);

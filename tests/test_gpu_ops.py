@@ -127,6 +127,38 @@ def test_gemm_128x256_two_workgroups_per_cu_kernel():
         lib.mavlm_set_gemm_tile(0)
 
 
+def test_gemm_splitk_on_256_row_tiles():
+    """Round 4: a long contraction (K >= 8192) over a grid of 64-128 tiles of 256 rows - the 4D -> D projection of a single
+    video at the OneVision-7B width - is split into K ranges on the 256-row kernel (blockIdx.y, fp32 planes) and reduced
+    once.  Exact on integer data for every epilogue the reduce applies, ragged M, and the plan is what the workspace query
+    reports."""
+    lib = capi.lib()
+    M, N, K = 1568 + 5, 2560, 8192
+    assert lib.mavlm_linear_ws_floats(M, N, K, capi.EPI_F32, N) == 3 * M * N        # 7 x 10 = 70 tiles -> 3 K ranges
+    assert lib.mavlm_linear_ws_floats(M, N, 4096, capi.EPI_F32, N) == 0
+    A = _int_mat((M, K), 41, -2, 2)
+    W = _int_mat((N, K), 42, -2, 2)
+    b = _int_mat((N,), 43).astype(np.float32)
+    ref = A @ W.T + b
+    a_, w_, b_ = to_dev(A), to_dev(W), f32_dev(b)
+    for _ in range(2):
+        np.testing.assert_array_equal(to_np(ops.linear(a_, w_, b_, capi.EPI_F32)), ref)
+    np.testing.assert_array_equal(to_np(ops.linear(a_, w_, b_, capi.EPI_RELU)), O.bf16_round(np.maximum(ref, 0)))
+    np.testing.assert_array_equal(to_np(ops.linear(a_, w_, b_, capi.EPI_BIAS)), O.bf16_round(ref))
+    # the 7B shape itself, random data, against the unsplit kernel (fp32 partial planes: another summation order)
+    M, N, K = 1568, 3584, 14336
+    a = to_dev(O.bf16_round(O.hash_normal_like((M, K), 44)))
+    w = to_dev(O.bf16_round(O.hash_uniform((N, K), 45, -0.01, 0.01)))
+    bb = f32_dev(O.hash_uniform((N,), 46, -0.1, 0.1))
+    got = ops.linear(a, w, bb, capi.EPI_F32).clone()
+    try:
+        lib.mavlm_set_gemm_tile(256)          # (a forced tile disables the split plan)
+        want = ops.linear(a, w, bb, capi.EPI_F32).clone()
+    finally:
+        lib.mavlm_set_gemm_tile(0)
+    assert O.rel_l2(to_np(got), to_np(want)) < 1e-5
+
+
 def test_gemm_256_tile_kernels_with_l2_resident_weights():
     """The 256-column-tile kernels re-stage a B half-tile (LDS-DMA) in the barrier interval in which the other wave group
     retires its last reads of it; the margin is the DMA's latency (gemm256.hip, hazard table: WAR).  The shortest latency
