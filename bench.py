@@ -465,7 +465,7 @@ def run_replica(args, rank, world, local, device, dist_info):
     att_ms = ms[di] + ms[fi] + ms[mi]
     att_weighted = (fl[di] + fl[fi]) / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0
     traffic, tnote = None, None
-    for tp in ("r03_attn_fwd_hbm_traffic.json",):
+    for tp in ("r04_attn_fwd_hbm_traffic.json", "r03_attn_fwd_hbm_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tp)
         if os.path.exists(tpath):      # PMC summary committed from a separate rocprofv3 --pmc run (tools/pmc_traffic.sh)
             tj = json.load(open(tpath))
@@ -483,7 +483,7 @@ def run_replica(args, rank, world, local, device, dist_info):
                 "attention_fwd_all_launches_tflops": round(att_weighted, 1),
                 "attention_fwd_all_launches_frac": round(att_weighted / MFMA_PEAK_TFLOPS, 4),
                 "clock_note": "frac is against the nominal 2.5 PFLOP/s (2.4 GHz); sclk of THIS box while the blocks ran: "
-                              "timing.clock; the box profiles/r03_* were taken on: profiles/README.md"}
+                              "timing.clock; the box profiles/r04_* were taken on: profiles/README.md"}
 
     extras = {}
     if args.m8_extra or (world == 1 and os.environ.get("MAVLM_BENCH_M8", "1") != "0"):

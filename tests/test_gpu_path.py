@@ -245,6 +245,34 @@ def test_golden_g7_reference_fullsize(tag, M, F, steps):
         assert errs[t] / errs[t - 1] <= 1.25 * ref_errs[t] / ref_errs[t - 1] + 0.05, (errs, ref_errs)
 
 
+@pytest.mark.parametrize("tag,M,F,steps", [("m8f32", 8, 32, 3), ("m64f32", 64, 32, 2)])
+def test_golden_g7_reference_fullsize_fp16(tag, M, F, steps):
+    """The fp16 path (MFMA f16, BASELINE.json configs[4]) against the REFERENCE's fp32 run at a flat tolerance: 16-bit floats
+    with 10 mantissa bits sit inside the north-star's 1e-3 at the first steps (the reference's own fp16 run: 6.4e-4 -> 1.1e-3
+    over four steps) - gate 1.5e-3 rel-L2 per step as the survey's protocol states, unbiased, frame scores
+    5e-3.  (bf16 cannot meet a flat 1e-3 against fp32 - one rounding of an exact result costs 1.6e-3 - and is gated against the
+    reference's own bf16 run instead, test_golden_g7_reference_fullsize.)"""
+    z, m = load_golden("g7_fullsize.npz")
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=M, depth=2)
+    w = O.make_weights(cfg, seed=m["wseed"])
+    proj = make_projector(cfg, w, "fp16")
+    proj.memory_cache = []
+    with torch.no_grad():
+        for t in range(steps):
+            seg = O.bf16_round(O.hash_normal_like((F, 196, 1024), m["segseed0"] + t))      # (bf16-grid inputs are exact in fp16)
+            cache, scores = proj(to_dev(seg, "fp16"))
+            mem = to_np(cache[-1]).reshape(-1)
+            ref = z[f"{tag}_s{t}_sample"]
+            got = mem[::m["stride"]]
+            err = O.rel_l2(got, ref)
+            d = (got - ref).astype(np.float64)
+            bias, sem = d.mean(), d.std() / math.sqrt(d.size)
+            print(f"{tag} fp16 step {t}: HIP-fp16 vs ref-fp32 {err:.2e}; mean signed error {bias:+.2e} (standard error {sem:.1e})")
+            assert err < 1.5e-3
+            assert abs(bias) < 4.0 * sem + 1e-6
+            assert O.rel_l2(to_np(scores[-1]), z[f"{tag}_s{t}_scores"]) < 5e-3
+
+
 def _g7_gates(got, mem, scores, z, pfx, t, m, label):
     """the gates of the G7 tests for one step of one video; returns (err, reference's own bf16 err)"""
     ref = z[f"{pfx}s{t}_sample"]
