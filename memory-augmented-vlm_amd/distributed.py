@@ -86,6 +86,7 @@ class RowShardedMemory:
         self._engine = None
         self._pending = None
         self._n = 0
+        self._packed_epoch = -1
         self._pre = None           # (the tensor given as `prefetch`, its contiguous form whose K/V sit in the workspace)
 
     # -- engine (a row shard of the projector's fused engine) ------------------------------------------------
@@ -103,6 +104,7 @@ class RowShardedMemory:
             fuser, temb = p._fuser_refs if p._fuser_refs is not None else (None, None)
             e.pack(p, fuser, temb)
             e.version = v
+            self._packed_epoch = p._train_state["epoch"]
         return e
 
     def reset(self):
@@ -112,7 +114,7 @@ class RowShardedMemory:
         self._pre = None
         if self._engine is not None:
             capi.check(capi.lib().mavlm_reset(self._engine.ctx), "mavlm_reset")
-            if self.p._weights_maybe_stale():
+            if self.p._weights_maybe_stale(self._packed_epoch):
                 self._engine.version = None
             self._engine.post_ln_probe()
 

@@ -430,10 +430,13 @@ class TransformerProjector(nn.Module):
                 st["epoch"] += 1
         return super().train(mode)
 
-    def _weights_maybe_stale(self) -> bool:
+    def _weights_maybe_stale(self, packed_epoch=None) -> bool:
+        """`packed_epoch`: the training epoch at which the asking engine packed its copies (default: this module's own engine;
+        a BatchedProjector / RowShardedMemory keeps its own - round 4: they used to compare with the BASE module's, which
+        never packs when only pools run, and re-packed the weights at every video)."""
         st = self._train_state
         fuser_training = any(m.training for m in (self._fuser_refs or ()))
-        return st["training"] or fuser_training or st["epoch"] != self._packed_epoch
+        return st["training"] or fuser_training or st["epoch"] != (self._packed_epoch if packed_epoch is None else packed_epoch)
 
     # -- engine management -------------------------------------------------------------------------------
     def bind_fuser(self, memory_fuser, token_type_embedding):
@@ -608,6 +611,7 @@ class BatchedProjector:
             raise capi.MavlmError("BatchedProjector: batch >= 2 (a single video runs through TransformerProjector itself)")
         self.proj, self.batch = proj, int(batch)
         self._engine = None
+        self._packed_epoch = -1
         self.compute_frame_scores = True
         self.frame_scores: List[torch.Tensor] = []
         self._n = 0
@@ -625,6 +629,7 @@ class BatchedProjector:
             fuser, temb = proj._fuser_refs if proj._fuser_refs is not None else (None, None)
             e.pack(proj, fuser, temb)
             e.version = v
+            self._packed_epoch = proj._train_state["epoch"]
         return e
 
     def reset(self):
@@ -633,7 +638,7 @@ class BatchedProjector:
         self._n = 0
         if self._engine is not None:
             capi.check(capi.lib().mavlm_reset(self._engine.ctx), "mavlm_reset")
-            if self.proj._weights_maybe_stale():
+            if self.proj._weights_maybe_stale(self._packed_epoch):
                 self._engine.version = None
             self._engine.post_ln_probe()
 
