@@ -408,6 +408,11 @@ class GraphedVideoMemory:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out, _ = video_memory_tokens(self.view, self.x, self.idx, self.mp, self.fp, self.nl, with_frames)
+        # what the module's host-side state looks like after this video (ring views of the FIFO, scores of the chunks): a replay
+        # only re-runs the device work, so __call__ puts these back - `recurrent_memory_transformer.memory_cache` read after a
+        # replayed forward is the replayed video's cache, as after an eager forward (matters when the slot is the model itself)
+        rm_ = self.view.recurrent_memory_transformer
+        self._cache = list(rm_.memory_cache)
 
     @torch.no_grad()
     def __call__(self, frames, memory_prompt_embeds, frame_prompt_embeds, image_newline):
@@ -416,6 +421,7 @@ class GraphedVideoMemory:
         self.fp.copy_(frame_prompt_embeds)
         self.nl.copy_(image_newline)
         self.graph.replay()
+        self.view.recurrent_memory_transformer._memory_cache = list(self._cache)
         return self.out
 
 

@@ -492,11 +492,17 @@ def test_prepare_inputs_end_to_end_vs_oracle():
     with torch.no_grad():
         for rep in range(4):
             table.copy_(to_dev(O.bf16_round(O.hash_normal_like((F0, side * side, D), 920 + rep))))
+            rm_ = model.recurrent_memory_transformer
             lm._mem_graph_capacity = 0
             want = lm.prepare_inputs_labels_for_multimodal(ids, None, am, None, labels, images, modalities=["video"])[4].clone()
+            want_cache = [c_.clone() for c_ in rm_.memory_cache]
+            rm_.memory_cache = []                               # (host-side state of another video in between)
             lm._mem_graph_capacity = 2
             got = lm.prepare_inputs_labels_for_multimodal(ids, None, am, None, labels, images, modalities=["video"])[4]
             assert torch.equal(got, want), rep
+            # the module's host-side cache after a replayed forward is the replayed video's (ring views, oldest first)
+            assert len(rm_.memory_cache) == len(want_cache) == 2
+            assert all(torch.equal(a_, b_) for a_, b_ in zip(rm_.memory_cache, want_cache))
             assert len(lm._mem_graphs) == (1 if rep >= 1 else 0)
         # a second shape gets its own graph; the eager path of the first shape still works next to them
         images2 = [torch.arange(33, dtype=torch.float32, device="cuda").reshape(33, 1, 1, 1)]
