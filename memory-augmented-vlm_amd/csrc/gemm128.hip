@@ -6,7 +6,7 @@
 // exchange / stores) are exposed and a grid of 1.53 or 1.75 rounds of tiles costs 2.  Here a workgroup is 4 waves on a
 // 128x256 tile at 80 KiB of LDS and <= 256 registers: two of them share a CU (one wave of each per SIMD), independent of
 // each other, so one's K loop runs under the other's epilogue and the grid is cut twice as fine.  Both effects are real
-// (the GELU launch costs +7 % over ReLU here against +17 % on the 256-row kernel) - but two 128x256 tiles stage 1.5 x the
+// (the GELU launch costs +8 % over ReLU here against +18 % on the 256-row kernel) - but two 128x256 tiles stage 1.5 x the
 // operand bytes of one 256x256 tile per flop, and L2 -> LDS staging (~12.8 TB/s chip-wide under MFMA load: 48-50 GB/s
 // per CU in every GEMM loop measured in this repository, the vendor library's included) is what bounds these loops: this
 // kernel tops out at ~1 120-1 165 TFLOP/s in its K loop where the 256-row one reaches ~1 430.  It is therefore the
