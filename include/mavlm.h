@@ -170,7 +170,8 @@ int mavlm_prefetch_hits(const mavlm_ctx* ctx);
 /* replaces memory_fuser(cat(memory_cache)) + token_type add + fine-frame gather/add + prompt/newline concat
  * (llava_arch.py:513-524,545-554,620-629,708-731).  Writes
  *   out = [mem_prompt(10) ; fused memory (n*M*P rows, oldest first) ; newline ; frame_prompt(9) ; fine (n_fine*P) ; newline]
- * x_pe: [T,P,D] PE-added frames; fine_idx: [n_fine] int64 frame indices into x_pe.  Returns rows written via *rows (host). */
+ * x_pe: [T,P,D] PE-added frames; fine_idx: [n_fine] int64 frame indices into x_pe.  Returns rows written via *rows (host).
+ * Every device pointer 16-B aligned (the literal rows are copied by one kernel with 16-B accesses, not by memcpy nodes). */
 int mavlm_fuse_emit(mavlm_ctx* ctx, const void* x_pe, const int64_t* fine_idx, int32_t n_fine, const void* mem_prompt,
                     int32_t n_mem_prompt, const void* frame_prompt, int32_t n_frame_prompt, const void* newline,
                     int32_t with_frames, void* out, int64_t out_capacity_rows, int64_t* rows, void* stream);

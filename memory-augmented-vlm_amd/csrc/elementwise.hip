@@ -243,6 +243,21 @@ __global__ __launch_bounds__(256) void row_add_kernel(const uint16_t* __restrict
   }
 }
 
+// The literal rows of a video's token block (llava_arch.py:541-543,559-566: memory prompt, image_newline, frame prompt,
+// image_newline) - up to four short row runs copied to fixed rows of every video's block in ONE launch.
+struct copy_rows_args {
+  const uint16_t* src[4];
+  int n[4];            // rows of run i (0 = unused)
+  long long dst[4];    // first row of run i inside a video's block
+};
+__global__ __launch_bounds__(256) void copy_rows_kernel(copy_rows_args a, uint16_t* __restrict__ out, long long vstride, int D) {
+  int r = blockIdx.x, i = 0;
+  while (i < 3 && r >= a.n[i]) r -= a.n[i++];
+  const u16x8* s = (const u16x8*)(a.src[i] + (size_t)r * D);
+  u16x8* d = (u16x8*)(out + (size_t)blockIdx.y * vstride + (size_t)(a.dst[i] + r) * D);
+  for (int c = threadIdx.x; c < (D >> 3); c += 256) d[c] = s[c];
+}
+
 // get_2dPool, bilinear branch (llava/model/llava_arch.py:277-297): F.interpolate(size=ceil(side/stride), mode='bilinear',
 // align_corners=False) over the [side, side] token grid, channels last.  One workgroup per output token, 8 channels
 // per lane (16-B loads of the 4 source tokens), fp32 lerp, ONE rounding to 16 bits; optionally followed by the
@@ -347,6 +362,24 @@ hipError_t mavlm_launch_row_add(const void* x, const int64_t* src, const void* t
   else
     hipLaunchKernelGGL(row_add_kernel<BF16>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)x, src,
                        (const uint16_t*)table, idx, (uint16_t*)out, T_, P, D);
+  return hipGetLastError();
+}
+
+hipError_t mavlm_launch_copy_rows(const void* const* src, const int* n, const long long* dst, int runs, void* out,
+                                  long long vstride, int B, int D, hipStream_t s) {
+  if (runs < 0 || runs > 4 || !out || B <= 0 || D <= 0 || (D & 7)) return hipErrorInvalidValue;
+  copy_rows_args a = {};
+  int total = 0, k = 0;
+  for (int i = 0; i < runs; ++i) {
+    if (n[i] <= 0) continue;
+    if (!src[i]) return hipErrorInvalidValue;
+    a.src[k] = (const uint16_t*)src[i]; a.n[k] = n[i]; a.dst[k] = dst[i];
+    total += n[i];
+    ++k;
+  }
+  if (!total) return hipSuccess;
+  mavlm_prof_scope prof(MAVLM_K_ROWADD, 0.0, 4.0 * total * (double)B * D, s);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)total, (unsigned)B), dim3(256), 0, s, a, (uint16_t*)out, vstride, D);
   return hipGetLastError();
 }
 

@@ -648,8 +648,16 @@ int fuse_emit_impl(mavlm_ctx* x, const void* const* x_pe, const int64_t* fine_id
   const size_t vstride = (size_t)cap_rows * rowb;             // video b's token block starts b * cap_rows rows into `out`
   char* o = (char*)out;
   int64_t row = 0;
-  for (int b = 0; b < B && n_mem_prompt; ++b)
-    MAVLM_TRY(hipMemcpyAsync(o + b * vstride, mem_prompt, rowb * n_mem_prompt, hipMemcpyDeviceToDevice, s));
+  {
+    // the literal rows (memory prompt, newline, frame prompt, newline) of all B blocks: one launch, rows known up front
+    const int64_t r_nl1 = (int64_t)n_mem_prompt + (int64_t)n * R1, r_fp = r_nl1 + 1;
+    const int64_t r_nl2 = r_fp + n_frame_prompt + (int64_t)n_fine * c.patches;
+    const void* src[4] = {mem_prompt, newline, frame_prompt, newline};
+    const int cnt[4] = {n_mem_prompt, 1, with_frames ? n_frame_prompt : 0, with_frames ? 1 : 0};
+    const long long dst[4] = {0, r_nl1, r_fp, r_nl2};
+    if ((((uintptr_t)mem_prompt | (uintptr_t)newline | (uintptr_t)frame_prompt | (uintptr_t)out) & 15)) return MAVLM_E_ARG;
+    MAVLM_TRY(mavlm_launch_copy_rows(src, cnt, dst, 4, out, (long long)cap_rows * D, B, D, s));
+  }
   row += n_mem_prompt;
   const int oldest = x->steps <= cap ? 0 : x->steps % cap;
   // torch.cat(memory_cache) order = oldest first (llava_arch.py:545) = ring slots oldest..cap-1, then 0..oldest-1: at most
@@ -675,19 +683,13 @@ int fuse_emit_impl(mavlm_ctx* x, const void* const* x_pe, const int64_t* fine_id
     row += (int64_t)run * R1;
     done += run;
   }
-  for (int b = 0; b < B; ++b)
-    MAVLM_TRY(hipMemcpyAsync(o + b * vstride + (size_t)row * rowb, newline, rowb, hipMemcpyDeviceToDevice, s));
   row += 1;
   if (with_frames) {
-    for (int b = 0; b < B && n_frame_prompt; ++b)
-      MAVLM_TRY(hipMemcpyAsync(o + b * vstride + (size_t)row * rowb, frame_prompt, rowb * n_frame_prompt, hipMemcpyDeviceToDevice, s));
     row += n_frame_prompt;
     for (int b = 0; b < B && n_fine; ++b)
       MAVLM_TRY(mavlm_launch_row_add(x_pe[b], fine_idx, x->w.type1, nullptr, o + b * vstride + (size_t)row * rowb, n_fine,
                                      c.patches, D, dt, s));
     row += (int64_t)n_fine * c.patches;
-    for (int b = 0; b < B; ++b)
-      MAVLM_TRY(hipMemcpyAsync(o + b * vstride + (size_t)row * rowb, newline, rowb, hipMemcpyDeviceToDevice, s));
     row += 1;
   }
   *rows = row;

@@ -190,6 +190,11 @@ hipError_t mavlm_launch_layernorm(const float* x, const void* res, int ldr, cons
 hipError_t mavlm_launch_row_add(const void* x, const int64_t* src, const void* table, const int64_t* idx, void* out,
                                 int T, int P, int D, int dtype, hipStream_t s);
 
+// `runs` (<= 4) literal row runs: out[b*vstride + (dst[i]+r)*D ..] = src[i][r*D ..] for r < n[i], every video b < B
+// (vstride in elements); one launch for the prompt / newline rows of mavlm_fuse_emit
+hipError_t mavlm_launch_copy_rows(const void* const* src, const int* n, const long long* dst, int runs, void* out,
+                                  long long vstride, int B, int D, hipStream_t s);
+
 // out[f, oy*os+ox, :] = bilinear(x[f, side x side, :]) (+ table[idx[f], :] when table != null); os = ceil(side/stride)
 hipError_t mavlm_launch_pool_bilinear(const void* x, void* out, const void* table, const int64_t* idx, int F, int side,
                                       int stride, int D, int dtype, hipStream_t s);
