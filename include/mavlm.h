@@ -311,6 +311,13 @@ int mavlm_attention_bwd(const void* Q, int32_t ldq, const void* K, int32_t ldk, 
                         int32_t ldo, const void* dO, int32_t lddo, const float* lse2, float* delta, void* dQ,
                         int32_t lddq, void* dK, int32_t lddk, void* dV, int32_t lddv, int32_t R, int32_t S, int32_t H,
                         float scale, int32_t dtype, void* stream);
+/* The same for head_dim 448 (LLaVA-OneVision-7B: hidden 3584 / 8 heads, llava_arch.py:117-122; finetune_long.sh:33): all
+ * operands [rows, H*448]; other head sizes -> MAVLM_E_SHAPE.  Flash style as well (rounds 2-4 composed this width's backward
+ * from GEMMs over one head's materialised [R,S] scores). */
+int mavlm_attention_bwd_hd(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, const void* O,
+                           int32_t ldo, const void* dO, int32_t lddo, const float* lse2, float* delta, void* dQ,
+                           int32_t lddq, void* dK, int32_t lddk, void* dV, int32_t lddv, int32_t R, int32_t S, int32_t H,
+                           int32_t head_dim, float scale, int32_t dtype, void* stream);
 /* C[M,N] 16-bit = A[M,K] . W[N,K]^T, contraction split over `splits` workgroup planes; ws = splits*M*N fp32;
  * zero_bias = N fp32 zeros.  For dW = dY^T X, whose contraction runs over all rows of the activations. */
 int mavlm_linear_splitk(const void* A, int32_t lda, const void* W, int32_t ldw, void* C, int32_t M, int32_t N, int32_t K,

@@ -4,7 +4,7 @@ import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "gemm256.hip", "gemm256p.hip", "gemm128.hip", "attention.hip", "attention3.hip", "attention_hd.hip", "attention_bwd.hip", "backward.hip", "variants.hip", "elementwise.hip", "mavlm_api.hip", "prof.hip"]
+SOURCES = ["gemm.hip", "gemm256.hip", "gemm256p.hip", "gemm128.hip", "attention.hip", "attention3.hip", "attention_hd.hip", "attention_bwd.hip", "attention_bwd_hd.hip", "backward.hip", "variants.hip", "elementwise.hip", "mavlm_api.hip", "prof.hip"]
 HEADERS = ["mavlm_common.h", "mavlm_kernels.h", os.path.join("..", "..", "include", "mavlm.h")]
 
 

@@ -93,6 +93,8 @@ SIGNATURES = {
     "mavlm_pool_bilinear": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "mavlm_attention_bwd": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, i32,
                                       i32, i32, i32, C.c_float, i32, vp]),
+    "mavlm_attention_bwd_hd": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, i32,
+                                         i32, i32, i32, i32, C.c_float, i32, vp]),
     "mavlm_linear_splitk": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp]),
     "mavlm_layernorm_bwd_ws_floats": (C.c_int64, [i32]),
     "mavlm_layernorm_bwd": (C.c_int, [vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, C.c_float, i32, vp]),

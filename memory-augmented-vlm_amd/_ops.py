@@ -422,13 +422,45 @@ def _wide_bwd_streams(dev, n):
     return _WIDE_BWD_POOL[key]
 
 
+WIDE_BWD_FLASH = True       # head_dim 448: the flash-style kernels of attention_bwd_hd.hip (False: the GEMM-composed form below)
+
+
+def attention_bwd_hd(q, k, v, o, do, lse2, heads, head_dim, scale, need_dq=True, need_dk=True, need_dv=True):
+    """Gradients of `attention` at head_dim 448 (LLaVA-OneVision-7B), flash style (`mavlm_attention_bwd_hd`): the
+    probabilities are recomputed per tile from lse2, nothing of size [R, S] is materialised.  Returns (dq, dk, dv)."""
+    _need_gpu(q, k, v, o, do, lse2)
+    R, _, ldq = _rows(q)
+    S, _, ldk = _rows(k)
+    _, _, ldv = _rows(v)
+    _, _, ldo = _rows(o)
+    do = do if do.stride(-1) == 1 else do.contiguous()
+    _, _, lddo = _rows(do)
+    W = heads * head_dim
+    if o.shape != (R, W) or do.shape != (R, W) or lse2.shape != (heads, R) or lse2.dtype != torch.float32 \
+            or not lse2.is_contiguous() or v.shape[0] != S or do.dtype != q.dtype:
+        raise capi.MavlmError("attention_bwd_hd: operand mismatch")
+    dq = torch.empty((R, W), device=q.device, dtype=q.dtype) if need_dq else None
+    dk = torch.empty((S, W), device=q.device, dtype=q.dtype) if need_dk else None
+    dv = torch.empty((S, W), device=q.device, dtype=q.dtype) if need_dv else None
+    delta = torch.empty((heads, R), device=q.device, dtype=torch.float32)
+    p = lambda t: t.data_ptr() if t is not None else 0
+    capi.check(capi.lib().mavlm_attention_bwd_hd(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, o.data_ptr(), ldo,
+                                                 do.data_ptr(), lddo, lse2.data_ptr(), delta.data_ptr(), p(dq), W, p(dk), W,
+                                                 p(dv), W, R, S, heads, head_dim, float(scale), dtype_code(q.dtype),
+                                                 stream_ptr()), "mavlm_attention_bwd_hd")
+    return dq, dk, dv
+
+
 def attention_bwd_wide(q, k, v, o, do, lse2, heads, head_dim, scale, need_dq=True, need_dk=True, need_dv=True):
-    """Gradients of `attention` for wide heads (head_dim 448: LLaVA-OneVision-7B).  The flash-style backward kernels
-    hold a 128-wide head in registers; a 448-wide one does not fit, so ONE head's [R,S] scores are materialised at a
+    """Gradients of `attention` for wide heads.  head_dim 448 runs the flash-style kernels (`attention_bwd_hd`); the form
+    below - rounds 2-4, kept for the other multiples of 64 and as the cross-check of the kernels - composes the backward from
+    GEMMs: ONE head's [R,S] scores are materialised at a
     time (fp32, from the MFMA GEMM) and every product of the backward runs as a GEMM of this library:
         S = q_h k_h^T  ->  P = exp2(S c - lse2)  ->  dP = dO_h v_h^T  ->  dS = P o (dP - delta) scale
         dV_h = P^T dO_h,   dQ_h = dS k_h,   dK_h = dS^T q_h
     (same rounding points as the flash-style path: P and dS in 16 bits, everything else fp32 accumulation)."""
+    if head_dim == 448 and WIDE_BWD_FLASH:
+        return attention_bwd_hd(q, k, v, o, do, lse2, heads, head_dim, scale, need_dq, need_dk, need_dv)
     _need_gpu(q, k, v, o, do, lse2)
     R, S = q.shape[0], k.shape[0]
     hd, H = head_dim, heads

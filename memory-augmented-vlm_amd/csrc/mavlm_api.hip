@@ -921,6 +921,31 @@ int mavlm_attention_bwd(const void* Q, int32_t ldq, const void* K, int32_t ldk, 
   return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
 }
 
+int mavlm_attention_bwd_hd(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, const void* O,
+                           int32_t ldo, const void* dO, int32_t lddo, const float* lse2, float* delta, void* dQ,
+                           int32_t lddq, void* dK, int32_t lddk, void* dV, int32_t lddv, int32_t R, int32_t S, int32_t H,
+                           int32_t head_dim, float scale, int32_t dtype, void* stream) {
+  if (!Q || !K || !V || !O || !dO || !lse2 || !delta || R <= 0 || S <= 0 || H <= 0) return MAVLM_E_ARG;
+  if (head_dim != 448) return MAVLM_E_SHAPE;
+  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7) || (lddo & 7) || (lddq & 3) || (lddk & 3) || (lddv & 3))
+    return MAVLM_E_ARG;
+  const int w = H * head_dim;
+  if (ldq < w || ldk < w || ldv < w || ldo < w || lddo < w || (dQ && lddq < w) || (dK && lddk < w) || (dV && lddv < w))
+    return MAVLM_E_ARG;
+  if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)dO) & 15) return MAVLM_E_ARG;
+  if (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 7) return MAVLM_E_ARG;
+  mavlm_attn_bwd_args a;
+  a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.dO = dO; a.lddo = lddo;
+  a.lse2 = lse2; a.delta = delta; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
+  a.R = R; a.S = S; a.H = H; a.scale = scale;
+  // (algorithmic flops: 3 products for dQ, 3 for dK, 2 for dV; the kernels run 5 / 5 / 2 - attention_bwd_hd.hip)
+  const double units = (dQ ? 3.0 : 0.0) + (dK ? 3.0 : 0.0) + (dV ? 2.0 : 0.0);
+  mavlm_prof_scope prof(MAVLM_K_ATTN_BWD, units * 2.0 * R * (double)S * H * head_dim, 2.0 * head_dim * H * (4.0 * R + 4.0 * S),
+                        (hipStream_t)stream);
+  hipError_t e = mavlm_launch_attention_bwd_hd(a, head_dim, dtype, (hipStream_t)stream);
+  return e == hipErrorInvalidValue ? MAVLM_E_ARG : (int)e;
+}
+
 int mavlm_linear_splitk(const void* A, int32_t lda, const void* W, int32_t ldw, void* C, int32_t M, int32_t N, int32_t K,
                         int32_t splits, float* ws, const float* zero_bias, int32_t dtype, void* stream) {
   if (!A || !W || !C || !ws || !zero_bias || M < 0 || splits < 1) return MAVLM_E_ARG;

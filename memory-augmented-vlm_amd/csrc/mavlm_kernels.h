@@ -128,6 +128,8 @@ struct mavlm_attn_bwd_args {
   float scale;
 };
 hipError_t mavlm_launch_attention_bwd(const mavlm_attn_bwd_args& a, int dtype, hipStream_t s);
+// the same for head_dim 448 (attention_bwd_hd.hip); O / dO / dQ / dK / dV are [rows, H*448]
+hipError_t mavlm_launch_attention_bwd_hd(const mavlm_attn_bwd_args& a, int head_dim, int dtype, hipStream_t s);
 
 // backward.hip
 size_t mavlm_layernorm_bwd_partial_floats(int D);

@@ -152,25 +152,72 @@ def test_attention_bwd_strided_operands_and_bad_args(bwd_fused):
         ops.attention_bwd(q.cpu(), kv[:, :W], kv[:, W:], o, do, lse, H)
 
 
-@pytest.mark.parametrize("mode", ["bf16", "fp16"])
-@pytest.mark.parametrize("R,S,H", [(196, 392, 2), (130, 200, 1), (64, 128, 8)])
-def test_attention_bwd_wide_heads_vs_oracle(mode, R, S, H):
-    """head_dim 448 (LLaVA-OneVision-7B): per-head materialised scores, every product a GEMM; same gates as the
-    flash-style backward (P and dS are the only 16-bit operands, as there)."""
-    hd = 448
+@pytest.fixture(params=[True, False], ids=["flash", "composed"])
+def wide_flash(request):
+    """head_dim-448 backward tests run the flash-style kernels (the product) and the GEMM-composed form they replaced."""
+    prev = ops.WIDE_BWD_FLASH
+    ops.WIDE_BWD_FLASH = request.param
+    yield request.param
+    ops.WIDE_BWD_FLASH = prev
+
+
+def _wide_case(R, S, H, mode, seed=61):
     r = O.rounder(mode)
-    W = H * hd
-    Q = r(O.hash_normal_like((R, W), 61, 0.5))
-    K = r(O.hash_normal_like((S, W), 62, 0.5))
-    V = r(O.hash_normal_like((S, W), 63, 1.0))
-    dO = r(O.hash_normal_like((R, W), 64, 0.5))
+    W = H * 448
+    Q = r(O.hash_normal_like((R, W), seed, 0.5))
+    K = r(O.hash_normal_like((S, W), seed + 1, 0.5))
+    V = r(O.hash_normal_like((S, W), seed + 2, 1.0))
+    dO = r(O.hash_normal_like((R, W), seed + 3, 0.5))
+    return Q, K, V, dO
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("R,S,H", [(196, 392, 2), (130, 200, 1), (64, 128, 8), (1, 2, 1), (33, 97, 2), (300, 131, 2)])
+def test_attention_bwd_wide_heads_vs_oracle(mode, R, S, H, wide_flash):
+    """head_dim 448 (LLaVA-OneVision-7B).  flash: `attn_bwd_hd_kernel` (P recomputed per tile from lse2; dS rounded to 16 bits,
+    the scale applied to the fp32 result - as the 128-wide kernels); composed: per-head materialised scores, every product a
+    GEMM (the scale inside dS).  Same gates as the 128-wide backward; ragged row counts on both sides of every tile size."""
+    hd = 448
+    if not wide_flash and (R, S) in ((1, 2), (33, 97), (300, 131)):
+        pytest.skip("ragged cases: the flash kernels' tile edges")
+    r = O.rounder(mode)
+    Q, K, V, dO = _wide_case(R, S, H, mode)
     q, k, v, do = (to_dev(a, mode) for a in (Q, K, V, dO))
     o, lse = ops.attention(q, k, v, H, want_lse=True, head_dim=hd)
     scale = ops.attn_scale(hd)
     dq, dk, dv = ops.attention_bwd_wide(q, k, v, o, do, lse, H, hd, scale)
-    rq, rk, rv = OB.attention_bwd(Q, K, V, to_np(o), dO, to_np(lse), H, mode, scale_in_ds=True)
+    rq, rk, rv = OB.attention_bwd(Q, K, V, to_np(o), dO, to_np(lse), H, mode, scale_in_ds=not wide_flash)
     assert O.rel_l2(to_np(dv), r(rv)) < TOL
     assert O.rel_l2(to_np(dq), r(rq)) < TOL
     assert O.rel_l2(to_np(dk), r(rk)) < TOL
     a = ops.attention_bwd_wide(q, k, v, o, do, lse, H, hd, scale, need_dq=False, need_dk=True, need_dv=False)
     assert a[0] is None and a[2] is None and torch.equal(a[1], dk)
+
+
+def test_attention_bwd_wide_flash_vs_composed_and_strided_operands():
+    """The flash-style 448 kernels against the GEMM-composed form on the same inputs (two independent implementations of the
+    same rounding points up to where the scale enters), K / V as column slices of a packed [S, 2W] projection output (as the
+    path stores them), a path-sized row count (M = 8: 1568 memory rows against a 32-frame chunk + one memory), determinism."""
+    hd, H, R, S = 448, 8, 1568, 1568 + 2 * 196
+    W = H * hd
+    Q, K, V, dO = _wide_case(R, S, H, "bf16", 71)
+    kv = to_dev(np.concatenate([K, V], axis=1), "bf16")
+    q, do = to_dev(Q, "bf16"), to_dev(dO, "bf16")
+    k, v = kv[:, :W], kv[:, W:]
+    o, lse = ops.attention(q, k, v, H, want_lse=True, head_dim=hd)
+    scale = ops.attn_scale(hd)
+    a = ops.attention_bwd_hd(q, k, v, o, do, lse, H, hd, scale)
+    b = ops.attention_bwd_hd(q, k.contiguous(), v.contiguous(), o, do, lse, H, hd, scale)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    prev, ops.WIDE_BWD_FLASH = ops.WIDE_BWD_FLASH, False
+    try:
+        cmp = ops.attention_bwd_wide(q, k.contiguous(), v.contiguous(), o, do, lse, H, hd, scale)
+    finally:
+        ops.WIDE_BWD_FLASH = prev
+    for x, y in zip(a, cmp):
+        assert O.rel_l2(to_np(x), to_np(y)) < 6e-3        # (two 16-bit roundings of the outputs + where the scale enters dS)
+    with pytest.raises(capi.MavlmError):
+        ops.attention_bwd_hd(q, k, v, o, do[:50], lse, H, hd, scale)
+    with pytest.raises(capi.MavlmError):
+        ops.attention_bwd_hd(q.cpu(), k, v, o, do, lse, H, hd, scale)
