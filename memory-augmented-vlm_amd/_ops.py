@@ -330,6 +330,11 @@ def matmul_nt_splitk(a, b, splits=None):
     tiles = -(-M // 128) * (N // 128)
     if splits is None:
         splits = max(1, min(K // 64, -(-512 // tiles)))
+    if splits == 1:
+        # enough output tiles to fill the chip (every dW of the OneVision-7B width): the plain GEMM with its automatic tile
+        # choice (256-row kernels), 16-bit output written directly - no fp32 plane, no reduction pass.  Same bits: every kernel
+        # sums an element's K products in the same order.
+        return matmul_nt(a, b)
     out = torch.empty((M, N), device=a.device, dtype=a.dtype)
     ws = torch.empty((splits, M, N), device=a.device, dtype=torch.float32)
     capi.check(capi.lib().mavlm_linear_splitk(a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(), M, N, K, splits,
