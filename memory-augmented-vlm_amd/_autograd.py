@@ -22,6 +22,22 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+_WT = {}        # (data_ptr, shape, dtype, stream) -> (version, W^T): the transposed weights of ONE backward pass
+
+
+def _wT(w):
+    """W^T [K, N] for dx = dy W (the GEMM wants both operands contraction-contiguous).  A weight used by several steps of a
+    video (the projector runs once per chunk) is transposed once per backward pass: the cache is emptied by every forward of
+    these functions - weights change between a backward pass and the next forward, never inside a backward pass."""
+    key = (w.data_ptr(), tuple(w.shape), w.dtype, torch.cuda.current_stream().cuda_stream)
+    hit = _WT.get(key)
+    if hit is not None and hit[0] == w._version:
+        return hit[1]
+    t = ops.transpose(w)
+    _WT[key] = (w._version, t)
+    return t
+
+
 def _weight_grads(dy, x):
     """dW = dy^T x and db = column sums of dy, both through the transposed (contraction-contiguous) operands."""
     dyT = ops.transpose(dy)                     # [N, Mpad], zero pad
@@ -34,6 +50,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, act):
+        _WT.clear()
         b32 = bias.detach().float()
         x = _c(x.detach())
         w = weight.detach()
@@ -64,7 +81,7 @@ class LinearFn(torch.autograd.Function):
             dy = ops.act(ops.ACT_RELU_BWD, saved[2], dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.matmul_nt(dy, ops.transpose(w))          # dy [M,N] . (W^T [K,N])^T
+            dx = ops.matmul_nt(dy, _wT(w))                    # dy [M,N] . (W^T [K,N])^T
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw, db = _weight_grads(dy, x)
             db = db.to(ctx.bias_dtype)
@@ -77,6 +94,7 @@ class DenseResidualNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, res, gamma, beta, eps):
+        _WT.clear()
         x, res, w = _c(x.detach()), _c(res.detach()), weight.detach()
         g32 = gamma.detach().float()
         # the form the fused inference step takes for this shape (one kernel where the GEMM fills the chip, else GEMM + row
@@ -91,7 +109,7 @@ class DenseResidualNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, z, res, g32 = ctx.saved_tensors
         dz, dg, dbeta = ops.layernorm_bwd(_c(dy), z, res, g32, ctx.eps)
-        dx = ops.matmul_nt(dz, ops.transpose(w)) if ctx.needs_input_grad[0] else None
+        dx = ops.matmul_nt(dz, _wT(w)) if ctx.needs_input_grad[0] else None
         dw, db = _weight_grads(dz, x)
         bd, gd, btd = ctx.dtypes
         return dx, dw, db.to(bd), (dz if ctx.needs_input_grad[3] else None), dg.to(gd), dbeta.to(btd), None

@@ -77,8 +77,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_hd_kernel(const uint16_t* __r
   constexpr int NPW = NSUB * 2;                             // 1 KiB DMA pieces per wave, image and tile
   constexpr int XCH = 4 * TILE;                             // exchange: [row group][role][4][64 lanes][16 B] = 16 KiB
   constexpr int STAT = XCH + 16384;                         // 2 stages x {lse2[64], delta[64]} floats
-  constexpr int KPF = 2;                                    // fragment reads in flight ahead of their MFMA
-  static_assert(HD % 64 == 0 && (HD / 32) % SL == 0 && 2 * NPW <= KS && TILE + (NSUB - 1) * SUB + 4096 < 65536, "wide head");
+  constexpr int KPF = 4;                                    // first phase: fragment reads in flight ahead of their MFMA
+  constexpr int ZPF = DKV ? 2 : 4;                          // second phase (two / four reads per step)
+  static_assert(HD % 64 == 0 && (HD / 32) % SL == 0 && DBS >= 6 && 2 * NPW <= KS && TILE + (NSUB - 1) * SUB + 4096 < 65536, "wide head");
   // LDS: Y stage 0, Y stage 1, Y2 stage 0, Y2 stage 1 (stage and sub-image offsets then fit the 16-bit instruction immediates)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -195,6 +196,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_hd_kernel(const uint16_t* __r
     const bool ragged = (t == nt - 1) && (NY & (WKT - 1));
     const int ytile = (t + 1) * WKT * ldy * 2, y2tile = (t + 1) * WKT * ldy2 * 2;     // scalar byte offsets of tile t+1
 
+    // second-phase fragments (step i = (16-row step i / DBS, block i % DBS)): the first ZPF steps' reads are issued before the
+    // exchange, so that they travel under its write - barrier - read round trip
+    constexpr int NRD = DKV ? 4 : 2;                          // reads per step
+    u32x2 zlo[NA], zhi[NA], z2lo[DKV ? NA : 1], z2hi[DKV ? NA : 1];
+    auto zrd = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int db = i % DBS, sx = i / DBS;
+      constexpr int off = P * TILE + (db / BPS) * SUB + 4096 * sx;
+      u32x2 lo, hi;
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(zad[db % BPS][0]), "i"(off));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(zad[db % BPS][1]), "i"(off));
+      zlo[i] = lo; zhi[i] = hi;
+      if constexpr (DKV) {
+        u32x2 lo2, hi2;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo2) : "v"(zad2[db % BPS][0]), "i"(off));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi2) : "v"(zad2[db % BPS][1]), "i"(off));
+        z2lo[i] = lo2; z2hi[i] = hi2;
+      }
+    };
+
     // ---- first phase: this wave's product (role 0: T^T = Y . X^T, role 1: dP^T = Y2 . X2^T; kad points at its image); the DMA
     // pieces of tile t+1 (other stage - dead since the barrier that ended tile t-1) ride along, one per k-step; a tile past the
     // last one lies behind the descriptors' end.
@@ -224,10 +245,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_hd_kernel(const uint16_t* __r
         __builtin_amdgcn_sched_barrier(0);
       };
       wait_lgkm<0>();
-      yrd(WIC<0>{});
-      yrd(WIC<1>{});
+      bw_for_each(std::make_integer_sequence<int, KPF>{}, yrd);
       __builtin_amdgcn_sched_barrier(0);
       bw_for_each(std::make_integer_sequence<int, KS>{}, sstep);
+      bw_for_each(std::make_integer_sequence<int, ZPF>{}, zrd);
       if constexpr (TWO) {
         // exchange with the partner wave of the row group (same lanes hold the same elements of both tiles)
         char* const mp = xch + slab * 4096;
@@ -248,33 +269,35 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_hd_kernel(const uint16_t* __r
       }
     }
 
-    // ---- E = P (dV) or dS = P o (dP - delta); value i of the lane is streamed row (i & 3) + 8 (i >> 2) + 4 hh of the tile
+    // ---- E = P (dV) or dS = P o (dP - delta); value i of the lane is streamed row (i & 3) + 8 (i >> 2) + 4 hh of the tile.
+    // Second phase: A^T[d][x] += Z^T[d][y] . E^T[y][x] over this wave's DBS blocks (MODE 3: and dV^T[d][x] += dO^T[d][y] . P^T[y][x]
+    // from the Y2 image), step i = (16-row step sx = i / DBS, block db = i % DBS): the steps of sx = 0 need the values 0-7 only, so
+    // the values 8-15 are evaluated between their MFMAs, and the first fragments are on their way while the values 0-7 are.
     typename T::vec8 ef[2], pf[2];
     {
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        f32x4 l4 = {0.f, 0.f, 0.f, 0.f}, d4 = {0.f, 0.f, 0.f, 0.f};
+      f32x4 l4[4], d4[4];                                       // statistics of the streamed rows (MODE 1-3)
+      auto vstat = [&](int gq) {
         if constexpr (MODE != 0) {
-          l4 = *(const f32x4*)(stat + 8 * gq + 4 * hh);
-          if constexpr (MODE != 2) d4 = *(const f32x4*)(stat + 64 + 8 * gq + 4 * hh);
+          l4[gq] = *(const f32x4*)(stat + 8 * gq + 4 * hh);
+          if constexpr (MODE != 2) d4[gq] = *(const f32x4*)(stat + 64 + 8 * gq + 4 * hh);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = 4 * gq + e;
-          const float l = (MODE == 0) ? lse_l : l4[e];
-          float p = __builtin_amdgcn_exp2f(tt[i] * c - l);
-          if (MODE == 0 && ragged && t * WKT + e + 8 * gq + 4 * hh >= NY) p = 0.f;      // key past the end
-          // (MODE 1-3: a query past the end has zero Y / Y2 rows and zero statistics - p = 1, every product 0)
-          if constexpr (MODE == 2) {
-            tt[i] = p;
-          } else {
-            tt[i] = p * (dp[i] - ((MODE == 0) ? del_l : d4[e]));
-            if constexpr (DKV) dp[i] = p;                       // dP is consumed: its registers carry P
-          }
+      };
+      auto vval = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int gq = i >> 2, e = i & 3;
+        const float l = (MODE == 0) ? lse_l : l4[gq][e];
+        float p = __builtin_amdgcn_exp2f(tt[i] * c - l);
+        if (MODE == 0 && ragged && t * WKT + e + 8 * gq + 4 * hh >= NY) p = 0.f;        // key past the end
+        // (MODE 1-3: a query past the end has zero Y / Y2 rows and zero statistics - p = 1, every product 0)
+        if constexpr (MODE == 2) {
+          tt[i] = p;
+        } else {
+          tt[i] = p * (dp[i] - ((MODE == 0) ? del_l : d4[gq][e]));
+          if constexpr (DKV) dp[i] = p;                         // dP is consumed: its registers carry P
         }
-      }
-#pragma unroll
-      for (int sx = 0; sx < 2; ++sx) {
+      };
+      auto vpack = [&](auto sc) {
+        constexpr int sx = decltype(sc)::value;
         u32x4 w;
 #pragma unroll
         for (int j = 0; j < 4; ++j) w[j] = pack2<T>(tt[8 * sx + 2 * j], tt[8 * sx + 2 * j + 1]);
@@ -286,34 +309,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_hd_kernel(const uint16_t* __r
           asm volatile("" : "+v"(w));
           pf[sx] = __builtin_bit_cast(typename T::vec8, w);
         }
-      }
-    }
-
-    // ---- second phase: A^T[d][x] += Z^T[d][y] . E^T[y][x] over this wave's DBS blocks, two 16-row steps each
-    // (MODE 3: and dV^T[d][x] += dO^T[d][y] . P^T[y][x] from the Y2 image)
-    {
-      constexpr int NRD = DKV ? 4 : 2;                          // reads per step
-      u32x2 zlo[NA], zhi[NA], z2lo[DKV ? NA : 1], z2hi[DKV ? NA : 1];
-      auto zrd = [&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        constexpr int db = i >> 1, sx = i & 1;
-        constexpr int off = P * TILE + (db / BPS) * SUB + 4096 * sx;
-        u32x2 lo, hi;
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(zad[db % BPS][0]), "i"(off));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(zad[db % BPS][1]), "i"(off));
-        zlo[i] = lo; zhi[i] = hi;
-        if constexpr (DKV) {
-          u32x2 lo2, hi2;
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo2) : "v"(zad2[db % BPS][0]), "i"(off));
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi2) : "v"(zad2[db % BPS][1]), "i"(off));
-          z2lo[i] = lo2; z2hi[i] = hi2;
-        }
       };
+      vstat(0); vstat(1); vstat(2); vstat(3);
+      bw_for_each(std::make_integer_sequence<int, 8>{}, vval);
+      vpack(WIC<0>{});
       auto zstep = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        constexpr int db = i >> 1, sx = i & 1;
-        if constexpr (i + KPF < NA) zrd(WIC<(i + KPF < NA ? i + KPF : NA - 1)>{});
-        constexpr int ahead = (NA - 1 - i) < KPF ? (NA - 1 - i) : KPF;
+        constexpr int db = i % DBS, sx = i / DBS;
+        if constexpr (i + ZPF < NA) zrd(WIC<(i + ZPF < NA ? i + ZPF : NA - 1)>{});
+        constexpr int ahead = (NA - 1 - i) < ZPF ? (NA - 1 - i) : ZPF;
         wait_lgkm<ahead * NRD>();
         __builtin_amdgcn_sched_barrier(0);
         u32x4 both;
@@ -324,12 +328,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_hd_kernel(const uint16_t* __r
           b2[0] = z2lo[i][0]; b2[1] = z2lo[i][1]; b2[2] = z2hi[i][0]; b2[3] = z2hi[i][1];
           acc2[db] = T::mfma32(__builtin_bit_cast(typename T::vec8, b2), pf[sx], acc2[db]);
         }
+        // the values 8-15 ride along the steps of sx = 0: two per step, packed behind the last of them
+        if constexpr (i < 4) {
+          vval(WIC<8 + 2 * (i < 4 ? i : 0)>{});
+          vval(WIC<9 + 2 * (i < 4 ? i : 0)>{});
+        }
+        if constexpr (i == 4) vpack(WIC<1>{});
         __builtin_amdgcn_sched_barrier(0);
       };
-      wait_lgkm<0>();                                           // nothing older than the reads below is outstanding
-      zrd(WIC<0>{});
-      zrd(WIC<1>{});
-      __builtin_amdgcn_sched_barrier(0);
       bw_for_each(std::make_integer_sequence<int, NA>{}, zstep);
     }
 
