@@ -389,9 +389,10 @@ def g7_wide():
 
 # --------------------------------------------------------------------------- G8 (gradients)
 G8_CASES = {"d256": (256, 7), "d1024": (1024, 61)}      # hidden (8 heads: the reference's dead reshape needs H = M = 8), stride
+G8_WIDE = {"d3584": (3584, 1999)}                       # the OneVision-7B width (heads of 448; `python make_golden.py g8wide`, ~1 h of CPU)
 
 
-def g8_case(dtype, hidden, stride):
+def g8_case(dtype, hidden, stride, small_full=0):
     """3 recurrent steps of the reference TransformerProjector under autograd (BPTT through the un-detached
     memory_cache, MemoryController.py:125-127,152), loss = sum_t <cache[t], G_t>; gradients of every parameter."""
     cfg = O.PathConfig(hidden=hidden, heads=8, mem_tokens=8, depth=2)
@@ -412,15 +413,18 @@ def g8_case(dtype, hidden, stride):
     out = {"loss": np.array(float(loss))}
     for name, p in m.named_parameters():
         g = p.grad.float().numpy().reshape(-1)
-        out["g_" + name + "_sample"] = g[::stride].copy()
+        # (wide case: parameters of <= small_full elements - biases, LayerNorm affines - are stored whole: 2 samples of a
+        # 3584-vector make no envelope)
+        out["g_" + name + "_sample"] = g[::(1 if g.size <= small_full else stride)].copy()
         out["g_" + name + "_norm"] = np.array(np.linalg.norm(g.astype(np.float64)))
     return cfg, frames, out
 
 
-def g8():
-    for tag, (hidden, stride) in G8_CASES.items():
-        cfg, frames, ref = g8_case(torch.float32, hidden, stride)
-        _, _, bf = g8_case(torch.bfloat16, hidden, stride)
+def g8(cases=None):
+    small_full = 65536 if cases is G8_WIDE else 0
+    for tag, (hidden, stride) in (cases or G8_CASES).items():
+        cfg, frames, ref = g8_case(torch.float32, hidden, stride, small_full)
+        _, _, bf = g8_case(torch.bfloat16, hidden, stride, small_full)
         # the reference's own bf16-vs-fp32 distance per parameter gradient (on the stored samples): the envelope the
         # 16-bit HIP backward is judged against
         env = {}
@@ -428,7 +432,7 @@ def g8():
             if k.endswith("_sample"):
                 env["env_" + k[2:-7]] = np.array(O.rel_l2(bf[k], ref[k]))
         save(f"g8_grads_{tag}.npz", meta=meta(hidden=hidden, heads=8, mem_tokens=8, depth=2, frames=frames, wseed=81,
-                                              segseed0=800, gseed0=850, gstd=0.05, stride=stride), **ref, **env)
+                                              segseed0=800, gseed0=850, gstd=0.05, stride=stride, small_full=small_full), **ref, **env)
         print(tag, "reference bf16-vs-fp32 gradient envelope: max", max(float(v) for v in env.values()),
               "median", float(np.median([float(v) for v in env.values()])))
 
@@ -498,6 +502,8 @@ if __name__ == "__main__":
         g9()
     if "g8" in which:
         g8()
+    if "g8wide" in which:
+        g8(G8_WIDE)
     if "g1" in which:
         g1_g2()
     if "g3" in which:
