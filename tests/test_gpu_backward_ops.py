@@ -217,6 +217,13 @@ def test_attention_bwd_wide_flash_vs_composed_and_strided_operands():
         ops.WIDE_BWD_FLASH = prev
     for x, y in zip(a, cmp):
         assert O.rel_l2(to_np(x), to_np(y)) < 6e-3        # (two 16-bit roundings of the outputs + where the scale enters dS)
+    # size-independent properties at the path's size: a second run repeats every bit (no atomics, fixed schedules), and the
+    # gradients are linear in dO - exactly so for a power of two (P does not depend on dO; dP, delta, dS and the sums double)
+    a2 = ops.attention_bwd_hd(q, k, v, o, do, lse, H, hd, scale)
+    d2 = ops.attention_bwd_hd(q, k, v, o, do * 2, lse, H, hd, scale)
+    for x, y, z in zip(a, a2, d2):
+        assert torch.equal(x, y)
+        assert torch.equal(x * 2, z)
     with pytest.raises(capi.MavlmError):
         ops.attention_bwd_hd(q, k, v, o, do[:50], lse, H, hd, scale)
     with pytest.raises(capi.MavlmError):
