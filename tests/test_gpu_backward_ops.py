@@ -192,6 +192,8 @@ def test_attention_bwd_wide_heads_vs_oracle(mode, R, S, H, wide_flash):
     assert O.rel_l2(to_np(dk), r(rk)) < TOL
     a = ops.attention_bwd_wide(q, k, v, o, do, lse, H, hd, scale, need_dq=False, need_dk=True, need_dv=False)
     assert a[0] is None and a[2] is None and torch.equal(a[1], dk)
+    b = ops.attention_bwd_wide(q, k, v, o, do, lse, H, hd, scale, need_dq=False, need_dk=False, need_dv=True)
+    assert b[0] is None and b[1] is None and torch.equal(b[2], dv)      # (flash: the dV-only kernel against the fused dK + dV one)
 
 
 def test_attention_bwd_wide_flash_vs_composed_and_strided_operands():
