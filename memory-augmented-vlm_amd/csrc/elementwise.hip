@@ -243,6 +243,32 @@ __global__ __launch_bounds__(256) void row_add_kernel(const uint16_t* __restrict
   }
 }
 
+// row_add_kernel for the videos of a row batch in ONE launch (blockIdx.y = video): the fine-frame gather + token-type add of
+// mavlm_fuse_emit_batch (llava_arch.py:620-629), one source pointer per video, the videos' outputs vstride elements apart
+struct row_add_srcs { const uint16_t* p[16]; };
+template <typename T>
+__global__ __launch_bounds__(256) void row_add_batch_kernel(row_add_srcs xs, const int64_t* __restrict__ src,
+                                                            const uint16_t* __restrict__ table, uint16_t* __restrict__ out,
+                                                            long long vstride, int T_, int P, int D) {
+  const uint16_t* __restrict__ x = xs.p[blockIdx.y];
+  out += (size_t)blockIdx.y * vstride;
+  const int dv = D >> 3;
+  const size_t total = (size_t)T_ * P * dv;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % dv);
+    const size_t rowi = i / dv;
+    const int t = (int)(rowi / P);
+    const int p = (int)(rowi % P);
+    const int64_t st = src ? src[t] : t;
+    const u16x8 a = *(const u16x8*)(x + ((size_t)st * P + p) * D + 8 * c);
+    const u16x8 b = *(const u16x8*)(table + 8 * c);
+    u16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = T::from_f32(T::to_f32(a[e]) + T::to_f32(b[e]));
+    *(u16x8*)(out + rowi * D + 8 * c) = o;
+  }
+}
+
 // The literal rows of a video's token block (llava_arch.py:541-543,559-566: memory prompt, image_newline, frame prompt,
 // image_newline) - up to four short row runs copied to fixed rows of every video's block in ONE launch.
 struct copy_rows_args {
@@ -362,6 +388,32 @@ hipError_t mavlm_launch_row_add(const void* x, const int64_t* src, const void* t
   else
     hipLaunchKernelGGL(row_add_kernel<BF16>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)x, src,
                        (const uint16_t*)table, idx, (uint16_t*)out, T_, P, D);
+  return hipGetLastError();
+}
+
+hipError_t mavlm_launch_row_add_batch(const void* const* x, const int64_t* src, const void* table_row, void* out,
+                                      long long vstride, int B, int T_, int P, int D, int dtype, hipStream_t s) {
+  if (T_ <= 0 || B <= 0) return hipSuccess;
+  if (!x || !table_row || !out || P <= 0 || D <= 0 || (D & 7)) return hipErrorInvalidValue;
+  const size_t total = (size_t)T_ * P * (D >> 3);
+  mavlm_prof_scope prof(MAVLM_K_ROWADD, 0.0, 4.0 * B * T_ * (double)P * D, s);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  for (int b0 = 0; b0 < B; b0 += 16) {
+    const int nb = B - b0 < 16 ? B - b0 : 16;
+    row_add_srcs xs = {};
+    for (int i = 0; i < nb; ++i) {
+      if (!x[b0 + i]) return hipErrorInvalidValue;
+      xs.p[i] = (const uint16_t*)x[b0 + i];
+    }
+    uint16_t* o = (uint16_t*)out + (size_t)b0 * vstride;
+    if (dtype == MAVLM_F16)
+      hipLaunchKernelGGL(row_add_batch_kernel<F16>, dim3((unsigned)blocks, (unsigned)nb), dim3(256), 0, s, xs, src,
+                         (const uint16_t*)table_row, o, vstride, T_, P, D);
+    else
+      hipLaunchKernelGGL(row_add_batch_kernel<BF16>, dim3((unsigned)blocks, (unsigned)nb), dim3(256), 0, s, xs, src,
+                         (const uint16_t*)table_row, o, vstride, T_, P, D);
+  }
   return hipGetLastError();
 }
 

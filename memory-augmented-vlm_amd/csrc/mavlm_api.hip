@@ -645,7 +645,7 @@ int fuse_emit_impl(mavlm_ctx* x, const void* const* x_pe, const int64_t* fine_id
     for (int b = 0; b < B; ++b)
       if (!x_pe[b]) return MAVLM_E_ARG;
   const size_t rowb = (size_t)D * 2;
-  const size_t vstride = (size_t)cap_rows * rowb;             // video b's token block starts b * cap_rows rows into `out`
+  // (video b's token block starts b * cap_rows rows into `out`)
   char* o = (char*)out;
   int64_t row = 0;
   {
@@ -686,9 +686,9 @@ int fuse_emit_impl(mavlm_ctx* x, const void* const* x_pe, const int64_t* fine_id
   row += 1;
   if (with_frames) {
     row += n_frame_prompt;
-    for (int b = 0; b < B && n_fine; ++b)
-      MAVLM_TRY(mavlm_launch_row_add(x_pe[b], fine_idx, x->w.type1, nullptr, o + b * vstride + (size_t)row * rowb, n_fine,
-                                     c.patches, D, dt, s));
+    if (n_fine)
+      MAVLM_TRY(mavlm_launch_row_add_batch(x_pe, fine_idx, x->w.type1, o + (size_t)row * rowb, (long long)cap_rows * D, B, n_fine,
+                                           c.patches, D, dt, s));
     row += (int64_t)n_fine * c.patches;
     row += 1;
   }

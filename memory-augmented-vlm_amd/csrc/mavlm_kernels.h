@@ -192,6 +192,11 @@ hipError_t mavlm_launch_layernorm(const float* x, const void* res, int ldr, cons
 hipError_t mavlm_launch_row_add(const void* x, const int64_t* src, const void* table, const int64_t* idx, void* out,
                                 int T, int P, int D, int dtype, hipStream_t s);
 
+// row_add for B videos in one launch: out[b*vstride + (t*P + p)*D ..] = x[b][src[t], p, :] + table_row[:]  (x = HOST array of B
+// device pointers; vstride in elements)
+hipError_t mavlm_launch_row_add_batch(const void* const* x, const int64_t* src, const void* table_row, void* out,
+                                      long long vstride, int B, int T, int P, int D, int dtype, hipStream_t s);
+
 // `runs` (<= 4) literal row runs: out[b*vstride + (dst[i]+r)*D ..] = src[i][r*D ..] for r < n[i], every video b < B
 // (vstride in elements); one launch for the prompt / newline rows of mavlm_fuse_emit
 hipError_t mavlm_launch_copy_rows(const void* const* src, const int* n, const long long* dst, int runs, void* out,
