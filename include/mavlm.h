@@ -397,10 +397,12 @@ int mavlm_set_attention_colsum_wgs(int32_t wgs);
  * its deferred rescales as one group and adds the fp32 row sums in a different order (results agree to the tolerance of the
  * oracle tests, not bit for bit). */
 int mavlm_set_attention_wide_groups(int32_t groups);
-/* how mavlm_step obtains the frame scores of the last formation layer (head_dim <= 128, patches % 4 == 0, <= 64 frames per
- * chunk): 1 (default) = fused into that layer's attention forward - every query row carries the probability mass of the
- * current frame next to its row sum; 0 = the separate column-sum pass over Q, K and lse2.  Same
- * values up to fp32 summation order. */
+/* how mavlm_step obtains the frame scores of the last formation layer (patches % 4 == 0, <= 64 frames per chunk): 1 (default) =
+ * fused into that layer's attention forward - heads of <= 128 columns: every query row carries the probability mass of the
+ * current frame next to its row sum; heads of 448 (round 4): the forward writes one log-mass entry per query row and 32-key tile,
+ * whatever its schedule, and a small kernel adds them per frame once the row's log-sum-exp is final (up to 1 GiB of entries in the
+ * workspace, else mode 0) -; 0 = the separate column-sum pass over Q, K and lse2.  Same values up to fp32 summation order; the
+ * memory never depends on the mode. */
 int mavlm_set_frame_score_mode(int32_t mode);
 /* 1 if mavlm_step (single video) takes the fused form for a last-layer attention of R memory rows over S = F * patches keys
  * with heads of <= 128 columns - patches % 4 == 0, patches >= 64, <= 64 frames, and not one of the small grids that split

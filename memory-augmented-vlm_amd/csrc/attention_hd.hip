@@ -304,14 +304,24 @@ struct hd_sk_plan {
 // with hand-counted lgkmcnt waits around inline-asm fragment reads, buffer-load LDS-DMA (one loop-invariant lane offset per
 // operand, tile and piece in the scalar offset; rows past S read as zeros) and K / V in separate 2-slot rings (K runs one
 // tile ahead of V).  Same image layout, swizzle and rounding points as attn_fwd_hd_kernel; 4 waves x 32 queries per workgroup.
-template <typename T, int HD, int KPF, int VPF>
+//
+// FT = 1: the frame-score variant (last formation layer at the OneVision-7B width, MemoryController.py:135-139; round 4 - the column-sum
+// pass attn_colsum_hd_kernel recomputed Q.K^T for it: 4 % of the step).  The keys are frames of FPK consecutive patches.  For every
+// (query row, 32-key tile) the kernel writes ONE 8-byte entry: the log2 masses (relative to nothing: log2 sum p + m c) of the tile's keys
+// before and behind the frame boundary inside it (FPK % 4 == 0: a boundary never cuts one of the 4-key groups a lane holds; FPK > 32:
+// at most one boundary per tile; no boundary: the second value is -inf).  A (row, tile) has exactly one writer under every schedule -
+// plain grid, split-KV, levelled stream-K: pieces own disjoint tile ranges - so nothing has to be merged; frame_tiles_kernel, which runs
+// after the row's final log-sum-exp is known, turns the entries into partial frame sums, frame_finish_kernel (attention3.hip) adds
+// them in a fixed order.  O and lse2 are bit-identical to the FT = 0 kernel (the row sums keep their order).
+template <typename T, int HD, int KPF, int VPF, int FT = 0>
 __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __restrict__ Qa, int ldq,
                                                               const uint16_t* __restrict__ Ka, int ldk,
                                                               const uint16_t* __restrict__ Va, int ldv,
                                                               uint16_t* __restrict__ Oa, int ldo, float* __restrict__ lse2a,
                                                               int R, int S_all, int H, float c, float* __restrict__ Opart,
                                                               float* __restrict__ lse_part, int tps, long long kv_bs,
-                                                              hd_sk_plan plan) {
+                                                              hd_sk_plan plan, float* __restrict__ fent = nullptr, int FPK = 0,
+                                                              int HA = 0) {
   constexpr int NSUB = (HD + 127) / 128;
   constexpr int SUB = KTH * 256;
   constexpr int TILE = NSUB * SUB;
@@ -389,6 +399,19 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
   float* const lse2 = lse2a != nullptr ? lse2a + (size_t)vb * H * R : nullptr;
   const int S = (S_all - t_lo * KTH < nt * KTH) ? S_all - t_lo * KTH : nt * KTH;      // keys of this segment
   const int q0 = qblk * 128 + wave * 32;
+  // frame-tile entries (FT): [global head][tile of the unit][row] x 8 bytes (a wave's 32 rows of a tile are 256 contiguous bytes: one
+  // coalesced store); rows past R (clamped duplicates of row R-1) store behind the descriptor's end, which the hardware drops
+  __amdgpu_buffer_rsrc_t ers;
+  int e_voff = 0, f_end = 0;
+  if constexpr (FT != 0) {
+    const uintptr_t ea = (uintptr_t)fent;
+    const uint32_t elo = __builtin_amdgcn_readfirstlane((uint32_t)ea);
+    const uint32_t ehi = __builtin_amdgcn_readfirstlane((uint32_t)(ea >> 32));
+    const uint32_t ebytes = __builtin_amdgcn_readfirstlane((uint32_t)HA * (uint32_t)R * (uint32_t)nt_all * 8u);   // HA: heads of all videos
+    ers = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)ehi << 32) | elo), 0, ebytes, 0x00020000);
+    e_voff = q0 + r < R ? ((hg * nt_all + t_lo) * R + q0 + r) * 8 : 0x7ffffff0;
+    f_end = ((t_lo * KTH) / FPK + 1) * FPK - t_lo * KTH;      // end of the frame that holds the segment's first key, piece-local
+  }
 
   // ---- Q fragments (B operand): lane holds Q[q0 + r][h*HD + 16 ks + 8 hh + 0..7]
   typename T::vec8 qf[KS];
@@ -521,6 +544,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
     const float mc = m_run * c;
     typename T::vec8 pf[2];
     float psum = 0.f;
+    // (FT) keys [0, ft_kb) of this tile belong to the current frame; ft_cut: the frame ends inside the tile (or at its end)
+    const int ft_kb = f_end - t * KTH;
+    const bool ft_cut = FT != 0 && ft_kb <= KTH;
+    float ft_lo = 0.f;
     // element e of tile t.  The score is pinned to ITS step, and v_exp_f32 is inline asm: a volatile statement keeps its place
     // between the MFMAs without the register copy the "+v" pin around the builtin cost (a v_mov per probability).  Its readers -
     // converts and row sums in cvt() - come >= 2 steps after the last exp (the transcendental-result hazard needs one
@@ -539,6 +566,15 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
       for (int j = 1; j < 8; ++j) ps += st[P][8 * bs + j];    // fp32, element order
       asm volatile("" : "+v"(ps));                            // (summed here, not at the top of phase [B])
       psum += ps;
+      if constexpr (FT != 0) {
+        // a frame ends inside this tile: the mass of this lane's 4-key groups (keys 8 g + 4 hh + 0..3, g = 2 bs, 2 bs + 1) below
+        // the boundary.  (A scalar branch: five tiles of six have no boundary.)
+        if (ft_cut) {
+          const float g0 = (st[P][8 * bs] + st[P][8 * bs + 1]) + (st[P][8 * bs + 2] + st[P][8 * bs + 3]);
+          const float g1 = (st[P][8 * bs + 4] + st[P][8 * bs + 5]) + (st[P][8 * bs + 6] + st[P][8 * bs + 7]);
+          ft_lo += (16 * bs + 4 * hh < ft_kb ? g0 : 0.f) + (16 * bs + 8 + 4 * hh < ft_kb ? g1 : 0.f);
+        }
+      }
       u32x4 pw;
 #pragma unroll
       for (int j = 0; j < 4; ++j) pw[j] = pack2<T>(st[P][8 * bs + 2 * j], st[P][8 * bs + 2 * j + 1]);
@@ -663,11 +699,33 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
       __builtin_amdgcn_sched_barrier(0);
       hd_for_each(std::make_integer_sequence<int, NB>{}, vstep);
     }
+    if constexpr (FT != 0) {
+      // (psum and ft_lo are summed in different orders: where nothing lies behind the boundary their difference is rounding noise of
+      //  either sign - clamp it, log2 of a negative value is NaN)
+      float alo = ft_cut ? ft_lo : psum, ahi = fmaxf(psum - ft_lo, 0.f);
+      alo = xhalf_sum(alo);                                   // both key halves of the row
+      float vhi = -INFINITY;
+      if (ft_cut) {
+        ahi = ft_kb < KTH ? xhalf_sum(ahi) : 0.f;             // (a boundary at the tile's end: nothing behind it)
+        vhi = __builtin_amdgcn_logf(ahi) + mc;                // (v_log_f32 = log2; log2(0) = -inf: weight 0)
+        f_end += FPK;
+      }
+      const float vlo = __builtin_amdgcn_logf(alo) + mc;
+      if (hh == 0) {
+        u32x2 e;
+        e[0] = __builtin_bit_cast(unsigned, vlo);
+        e[1] = __builtin_bit_cast(unsigned, vhi);
+        __builtin_amdgcn_raw_buffer_store_b64(e, ers, e_voff, t * R * 8, 0);
+      }
+    }
     l_run += psum;                                            // per-lane partial (this half's keys); halves are summed at the end
     if (has_next) rescale(mx);                                // reference maximum for tile t+1 (after P.V(t): it touches O)
     // (tried: the barrier VPF steps before the end of phase [B] - legal once every V(t) fragment is in registers - with the first
     //  K fragments of the next tile read behind it, under the last MFMAs and the rescale check: 940 -> 906 TFLOP/s, reverted)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of K(t+2), V(t+1) have landed
+    // this wave's pieces of K(t+2), V(t+1) have landed.  (FT: the entry store of this tile is the YOUNGEST vector-memory operation
+    // and stays in flight - waiting for its round trip cost attn_fwd3_kernel ~20 us per launch.)
+    if constexpr (FT != 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -716,6 +774,48 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
     }
   }
   }  // segments
+}
+
+// Frame-tile entries [head][tile][row] -> partial frame sums (attn_fwd_hd2_kernel<.., FT = 1>).  One workgroup per (256-row block,
+// global head), a wave per 64 rows, lane = row: the wave walks the tiles in key order (one coalesced 512-byte load per tile), every
+// lane turns the entry's two values into masses 2^(v - lse2[row]) and adds them to its running sum of the current frame; when the
+// walk leaves a frame (wave-uniform: tile t holds the first key of frame (32 t) / FPK and, behind a boundary, of the next one) the
+// 64 sums are added across the wave in a fixed tree order and lane 0 stores the wave's partial for that frame:
+// fout[video][(head, block, wave)][frame], which frame_finish_kernel sums in a fixed order.
+__global__ __launch_bounds__(256) void frame_tiles_kernel(const float* __restrict__ fent, const float* __restrict__ lse2,
+                                                          float* __restrict__ fout, int R, int Hv, int nt_all, int FPK, int FN) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.x, hg = blockIdx.y, nblk = gridDim.x;
+  const int row = blk * 256 + wave * 64 + lane;
+  const bool ok = row < R;
+  const float lse = ok ? lse2[(size_t)hg * R + row] : 0.f;
+  const float2* e = (const float2*)fent + (size_t)hg * nt_all * R + (ok ? row : 0);
+  const int vb = hg / Hv, h = hg - vb * Hv;
+  float* const fo = fout + ((size_t)vb * Hv * nblk * 4 + ((size_t)h * nblk + blk) * 4 + wave) * FN;
+  float cur = 0.f;                                             // this row's mass of frame fc so far
+  int fc = 0, f_end = FPK;                                     // current frame, its end key
+  for (int t0 = 0; t0 < nt_all; t0 += 4) {
+    float2 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = t0 + j < nt_all ? e[(size_t)(t0 + j) * R] : float2{-INFINITY, -INFINITY};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = t0 + j;
+      if (t >= nt_all) break;
+      cur += ok ? __builtin_amdgcn_exp2f(v[j].x - lse) : 0.f;
+      if (f_end <= (t + 1) * KTH) {                            // the frame ends inside this tile (or at its end): wave-uniform
+        const float tot = wave_sum(cur);
+        if (lane == 0 && fc < FN) fo[fc] = tot;
+        cur = ok ? __builtin_amdgcn_exp2f(v[j].y - lse) : 0.f; // the keys behind the boundary open the next frame
+        fc += 1;
+        f_end += FPK;
+      }
+    }
+  }
+  if (fc < FN) {                                               // (S % 32 != 0: the last frame ends in the ragged tile's masked keys)
+    const float tot = wave_sum(cur);
+    if (lane == 0) fo[fc] = tot;
+  }
 }
 
 // Stream-K merge for attn_fwd_hd2_kernel: unit `ul` of level j (cut into NP = 2^k key ranges) has its partials in the slots
@@ -916,7 +1016,7 @@ static size_t hd2_plan_floats(const hd_sk_plan& p, int head_dim) {
   return p.wgs > 0 ? (size_t)p.wgs * p.nlev * ((size_t)128 * head_dim + 128) : 0;
 }
 
-template <typename T, int HD, int QG>
+template <typename T, int HD, int QG, int FT = 0>
 hipError_t launch_fwd_hd(const mavlm_attn_args& a, hipStream_t s) {
   constexpr int LDS = 4 * ((HD + 127) / 128) * KTH * 256;
   const float c = a.scale * 1.44269504088896340736f;
@@ -930,7 +1030,7 @@ hipError_t launch_fwd_hd(const mavlm_attn_args& a, hipStream_t s) {
   float* lpart = ns > 1 ? a.split_ws + (size_t)ns * a.R * a.H * HD : nullptr;
   static mavlm_per_device_once once;
   if constexpr (QG == 2) {
-    auto kern = attn_fwd_hd2_kernel<T, HD, 3, 3>;
+    auto kern = attn_fwd_hd2_kernel<T, HD, 3, 3, FT>;
     {
       hipError_t e = once.dyn_lds((const void*)kern, LDS);
       if (e != hipSuccess) return e;
@@ -947,7 +1047,7 @@ hipError_t launch_fwd_hd(const mavlm_attn_args& a, hipStream_t s) {
       mavlm_prof_scope prof(MAVLM_K_ATTN, 4.0 * a.R * (double)a.S * a.H * HD, 2.0 * HD * a.H * (2.0 * a.R + 2.0 * a.S), s);
       hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, (const uint16_t*)a.Q, a.ldq, (const uint16_t*)a.K, a.ldk,
                          (const uint16_t*)a.V, a.ldv, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.S, Hv, c, opart, lpart, tps,
-                         (long long)a.kv_bstride, plan);
+                         (long long)a.kv_bstride, plan, FT ? a.frame_scr : (float*)nullptr, FT ? a.frame_keys : 0, a.H);
     }
     if (plan.wgs > 0) {
       int cut = 0;
@@ -1045,6 +1145,34 @@ hipError_t mavlm_launch_attention_hd(const mavlm_attn_args& a, int head_dim, int
   if (head_dim == 256) return f16 ? launch_fwd_hd<F16, 256, 1>(a, s) : launch_fwd_hd<BF16, 256, 1>(a, s);
   if (head_dim == 224) return f16 ? launch_fwd_hd<F16, 224, 1>(a, s) : launch_fwd_hd<BF16, 224, 1>(a, s);
   return hipErrorInvalidValue;
+}
+
+// Forward + frame scores in one pass at head_dim 448 (attn_fwd_hd2_kernel<.., FT = 1> + frame_tiles_kernel; the caller finishes with
+// mavlm_launch_frame_finish over mavlm_attention_hd_frames_rows_per_video rows per video).  Runs whatever schedule the plain forward
+// of the shape runs: context and log-sum-exp are bit-identical to mavlm_launch_attention_hd's.
+bool mavlm_attention_hd_frames_supported(int R, int S, int H, int head_dim, int frame_keys) {
+  // frame_keys > 32: at most one frame boundary per 32-key tile; % 4: a boundary never cuts a lane's 4-key group; the entries are
+  // addressed through 32-bit offsets below the "dropped store" offset 0x7ffffff0
+  return head_dim == 448 && frame_keys > KTH && (frame_keys & 3) == 0 && R > 0 && S > 0 && S % frame_keys == 0 &&
+         S / frame_keys <= 64 && (double)H * R * ((S + KTH - 1) / KTH) * 8.0 < 2147483000.0;
+}
+size_t mavlm_attention_hd_frames_scr_floats(int R, int S, int H) { return (size_t)H * R * ((S + KTH - 1) / KTH) * 2; }
+int mavlm_attention_hd_frames_rows_per_video(int R, int Hv) { return Hv * ((R + 255) / 256) * 4; }
+size_t mavlm_attention_hd_frames_out_floats(int R, int S, int H, int frame_keys) {
+  return (size_t)H * ((R + 255) / 256) * 4 * (S / frame_keys);
+}
+hipError_t mavlm_launch_attention_hd_frames(const mavlm_attn_args& a, int head_dim, int dtype, hipStream_t s) {
+  if (!a.frame_scr || !a.frame_out || !a.lse2 || !mavlm_attention_hd_frames_supported(a.R, a.S, a.H, head_dim, a.frame_keys))
+    return hipErrorInvalidValue;
+  const int nb = a.nb > 0 ? a.nb : 1;
+  if (a.H % nb != 0) return hipErrorInvalidValue;
+  hipError_t e = dtype == MAVLM_F16 ? launch_fwd_hd<F16, 448, 2, 1>(a, s) : launch_fwd_hd<BF16, 448, 2, 1>(a, s);
+  if (e != hipSuccess) return e;
+  const int FN = a.S / a.frame_keys, nt_all = (a.S + KTH - 1) / KTH;
+  mavlm_prof_scope prof(MAVLM_K_MISC, 0.0, (double)a.H * a.R * nt_all * 8.0, s);
+  hipLaunchKernelGGL(frame_tiles_kernel, dim3((a.R + 255) / 256, a.H), dim3(256), 0, s, a.frame_scr, a.lse2, a.frame_out, a.R, a.H / nb,
+                     nt_all, a.frame_keys, FN);
+  return hipGetLastError();
 }
 
 hipError_t mavlm_launch_colsum_hd(const mavlm_colsum_args& a, int head_dim, int dtype, hipStream_t s) {

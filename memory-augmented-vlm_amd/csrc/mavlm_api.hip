@@ -154,6 +154,11 @@ void carve(mavlm_ctx* x) {
     if (!wide_heads(c) && mavlm_attention_frames_supported((int)R1, fc * c.patches, (int)(H * B), c.patches)) {
       x->o_fscr = o; o += al(mavlm_attention_frames_scr_floats((int)R1, fc * c.patches, (int)(H * B), c.patches) * 4);
       x->o_fout = o; o += al(mavlm_attention_frames_out_floats((int)R1, fc * c.patches, (int)(H * B), c.patches) * 4);
+    } else if (wide_heads(c) && mavlm_attention_hd_frames_supported((int)R1, fc * c.patches, (int)(H * B), c.hidden / c.heads, c.patches) &&
+               mavlm_attention_hd_frames_scr_floats((int)R1, fc * c.patches, (int)(H * B)) * 4 <= ((size_t)1 << 30)) {
+      // head_dim 448 (attention_hd.hip): one 8-byte entry per (head, memory row, 32-key tile) - up to 1 GiB, else the column-sum pass
+      x->o_fscr = o; o += al(mavlm_attention_hd_frames_scr_floats((int)R1, fc * c.patches, (int)(H * B)) * 4);
+      x->o_fout = o; o += al(mavlm_attention_hd_frames_out_floats((int)R1, c.patches, (int)(H * B), c.patches) * 64 * 4);
     }
   }
   // scratch of the fused dense + residual + LayerNorm epilogue (gemm256.hip EPI_LN): {epoch, value} granules of the row
@@ -256,7 +261,15 @@ int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const 
     const bool sk = mavlm_attention_hd_streamk(R1, S, H * B, hd, nullptr) > 0;
     if (sk) a.split_ws = mavlm_attention_hd_split_ws_floats(R1, S, H * B, hd) <= x->split_floats ? (float*)ws(x, x->o_split) : nullptr;
     else a.split_ws = (B == 1 && x->split_floats) ? (float*)ws(x, x->o_split) : nullptr;
-    MAVLM_TRY(mavlm_launch_attention_hd(a, hd, dt, s));
+    if (frames) {                             // forward + per-(row, tile) probability masses in one pass (no column-sum pass)
+      a.frame_scr = (float*)ws(x, x->o_fscr);
+      a.frame_out = (float*)ws(x, x->o_fout);
+      a.frame_keys = c.patches;
+      if (frame_rows) *frame_rows = mavlm_attention_hd_frames_rows_per_video(R1, H);
+      MAVLM_TRY(mavlm_launch_attention_hd_frames(a, hd, dt, s));
+    } else {
+      MAVLM_TRY(mavlm_launch_attention_hd(a, hd, dt, s));
+    }
   } else {
     // the schedule is part of the result: take it only when the carved workspace covers this shape's plan under the
     // CURRENT tuning hooks (they may have changed since mavlm_create) - never write past the carve
@@ -283,7 +296,10 @@ int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const 
 bool step_frames_fused(const mavlm_ctx* x, int S) {
   const mavlm_config& c = x->cfg;
   const int B = nbatch(c), R1 = q_tokens(c) * c.patches;
-  if (wide_heads(c) || x->o_fscr == 0) return false;
+  if (x->o_fscr == 0) return false;
+  if (wide_heads(c))       // (any schedule: a (row, tile) entry has one writer under all of them)
+    return g_mavlm_frame_score_mode == 1 && S <= (c.max_chunk_frames < 64 ? c.max_chunk_frames : 64) * c.patches &&
+           mavlm_attention_hd_frames_supported(R1, S, c.heads * B, c.hidden / c.heads, c.patches);
   if (B == 1) return mavlm_frame_scores_fused(R1, S, c.heads, c.patches) != 0;
   return g_mavlm_frame_score_mode == 1 && g_mavlm_attn_impl != 2 && mavlm_attention_frames_supported(R1, S, c.heads * B, c.patches);
 }

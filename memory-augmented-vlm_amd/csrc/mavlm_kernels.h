@@ -82,6 +82,13 @@ struct mavlm_attn_args {
   long long kv_bstride = 0;
 };
 hipError_t mavlm_launch_attention(const mavlm_attn_args& a, int dtype, hipStream_t s);
+// the same at head_dim 448 (attention_hd.hip): frame_scr = mavlm_attention_hd_frames_scr_floats floats (one 8-byte entry per query row
+// and 32-key tile), frame_out = mavlm_attention_hd_frames_out_floats floats; a.lse2 required
+bool mavlm_attention_hd_frames_supported(int R, int S, int H, int head_dim, int frame_keys);
+size_t mavlm_attention_hd_frames_scr_floats(int R, int S, int H);
+size_t mavlm_attention_hd_frames_out_floats(int R, int S, int H, int frame_keys);
+int mavlm_attention_hd_frames_rows_per_video(int R, int Hv);
+hipError_t mavlm_launch_attention_hd_frames(const mavlm_attn_args& a, int head_dim, int dtype, hipStream_t s);
 // forward + per-frame probability mass in one pass (attention3.hip; head_dim 128, frame_keys % 4 == 0, <= 64 frames)
 bool mavlm_attention_frames_supported(int R, int S, int H, int frame_keys);
 size_t mavlm_attention_frames_scr_floats(int R, int S, int H, int frame_keys);
