@@ -776,45 +776,37 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
   }  // segments
 }
 
-// Frame-tile entries [head][tile][row] -> partial frame sums (attn_fwd_hd2_kernel<.., FT = 1>).  One workgroup per (256-row block,
-// global head), a wave per 64 rows, lane = row: the wave walks the tiles in key order (one coalesced 512-byte load per tile), every
-// lane turns the entry's two values into masses 2^(v - lse2[row]) and adds them to its running sum of the current frame; when the
-// walk leaves a frame (wave-uniform: tile t holds the first key of frame (32 t) / FPK and, behind a boundary, of the next one) the
-// 64 sums are added across the wave in a fixed tree order and lane 0 stores the wave's partial for that frame:
-// fout[video][(head, block, wave)][frame], which frame_finish_kernel sums in a fixed order.
+// Frame-tile entries [head][tile][row] -> partial frame sums (attn_fwd_hd2_kernel<.., FT = 1>).  One workgroup per (64-row block,
+// global head), lane = row; wave w takes the frames w, w + 4, ...: a frame's mass in a row is the sum over the tiles that hold keys of
+// it - the SECOND value of the tile the frame starts in the middle of, the FIRST value of every tile whose first key is in the frame -
+// of 2^(v - lse2[row]), added in tile order; the (at most 8) entries of a frame are independent coalesced 512-byte loads.  The 64 row
+// sums are added across the wave in a fixed tree order: fout[video][(head, block)][frame], which frame_finish_kernel sums in a fixed
+// order.  (A first form walked all tiles of a row in one wave, carrying the running frame: 196 dependent steps, 48 us for 79 MB.)
 __global__ __launch_bounds__(256) void frame_tiles_kernel(const float* __restrict__ fent, const float* __restrict__ lse2,
                                                           float* __restrict__ fout, int R, int Hv, int nt_all, int FPK, int FN) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int blk = blockIdx.x, hg = blockIdx.y, nblk = gridDim.x;
-  const int row = blk * 256 + wave * 64 + lane;
+  const int row = blk * 64 + lane;
   const bool ok = row < R;
   const float lse = ok ? lse2[(size_t)hg * R + row] : 0.f;
   const float2* e = (const float2*)fent + (size_t)hg * nt_all * R + (ok ? row : 0);
   const int vb = hg / Hv, h = hg - vb * Hv;
-  float* const fo = fout + ((size_t)vb * Hv * nblk * 4 + ((size_t)h * nblk + blk) * 4 + wave) * FN;
-  float cur = 0.f;                                             // this row's mass of frame fc so far
-  int fc = 0, f_end = FPK;                                     // current frame, its end key
-  for (int t0 = 0; t0 < nt_all; t0 += 4) {
-    float2 v[4];
+  float* const fo = fout + ((size_t)vb * Hv * nblk + (size_t)h * nblk + blk) * FN;
+  for (int f = wave; f < FN; f += 4) {
+    const int t0 = (f * FPK) / KTH, t1 = (f * FPK + FPK - 1) / KTH;      // tiles that hold keys of frame f (t1 - t0 <= FPK / 32 + 1)
+    float rs = 0.f;
+    for (int tb = t0; tb <= t1; tb += 8) {
+      float2 v[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = t0 + j < nt_all ? e[(size_t)(t0 + j) * R] : float2{-INFINITY, -INFINITY};
+      for (int j = 0; j < 8; ++j) v[j] = (tb + j <= t1 && tb + j < nt_all) ? e[(size_t)(tb + j) * R] : float2{-INFINITY, -INFINITY};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int t = t0 + j;
-      if (t >= nt_all) break;
-      cur += ok ? __builtin_amdgcn_exp2f(v[j].x - lse) : 0.f;
-      if (f_end <= (t + 1) * KTH) {                            // the frame ends inside this tile (or at its end): wave-uniform
-        const float tot = wave_sum(cur);
-        if (lane == 0 && fc < FN) fo[fc] = tot;
-        cur = ok ? __builtin_amdgcn_exp2f(v[j].y - lse) : 0.f; // the keys behind the boundary open the next frame
-        fc += 1;
-        f_end += FPK;
+      for (int j = 0; j < 8; ++j) {
+        const int t = tb + j;
+        if (t <= t1 && t < nt_all) rs += __builtin_amdgcn_exp2f((((t * KTH) / FPK == f) ? v[j].x : v[j].y) - lse);
       }
     }
-  }
-  if (fc < FN) {                                               // (S % 32 != 0: the last frame ends in the ragged tile's masked keys)
-    const float tot = wave_sum(cur);
-    if (lane == 0) fo[fc] = tot;
+    const float tot = wave_sum(ok ? rs : 0.f);
+    if (lane == 0) fo[f] = tot;
   }
 }
 
@@ -1157,9 +1149,9 @@ bool mavlm_attention_hd_frames_supported(int R, int S, int H, int head_dim, int 
          S / frame_keys <= 64 && (double)H * R * ((S + KTH - 1) / KTH) * 8.0 < 2147483000.0;
 }
 size_t mavlm_attention_hd_frames_scr_floats(int R, int S, int H) { return (size_t)H * R * ((S + KTH - 1) / KTH) * 2; }
-int mavlm_attention_hd_frames_rows_per_video(int R, int Hv) { return Hv * ((R + 255) / 256) * 4; }
+int mavlm_attention_hd_frames_rows_per_video(int R, int Hv) { return Hv * ((R + 63) / 64); }
 size_t mavlm_attention_hd_frames_out_floats(int R, int S, int H, int frame_keys) {
-  return (size_t)H * ((R + 255) / 256) * 4 * (S / frame_keys);
+  return (size_t)H * ((R + 63) / 64) * (S / frame_keys);
 }
 hipError_t mavlm_launch_attention_hd_frames(const mavlm_attn_args& a, int head_dim, int dtype, hipStream_t s) {
   if (!a.frame_scr || !a.frame_out || !a.lse2 || !mavlm_attention_hd_frames_supported(a.R, a.S, a.H, head_dim, a.frame_keys))
@@ -1170,7 +1162,7 @@ hipError_t mavlm_launch_attention_hd_frames(const mavlm_attn_args& a, int head_d
   if (e != hipSuccess) return e;
   const int FN = a.S / a.frame_keys, nt_all = (a.S + KTH - 1) / KTH;
   mavlm_prof_scope prof(MAVLM_K_MISC, 0.0, (double)a.H * a.R * nt_all * 8.0, s);
-  hipLaunchKernelGGL(frame_tiles_kernel, dim3((a.R + 255) / 256, a.H), dim3(256), 0, s, a.frame_scr, a.lse2, a.frame_out, a.R, a.H / nb,
+  hipLaunchKernelGGL(frame_tiles_kernel, dim3((a.R + 63) / 64, a.H), dim3(256), 0, s, a.frame_scr, a.lse2, a.frame_out, a.R, a.H / nb,
                      nt_all, a.frame_keys, FN);
   return hipGetLastError();
 }
