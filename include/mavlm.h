@@ -401,12 +401,14 @@ int mavlm_set_attention_wide_groups(int32_t groups);
  * fused into that layer's attention forward - heads of <= 128 columns: every query row carries the probability mass of the
  * current frame next to its row sum; heads of 448 (round 4): the forward writes one log-mass entry per query row and 32-key tile,
  * whatever its schedule, and a small kernel adds them per frame once the row's log-sum-exp is final (up to 1 GiB of entries in the
- * workspace, else mode 0) -; 0 = the separate column-sum pass over Q, K and lse2.  Same values up to fp32 summation order; the
- * memory never depends on the mode. */
+ * workspace, else mode 0) -; 0 = the separate column-sum pass over Q, K and lse2.  Heads of <= 128 columns on the small grids
+ * that split their keys (one video with the checkpoint's 8 memory tokens), where the per-row frame masses are not available (one
+ * writer per entry), take the tile-entry form as well (64-key tiles; round 4); 2 = diagnostics: the tile-entry form wherever it is
+ * supported.  Same values up to fp32 summation order; the memory never depends on the mode. */
 int mavlm_set_frame_score_mode(int32_t mode);
 /* 1 if mavlm_step (single video) takes the fused form for a last-layer attention of R memory rows over S = F * patches keys
- * with heads of <= 128 columns - patches % 4 == 0, patches >= 64, <= 64 frames, and not one of the small grids that split
- * their keys (mavlm_attention_ws_floats), which keep the column-sum pass.  The fused launch runs the SAME schedule as the
+ * with heads of <= 128 columns in its per-(row, frame) form - patches % 4 == 0, patches >= 64, <= 64 frames, and not one of the
+ * small grids that split their keys (mavlm_attention_ws_floats), which take the tile-entry form (mavlm_set_frame_score_mode).  The fused launch runs the SAME schedule as the
  * plain forward of that shape (mavlm_attention_ws): the context and the memory do not depend on whether scores are asked for. */
 int mavlm_frame_scores_fused(int32_t R, int32_t S, int32_t H, int32_t patches);
 

@@ -305,13 +305,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
     const uintptr_t fa = (uintptr_t)fscr;
     const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)fa);          // (uint32_t: readfirstlane returns int - no
     const uint32_t fhi = __builtin_amdgcn_readfirstlane((uint32_t)(fa >> 32));  //  sign extension into the high word)
-    const uint32_t fbytes = __builtin_amdgcn_readfirstlane((uint32_t)H * (uint32_t)R * (uint32_t)FNE * 8u);
+    const uint32_t fbytes = __builtin_amdgcn_readfirstlane((uint32_t)H * (uint32_t)R * (uint32_t)(FR == 2 ? nt_all : FNE) * 8u);
     frs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)fhi << 32) | flo), 0, fbytes, 0x00020000);
     // entry [h][q][f + piece] = (a, m): 8 bytes.  Rows past R are clamped duplicates of row R-1 in every other respect; their
     // entry stores must land NOWHERE (a whole wave of duplicates can take a rescale the owning wave does not, and would
     // race with it): an offset behind the descriptor's end is dropped by the hardware, and the store stays issued, so the
     // vmcnt accounting of the tile loop does not change.
     f_voff = q0 + r < R ? ((h * R + q0 + r) * FNE + sk_piece) * 8 : 0x7ffffff0;
+    // FR = 2 (the small grids that split their keys, round 4): one entry per (row, 64-key TILE) instead - [head][tile][row] x 8
+    // bytes: log2 masses of the tile's keys before / behind the frame boundary inside it.  A (row, tile) has one writer under
+    // every schedule, nothing is merged; frame_tiles_kernel (attention_hd.hip) adds them per frame once lse2 is final.
+    if constexpr (FR == 2) f_voff = q0 + r < R ? ((h * nt_all + t_lo) * R + q0 + r) * 8 : 0x7ffffff0;
     // a piece of a cut unit starts at key t_lo * 64 of its unit: the frame that holds that key, and where it ends in
     // piece-local key numbers
     f_cur = (t_lo * KT3) / FP;
@@ -534,7 +538,43 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
     }
     l_run += psum;
     bool flushed = false;                                     // (wave-uniform)
-    if constexpr (FR != 0) {
+    if constexpr (FR == 2) {
+      flushed = true;                                         // (an entry store in every tile)
+      const int kofs = f_end - t * KT3;                       // keys [0, kofs) of the tile belong to the current frame
+      float plo = psum, phi = 0.f;
+      const bool cut = kofs <= KT3;                           // the frame ends inside this tile (or at its end)
+      if (cut) {
+        // as FR = 1 below: only the 32-key block that holds the boundary is looked at
+        if (kofs <= 32) {
+          plo = 0.f;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float s4 = (st[P][0][4 * g4] + st[P][0][4 * g4 + 1]) + (st[P][0][4 * g4 + 2] + st[P][0][4 * g4 + 3]);
+            plo += (8 * g4 + 4 * hh < kofs) ? s4 : 0.f;
+          }
+          phi = fmaxf(psum - plo, 0.f);
+        } else {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float s4 = (st[P][1][4 * g4] + st[P][1][4 * g4 + 1]) + (st[P][1][4 * g4 + 2] + st[P][1][4 * g4 + 3]);
+            phi += (32 + 8 * g4 + 4 * hh >= kofs) ? s4 : 0.f;
+          }
+          plo = fmaxf(psum - phi, 0.f);
+        }
+        f_end += FP;
+      }
+      const float mc2 = m_run * c;
+      const float vlo = __builtin_amdgcn_logf(xhalf_sum(plo)) + mc2;        // (v_log_f32 = log2; log2(0) = -inf: weight 0)
+      float vhi = -INFINITY;
+      if (cut && kofs < KT3) vhi = __builtin_amdgcn_logf(xhalf_sum(phi)) + mc2;
+      if (hh == 0) {
+        u32x2 e;
+        e[0] = __builtin_bit_cast(unsigned, vlo);
+        e[1] = __builtin_bit_cast(unsigned, vhi);
+        __builtin_amdgcn_raw_buffer_store_b64(e, frs, f_voff, t * R * 8, 0);
+      }
+    }
+    if constexpr (FR == 1) {
       const int k_end = (t + 1) * KT3;
       if (f_end <= k_end) {                                   // the current frame ends inside (or at the end of) this tile
         flushed = true;
@@ -584,7 +624,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
         m_run = m_new;
         l_run *= alpha;
-        if constexpr (FR != 0) a_cur *= alpha;
+        if constexpr (FR == 1) a_cur *= alpha;
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -608,7 +648,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
   }
   if (t < nt) iteration(IC<0>{}, t);
 
-  if constexpr (FR != 0) {
+  if constexpr (FR == 1) {
     // a piece that ends inside a frame: the mass of that frame's keys seen so far is still in a_cur (whole units end on a
     // frame boundary: S % FP == 0, the last flush happened in the loop and the next frame starts at key S)
     if (f_end - FP < S) {
@@ -656,7 +696,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd3_kernel(const uint16_t* _
       if (lse2 != nullptr && hh == 0) lse2[(size_t)h * R + q] = m_run * c + log2f(l_tot);
     }
   }
-  if (FR != 0 && out_kind == 0) {                             // whole unit: the row's final log-sum-exp is known here
+  if (FR == 1 && out_kind == 0) {                             // whole unit: the row's final log-sum-exp is known here
     // Lane j takes frame j (FN <= 64): for each of the wave's 32 queries it reads the (a, m) entry [h][q][j] - one 8-byte
     // load per lane, a query's F entries are contiguous - and adds a 2^(m c - lse2[q]).  The entries were written by this
     // wave (all stores retired by the vmcnt(0) that ended the last tile); nobody else has touched these lines.
@@ -1007,12 +1047,18 @@ hipError_t attn3_launch(const mavlm_attn_args& a, const attn3_launch_args& la, h
                         0.0, parts * 4.0 * (HD3 + 1), s);
   if (la.plan.wgs > 0 && la.cut_units > 0) {
     attn3_frames_args fa = {};
-    if (FR) fa = attn3_frames_args{a.frame_scr, a.frame_out, a.frame_keys, FN, la.FNE, a.S, la.c};
-    hipLaunchKernelGGL((attn_combine_sk_kernel<T, FR>), dim3(la.cut_units * (la.plan.qb / 32)), dim3(256), 0, s, la.opart,
+    constexpr int FRM = FR == 1 ? 1 : 0;                      // (FR = 2: the tile entries need no merge)
+    if (FRM) fa = attn3_frames_args{a.frame_scr, a.frame_out, a.frame_keys, FN, la.FNE, a.S, la.c};
+    hipLaunchKernelGGL((attn_combine_sk_kernel<T, FRM>), dim3(la.cut_units * (la.plan.qb / 32)), dim3(256), 0, s, la.opart,
                        la.lpart, (uint16_t*)a.O, a.ldo, a.lse2, a.R, a.H, la.plan, la.plan.qb, la.HB, fa);
   } else if (la.ns > 1) {
     hipLaunchKernelGGL(attn_combine_kernel<T>, dim3((a.R + 3) / 4), dim3(256), 0, s, la.opart, la.lpart, (uint16_t*)a.O, a.ldo,
                        a.lse2, a.R, a.H, HD3, la.ns);
+  }
+  if constexpr (FR == 2) {                                    // lse2 is final: tile entries -> partial frame sums
+    hipError_t e2 = mavlm_launch_frame_tiles(a.frame_scr, a.lse2, a.frame_out, a.R, a.H, la.HB, (a.S + KT3 - 1) / KT3, KT3,
+                                             a.frame_keys, FN, s);
+    if (e2 != hipSuccess) return e2;
   }
   return hipGetLastError();
 }
@@ -1080,13 +1126,15 @@ int mavlm_attention_frames_rows_per_video(const mavlm_attn_args& a) {
   return (a.H / nb) * ((a.R + qb - 1) / qb) * (qb / 32);
 }
 
-static hipError_t attn3_dispatch(const mavlm_attn_args& a, int dtype, bool frames, hipStream_t s) {
+static hipError_t attn3_dispatch(const mavlm_attn_args& a, int dtype, int frames, hipStream_t s) {      // frames: 0 / 1 (a, m) / 2 tile entries
   // K / V are addressed through 32-bit buffer offsets (one descriptor per head): the key block must span < 4 GiB
   // (2 GiB: the scalar offset of the tile after the last one must not wrap either)
   if ((double)a.S * a.ldk * 2.0 >= 2147483648.0 || (double)a.S * a.ldv * 2.0 >= 2147483648.0) return hipErrorInvalidValue;
   const int nb = a.nb > 0 ? a.nb : 1;
   if (a.H % nb != 0) return hipErrorInvalidValue;
-  if (frames && (!a.frame_scr || !a.frame_out || !mavlm_attention_frames_supported(a.R, a.S, a.H, a.frame_keys)))
+  if (frames == 1 && (!a.frame_scr || !a.frame_out || !mavlm_attention_frames_supported(a.R, a.S, a.H, a.frame_keys)))
+    return hipErrorInvalidValue;
+  if (frames == 2 && (!a.frame_scr || !a.frame_out || !a.lse2 || !mavlm_attention_frame_tiles_supported(a.R, a.S, a.H, a.frame_keys)))
     return hipErrorInvalidValue;
   const float c = a.scale * 1.44269504088896340736f;
   int tps = 0, ns = 1;
@@ -1094,7 +1142,7 @@ static hipError_t attn3_dispatch(const mavlm_attn_args& a, int dtype, bool frame
   if (a.split_ws != nullptr) {
     plan = attn3_plan(a.R, a.S, a.H);
     // the split-KV form of the small grids: single videos only, and never with the frame masses (one writer per entry)
-    if (plan.wgs == 0 && nb == 1 && !frames) ns = mavlm_attention_splits(a.R, a.S, a.H, &tps);
+    if (plan.wgs == 0 && nb == 1 && frames != 1) ns = mavlm_attention_splits(a.R, a.S, a.H, &tps);
   }
   const int skg = plan.wgs;
   int cut_units = 0;
@@ -1108,8 +1156,12 @@ static hipError_t attn3_dispatch(const mavlm_attn_args& a, int dtype, bool frame
   const dim3 grid(skg > 0 ? skg : units, skg > 0 ? 1 : ns);
   const bool w8 = skg > 0 && plan.qb == 256;
   const attn3_launch_args la = {grid, c, opart, lpart, tps, ns, cut_units, plan, a.H / nb,
-                                frames ? a.S / a.frame_keys + ATTN3_FR_EXTRA : 0};
+                                frames == 1 ? a.S / a.frame_keys + ATTN3_FR_EXTRA : 0};
   const bool h16 = dtype == MAVLM_F16;
+  if (frames == 2) {
+    if (h16) return w8 ? attn3_launch<F16, 8, 2>(a, la, s) : attn3_launch<F16, 4, 2>(a, la, s);
+    return w8 ? attn3_launch<BF16, 8, 2>(a, la, s) : attn3_launch<BF16, 4, 2>(a, la, s);
+  }
   if (frames) {
     if (h16) return w8 ? attn3_launch<F16, 8, 1>(a, la, s) : attn3_launch<F16, 4, 1>(a, la, s);
     return w8 ? attn3_launch<BF16, 8, 1>(a, la, s) : attn3_launch<BF16, 4, 1>(a, la, s);
@@ -1118,8 +1170,16 @@ static hipError_t attn3_dispatch(const mavlm_attn_args& a, int dtype, bool frame
   return w8 ? attn3_launch<BF16, 8, 0>(a, la, s) : attn3_launch<BF16, 4, 0>(a, la, s);
 }
 
-hipError_t mavlm_launch_attention3_frames(const mavlm_attn_args& a, int dtype, hipStream_t s) { return attn3_dispatch(a, dtype, true, s); }
-hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStream_t s) { return attn3_dispatch(a, dtype, false, s); }
+hipError_t mavlm_launch_attention3_frames(const mavlm_attn_args& a, int dtype, hipStream_t s) { return attn3_dispatch(a, dtype, 1, s); }
+hipError_t mavlm_launch_attention3(const mavlm_attn_args& a, int dtype, hipStream_t s) { return attn3_dispatch(a, dtype, 0, s); }
+// the tile-entry form (FR = 2): any schedule, incl. the split-KV form of the small grids
+bool mavlm_attention_frame_tiles_supported(int R, int S, int H, int frame_keys) {
+  return frame_keys >= KT3 && (frame_keys & 3) == 0 && R > 0 && S > 0 && S % frame_keys == 0 && S / frame_keys <= 64 &&
+         (double)H * R * ((S + KT3 - 1) / KT3) * 8.0 < 2147483000.0;
+}
+size_t mavlm_attention_frame_tiles_scr_floats(int R, int S, int H) { return (size_t)H * R * ((S + KT3 - 1) / KT3) * 2; }
+size_t mavlm_attention_frame_tiles_out_floats(int R, int S, int H, int frame_keys) { return (size_t)H * ((R + 63) / 64) * (S / frame_keys); }
+hipError_t mavlm_launch_attention3_frame_tiles(const mavlm_attn_args& a, int dtype, hipStream_t s) { return attn3_dispatch(a, dtype, 2, s); }
 
 // ------------------------------------------------------------------------------------------------------------
 // attn_colsum3_kernel: column sums of the normalised probabilities (frame scores, MemoryController.py:135-139).

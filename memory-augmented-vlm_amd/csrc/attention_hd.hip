@@ -783,7 +783,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_hd2_kernel(const uint16_t* __
 // sums are added across the wave in a fixed tree order: fout[video][(head, block)][frame], which frame_finish_kernel sums in a fixed
 // order.  (A first form walked all tiles of a row in one wave, carrying the running frame: 196 dependent steps, 48 us for 79 MB.)
 __global__ __launch_bounds__(256) void frame_tiles_kernel(const float* __restrict__ fent, const float* __restrict__ lse2,
-                                                          float* __restrict__ fout, int R, int Hv, int nt_all, int FPK, int FN) {
+                                                          float* __restrict__ fout, int R, int Hv, int nt_all, int FPK, int FN,
+                                                          int KT) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int blk = blockIdx.x, hg = blockIdx.y, nblk = gridDim.x;
   const int row = blk * 64 + lane;
@@ -793,7 +794,7 @@ __global__ __launch_bounds__(256) void frame_tiles_kernel(const float* __restric
   const int vb = hg / Hv, h = hg - vb * Hv;
   float* const fo = fout + ((size_t)vb * Hv * nblk + (size_t)h * nblk + blk) * FN;
   for (int f = wave; f < FN; f += 4) {
-    const int t0 = (f * FPK) / KTH, t1 = (f * FPK + FPK - 1) / KTH;      // tiles that hold keys of frame f (t1 - t0 <= FPK / 32 + 1)
+    const int t0 = (f * FPK) / KT, t1 = (f * FPK + FPK - 1) / KT;        // tiles (of KT keys) that hold keys of frame f
     float rs = 0.f;
     for (int tb = t0; tb <= t1; tb += 8) {
       float2 v[8];
@@ -802,7 +803,7 @@ __global__ __launch_bounds__(256) void frame_tiles_kernel(const float* __restric
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int t = tb + j;
-        if (t <= t1 && t < nt_all) rs += __builtin_amdgcn_exp2f((((t * KTH) / FPK == f) ? v[j].x : v[j].y) - lse);
+        if (t <= t1 && t < nt_all) rs += __builtin_amdgcn_exp2f((((t * KT) / FPK == f) ? v[j].x : v[j].y) - lse);
       }
     }
     const float tot = wave_sum(ok ? rs : 0.f);
@@ -1160,10 +1161,18 @@ hipError_t mavlm_launch_attention_hd_frames(const mavlm_attn_args& a, int head_d
   if (a.H % nb != 0) return hipErrorInvalidValue;
   hipError_t e = dtype == MAVLM_F16 ? launch_fwd_hd<F16, 448, 2, 1>(a, s) : launch_fwd_hd<BF16, 448, 2, 1>(a, s);
   if (e != hipSuccess) return e;
-  const int FN = a.S / a.frame_keys, nt_all = (a.S + KTH - 1) / KTH;
-  mavlm_prof_scope prof(MAVLM_K_MISC, 0.0, (double)a.H * a.R * nt_all * 8.0, s);
-  hipLaunchKernelGGL(frame_tiles_kernel, dim3((a.R + 63) / 64, a.H), dim3(256), 0, s, a.frame_scr, a.lse2, a.frame_out, a.R, a.H / nb,
-                     nt_all, a.frame_keys, FN);
+  return mavlm_launch_frame_tiles(a.frame_scr, a.lse2, a.frame_out, a.R, a.H, a.H / nb, (a.S + KTH - 1) / KTH, KTH, a.frame_keys,
+                                  a.S / a.frame_keys, s);
+}
+
+// entries [H][nt_all][R] of the tile-entry frame-score forms (this file: 32-key tiles; attention3.hip FR = 2: 64-key tiles) ->
+// fout[video][(head, 64-row block)][frame]
+hipError_t mavlm_launch_frame_tiles(const float* fent, const float* lse2, float* fout, int R, int H, int Hv, int nt_all,
+                                    int tile_keys, int frame_keys, int FN, hipStream_t s) {
+  if (!fent || !lse2 || !fout || R <= 0 || H <= 0 || Hv <= 0 || FN <= 0 || FN > 64) return hipErrorInvalidValue;
+  mavlm_prof_scope prof(MAVLM_K_MISC, 0.0, (double)H * R * nt_all * 8.0, s);
+  hipLaunchKernelGGL(frame_tiles_kernel, dim3((R + 63) / 64, H), dim3(256), 0, s, fent, lse2, fout, R, Hv, nt_all, frame_keys, FN,
+                     tile_keys);
   return hipGetLastError();
 }
 

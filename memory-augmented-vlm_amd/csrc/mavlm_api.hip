@@ -17,6 +17,7 @@ struct mavlm_ctx {
   // workspace carve (byte offsets)
   size_t o_kv, o_q, o_ctx, o_a, o_h, o_pre, o_mA, o_mB, o_lse, o_part, o_split, o_gsplit, gsplit_floats, total;
   size_t o_fscr = 0, o_fout = 0;   // frame-score variant of the last layer's forward (0 = not available for this config)
+  bool ftiles_ok = false;          // ... and the carve covers its tile-entry form (attention3.hip FR = 2)
   size_t split_floats = 0;         // floats carved at o_split (attention partials: split-KV / stream-K)
   size_t o_lnx = 0, lnx_bytes = 0; // scratch of the fused dense + residual + LayerNorm GEMM epilogue (0 = not used for this config)
   const void* pre_seg = nullptr;   // mavlm_project_chunk: the chunk whose K/V already sit in the workspace (0 = none)
@@ -149,11 +150,25 @@ void carve(mavlm_ctx* x) {
   // scratch of the frame-score variant of the last formation layer's forward (attention3.hip): (a, m) per (head, memory
   // row, frame) and the partial frame sums per (unit, 32-query group)
   x->o_fscr = x->o_fout = 0;
+  x->ftiles_ok = false;
   {
     const int fc = c.max_chunk_frames < 64 ? c.max_chunk_frames : 64;      // chunks of more frames take the column-sum pass
-    if (!wide_heads(c) && mavlm_attention_frames_supported((int)R1, fc * c.patches, (int)(H * B), c.patches)) {
-      x->o_fscr = o; o += al(mavlm_attention_frames_scr_floats((int)R1, fc * c.patches, (int)(H * B), c.patches) * 4);
-      x->o_fout = o; o += al(mavlm_attention_frames_out_floats((int)R1, fc * c.patches, (int)(H * B), c.patches) * 4);
+    const bool sup1 = !wide_heads(c) && mavlm_attention_frames_supported((int)R1, fc * c.patches, (int)(H * B), c.patches);
+    const bool sup2 = !wide_heads(c) && mavlm_attention_frame_tiles_supported((int)R1, fc * c.patches, (int)(H * B), c.patches) &&
+                      mavlm_attention_frame_tiles_scr_floats((int)R1, fc * c.patches, (int)(H * B)) * 4 <= ((size_t)1 << 30);
+    if (sup1 || sup2) {
+      // the per-(row, frame) form and / or the per-(row, 64-key tile) form (the small grids that split their keys): the larger of both
+      size_t scr = sup1 ? mavlm_attention_frames_scr_floats((int)R1, fc * c.patches, (int)(H * B), c.patches) : 0;
+      size_t out = sup1 ? mavlm_attention_frames_out_floats((int)R1, fc * c.patches, (int)(H * B), c.patches) : 0;
+      if (sup2) {
+        const size_t s2 = mavlm_attention_frame_tiles_scr_floats((int)R1, fc * c.patches, (int)(H * B));
+        const size_t o2 = mavlm_attention_frame_tiles_out_floats((int)R1, c.patches, (int)(H * B), c.patches) * 64;
+        scr = s2 > scr ? s2 : scr;
+        out = o2 > out ? o2 : out;
+      }
+      x->ftiles_ok = sup2;
+      x->o_fscr = o; o += al(scr * 4);
+      x->o_fout = o; o += al(out * 4);
     } else if (wide_heads(c) && mavlm_attention_hd_frames_supported((int)R1, fc * c.patches, (int)(H * B), c.hidden / c.heads, c.patches) &&
                mavlm_attention_hd_frames_scr_floats((int)R1, fc * c.patches, (int)(H * B)) * 4 <= ((size_t)1 << 30)) {
       // head_dim 448 (attention_hd.hip): one 8-byte entry per (head, memory row, 32-key tile) - up to 1 GiB, else the column-sum pass
@@ -243,7 +258,7 @@ int dense_ln(mavlm_ctx* x, hipStream_t s, const void* A, int lda, const void* W,
 // at once: xq / out are [B R, D]; video b's S keys start kv_bs elements after video b-1's.
 // frame_rows (out): rows of the partial frame sums per video when `frames` (argument of the finish kernel)
 int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const void* xq, const void* K, int ldk,
-               const void* V, int ldv, long long kv_bs, int S, void* out, float* lse2, bool frames = false,
+               const void* V, int ldv, long long kv_bs, int S, void* out, float* lse2, int frames = 0,
                int* frame_rows = nullptr) {
   const mavlm_config& c = x->cfg;
   const int B = nbatch(c), R1 = q_tokens(c) * c.patches, R = R1 * B, D = c.hidden, H = c.heads, dt = c.dtype,
@@ -277,7 +292,13 @@ int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const 
     const size_t need = (B == 1 || mavlm_attention_streamk_wgs(R1, S, H * B) > 0) ? mavlm_attention_split_ws_floats(R1, S, H * B) : 0;
     if (need > x->split_floats) return MAVLM_E_STATE;
     a.split_ws = x->split_floats ? (float*)ws(x, x->o_split) : nullptr;
-    if (frames) {                           // forward + per-frame probability mass in one pass (no column-sum pass)
+    if (frames == 2) {                      // forward + per-(row, tile) masses: any schedule, incl. the split-KV small grids
+      a.frame_scr = (float*)ws(x, x->o_fscr);
+      a.frame_out = (float*)ws(x, x->o_fout);
+      a.frame_keys = c.patches;
+      if (frame_rows) *frame_rows = H * ((R1 + 63) / 64);
+      MAVLM_TRY(mavlm_launch_attention3_frame_tiles(a, dt, s));
+    } else if (frames) {                    // forward + per-frame probability mass in one pass (no column-sum pass)
       a.frame_scr = (float*)ws(x, x->o_fscr);
       a.frame_out = (float*)ws(x, x->o_fout);
       a.frame_keys = c.patches;
@@ -293,15 +314,20 @@ int attn_block(mavlm_ctx* x, hipStream_t s, const mavlm_attn_weights& aw, const 
 
 // does the step take the fused frame scores for a last-layer attention over S keys?  (single videos: not the small grids
 // that split their keys - mavlm_frame_scores_fused; a row batch never splits)
-bool step_frames_fused(const mavlm_ctx* x, int S) {
+// 0 = no (column-sum pass), 1 = per-(row, frame) masses (attention3.hip FR = 1) or the wide heads' tile entries, 2 = the tile-entry
+// form of the 128-wide kernel (FR = 2: the small grids that split their keys; everywhere under mavlm_set_frame_score_mode(2))
+int step_frames_fused(const mavlm_ctx* x, int S) {
   const mavlm_config& c = x->cfg;
   const int B = nbatch(c), R1 = q_tokens(c) * c.patches;
-  if (x->o_fscr == 0) return false;
+  if (x->o_fscr == 0 || g_mavlm_frame_score_mode == 0) return 0;
+  const bool fits = S <= (c.max_chunk_frames < 64 ? c.max_chunk_frames : 64) * c.patches;
   if (wide_heads(c))       // (any schedule: a (row, tile) entry has one writer under all of them)
-    return g_mavlm_frame_score_mode == 1 && S <= (c.max_chunk_frames < 64 ? c.max_chunk_frames : 64) * c.patches &&
-           mavlm_attention_hd_frames_supported(R1, S, c.heads * B, c.hidden / c.heads, c.patches);
-  if (B == 1) return mavlm_frame_scores_fused(R1, S, c.heads, c.patches) != 0;
-  return g_mavlm_frame_score_mode == 1 && g_mavlm_attn_impl != 2 && mavlm_attention_frames_supported(R1, S, c.heads * B, c.patches);
+    return fits && mavlm_attention_hd_frames_supported(R1, S, c.heads * B, c.hidden / c.heads, c.patches) ? 1 : 0;
+  if (g_mavlm_attn_impl == 2) return 0;
+  const bool tiles = x->ftiles_ok && fits && mavlm_attention_frame_tiles_supported(R1, S, c.heads * B, c.patches);
+  if (g_mavlm_frame_score_mode == 2) return tiles ? 2 : 0;
+  if (B == 1) return mavlm_frame_scores_fused(R1, S, c.heads, c.patches) != 0 ? 1 : (tiles ? 2 : 0);
+  return mavlm_attention_frames_supported(R1, S, c.heads * B, c.patches) ? 1 : 0;
 }
 
 int step_impl(mavlm_ctx* x, const void* const* segs, int32_t F, void* frame_scores, int32_t scores_f32, hipStream_t s) {
@@ -359,7 +385,7 @@ int step_impl(mavlm_ctx* x, const void* const* segs, int32_t F, void* frame_scor
     const char* Kl = kvs + (size_t)(2 * l) * Dp * 2;
     const char* Vl = Kl + (size_t)Dp * 2;
     // frame scores: fused into this layer's forward (default), or the column-sum pass over its Q / K / lse2
-    const bool fused_scores = want_scores && step_frames_fused(x, S);
+    const int fused_scores = want_scores ? step_frames_fused(x, S) : 0;
     float* lse = want_scores ? (float*)ws(x, x->o_lse) : nullptr;      // (the fused form does not need it; kept for inspection)
     int frows = 0;
     int rc = attn_block(x, s, x->w.layer_attn[l], cur, Kl, ldkv, Vl, ldkv, (long long)S * ldkv, S, ws(x, x->o_a), lse,
@@ -463,7 +489,7 @@ int mavlm_set_attention_wide_groups(int32_t groups) {
 }
 
 int mavlm_set_frame_score_mode(int32_t mode) {
-  if (mode != 0 && mode != 1) return MAVLM_E_ARG;
+  if (mode < 0 || mode > 2) return MAVLM_E_ARG;       // (2: diagnostics - the tile-entry form wherever it is supported)
   g_mavlm_frame_score_mode = mode;
   return 0;
 }

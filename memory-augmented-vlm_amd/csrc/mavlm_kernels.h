@@ -89,6 +89,15 @@ size_t mavlm_attention_hd_frames_scr_floats(int R, int S, int H);
 size_t mavlm_attention_hd_frames_out_floats(int R, int S, int H, int frame_keys);
 int mavlm_attention_hd_frames_rows_per_video(int R, int Hv);
 hipError_t mavlm_launch_attention_hd_frames(const mavlm_attn_args& a, int head_dim, int dtype, hipStream_t s);
+hipError_t mavlm_launch_frame_tiles(const float* fent, const float* lse2, float* fout, int R, int H, int Hv, int nt_all,
+                                    int tile_keys, int frame_keys, int FN, hipStream_t s);
+// head_dim <= 128, the tile-entry form (attention3.hip FR = 2; 64-key tiles): for the small grids that split their keys, where the
+// per-(row, frame) form above is not available.  frame_scr = H*R*ceil(S/64)*2 floats, frame_out = H*ceil(R/64)*(S/frame_keys)
+// floats (rows per video for the finish kernel: Hv*ceil(R/64)); a.lse2 required
+bool mavlm_attention_frame_tiles_supported(int R, int S, int H, int frame_keys);
+size_t mavlm_attention_frame_tiles_scr_floats(int R, int S, int H);
+size_t mavlm_attention_frame_tiles_out_floats(int R, int S, int H, int frame_keys);
+hipError_t mavlm_launch_attention3_frame_tiles(const mavlm_attn_args& a, int dtype, hipStream_t s);
 // forward + per-frame probability mass in one pass (attention3.hip; head_dim 128, frame_keys % 4 == 0, <= 64 frames)
 bool mavlm_attention_frames_supported(int R, int S, int H, int frame_keys);
 size_t mavlm_attention_frames_scr_floats(int R, int S, int H, int frame_keys);

@@ -359,6 +359,39 @@ def test_wide_head_frame_scores_ride_on_the_forward():
         assert abs(float(s1.float().sum()) - 8 * 8) < 2e-2 * 64          # sum_f score_f = H * R / P (MemoryController.py:135-139)
 
 
+@pytest.mark.parametrize("M,frames", [(8, (32, 5, 3)), (24, (9, 4))])
+def test_frame_scores_from_tile_entries_on_small_grids(M, frames):
+    """head_dim 128, round 4: the small grids that split their keys (the checkpoint's 8 memory tokens, one video) had kept the
+    column-sum pass - the per-(row, frame) masses of `attn_fwd3_kernel<.., FR = 1>` need one writer per entry.  They now write one
+    log-mass entry per (row, 64-key tile) (`FR = 2`, any schedule) and `frame_tiles_kernel` adds them per frame.  Mode 1 (automatic:
+    tile entries where the keys are split, per-frame masses elsewhere), mode 2 (tile entries wherever supported) and mode 0 (the
+    column-sum pass) on the same chunks: the memory is bit-identical, the scores agree to the rounding of their 16-bit storage."""
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=M, depth=2)
+    w = O.make_weights(cfg, seed=78)
+    proj = make_projector(cfg, w)
+    segs = [to_dev(O.bf16_round(O.hash_normal_like((F, 196, 1024), 7800 + t))) for t, F in enumerate(frames)]
+    lib = capi.lib()
+
+    def run(mode):
+        capi.check(lib.mavlm_set_frame_score_mode(mode), "mode")
+        try:
+            proj.memory_cache = []
+            out = []
+            with torch.no_grad():
+                for seg in segs:
+                    cache, scores = proj(seg)
+                    out.append((cache[-1].clone(), scores[-1].clone()))
+            return out
+        finally:
+            lib.mavlm_set_frame_score_mode(1)
+    ref = run(0)
+    for mode in (1, 2):
+        for (m1, s1), (m0, s0) in zip(run(mode), ref):
+            assert torch.equal(m1, m0)
+            assert s1.shape == s0.shape and O.rel_l2(to_np(s1), to_np(s0)) < 5e-3
+            assert abs(float(s1.float().sum()) - 8 * M) < 2e-2 * 8 * M
+
+
 def test_golden_g7_fifo_wrap_fullsize():
     """The reference-pinned chain PAST the FIFO's capacity at full width (round 3): checkpoint shape (8 memory tokens,
     D = 1024), 13 steps of 1-2 frames, cap 10 - eviction at steps 10-12 (MemoryController.py:152-154), the evolution attends
