@@ -390,6 +390,26 @@ def test_frame_scores_from_tile_entries_on_small_grids(M, frames):
             assert torch.equal(m1, m0)
             assert s1.shape == s0.shape and O.rel_l2(to_np(s1), to_np(s0)) < 5e-3
             assert abs(float(s1.float().sum()) - 8 * M) < 2e-2 * 8 * M
+    # a row batch of two under the forced tile-entry form (the (video, head) pairs of a batch share one entry array)
+    from memory_augmented_vlm_amd.model.memory_module.MemoryController import BatchedProjector
+
+    def run_batch(mode):
+        capi.check(lib.mavlm_set_frame_score_mode(mode), "mode")
+        try:
+            bp = BatchedProjector(proj, 2)
+            bp.reset()
+            out = []
+            with torch.no_grad():
+                for seg in segs:
+                    sc = bp.step([seg, segs[0][:seg.shape[0]].clone()])
+                    out.append([(bp.memory_cache(b)[-1].clone(), sc[b].clone()) for b in range(2)])
+            return out
+        finally:
+            lib.mavlm_set_frame_score_mode(1)
+    for a, b in zip(run_batch(2), run_batch(0)):
+        for (m2, s2), (m0, s0) in zip(a, b):
+            assert torch.equal(m2, m0)
+            assert O.rel_l2(to_np(s2), to_np(s0)) < 5e-3
 
 
 def test_golden_g7_fifo_wrap_fullsize():
