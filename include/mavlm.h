@@ -164,7 +164,13 @@ int mavlm_batch(const mavlm_ctx* ctx);      /* B = max(config.batch, 1) */
  * overlap it with an exchange the step has to wait for - the all-gather of the previous memory's rows in the row-sharded
  * mode.  The next mavlm_step with the same (seg, F) skips the projection; any other call discards it. */
 int mavlm_project_chunk(mavlm_ctx* ctx, const void* seg, int32_t F, void* stream);
-/* number of mavlm_step calls of this context that found (and used) a projection left by mavlm_project_chunk */
+/* The same for the step AFTER the next one, on ANOTHER stream: call it before mavlm_step(chunk t) with chunk t + 1 and a side
+ * stream, and the projection of chunk t + 1 - the largest GEMM of a step at few memory tokens - runs beside step t's small-grid
+ * kernels (round 4).  The library keeps two chunk K/V buffers (single videos) and orders the streams with events: the projection
+ * waits for the last step that read its buffer, the consuming step waits for the projection; nothing to synchronise for the host.
+ * Not inside a graph capture (MAVLM_E_STATE).  `seg` must stay valid until the consuming step has been enqueued. */
+int mavlm_project_chunk_ahead(mavlm_ctx* ctx, const void* seg, int32_t F, void* stream);
+/* number of mavlm_step calls of this context that found (and used) a projection left by mavlm_project_chunk[_ahead] */
 int mavlm_prefetch_hits(const mavlm_ctx* ctx);
 
 /* replaces memory_fuser(cat(memory_cache)) + token_type add + fine-frame gather/add + prompt/newline concat

@@ -64,6 +64,7 @@ SIGNATURES = {
     "mavlm_step_batch": (C.c_int, [vp, C.POINTER(vp), i32, vp, i32, vp]),
     "mavlm_batch": (C.c_int, [vp]),
     "mavlm_project_chunk": (C.c_int, [vp, vp, i32, vp]),
+    "mavlm_project_chunk_ahead": (C.c_int, [vp, vp, i32, vp]),
     "mavlm_prefetch_hits": (C.c_int, [vp]),
     "mavlm_fuse_emit_batch": (C.c_int, [vp, C.POINTER(vp), vp, i32, vp, i32, vp, i32, vp, i32, vp, C.c_int64,
                                         C.POINTER(C.c_int64), vp]),

@@ -20,10 +20,25 @@ struct mavlm_ctx {
   bool ftiles_ok = false;          // ... and the carve covers its tile-entry form (attention3.hip FR = 2)
   size_t split_floats = 0;         // floats carved at o_split (attention partials: split-KV / stream-K)
   size_t o_lnx = 0, lnx_bytes = 0; // scratch of the fused dense + residual + LayerNorm GEMM epilogue (0 = not used for this config)
-  const void* pre_seg = nullptr;   // mavlm_project_chunk: the chunk whose K/V already sit in the workspace (0 = none)
-  int pre_F = 0;
-  void* pre_stream = nullptr;      // ... and the stream the projection was enqueued on (mavlm_step must use the same one)
-  int pre_hits = 0;                // steps that reused a mavlm_project_chunk projection (mavlm_prefetch_hits: tests)
+  // K/V projections of chunks ahead of their step (mavlm_project_chunk: the next step; mavlm_project_chunk_ahead: the one after it,
+  // on another stream): two chunk K/V buffers (o_kv, o_kv2; single videos), a slot per buffer
+  struct pre_slot {
+    const void* seg = nullptr;     // the chunk whose K/V the buffer holds / will hold (0 = none)
+    int F = 0, step = -1;          // ... for the step with this index
+    void* stream = nullptr;        // the stream the projection was enqueued on
+    bool pending = false;          // a projection into this buffer may still be in flight on `stream` (ev_pre not waited for yet)
+  } pre[2];
+  size_t o_kv2 = 0;                // second chunk K/V buffer (0 = none: row batches)
+  hipEvent_t ev_pre[2] = {nullptr, nullptr};    // recorded behind a projection into buffer b
+  hipEvent_t ev_done[2] = {nullptr, nullptr};   // recorded behind the last step that read buffer b
+  bool done_rec[2] = {false, false};
+  int pre_hits = 0;                // steps that reused a projection (mavlm_prefetch_hits: tests)
+  ~mavlm_ctx() {
+    for (int i = 0; i < 2; ++i) {
+      if (ev_pre[i]) (void)hipEventDestroy(ev_pre[i]);
+      if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
+    }
+  }
   int fuse_mems = 1;   // cached memories the Memory-Fuser MLP takes per GEMM launch (mavlm_fuse_emit)
   int fused_ln = 1;    // snapshot of the process-wide hook at mavlm_create (0 = two-kernel form, 1 / 2 = fused where supported)
   int ln_wide = 0;     // ... and of its "rows of up to 4096 columns" test mode
@@ -86,6 +101,8 @@ void carve(mavlm_ctx* x) {
                Dp = (size_t)padded_width(c);
   size_t o = 0;
   x->o_kv = o;   o += al(B * S * 2 * L * Dp * 2);
+  x->o_kv2 = 0;
+  if (B == 1) { x->o_kv2 = o; o += al(S * 2 * L * Dp * 2); }      // landing zone of mavlm_project_chunk_ahead
   x->o_q = o;    o += al(R * Dp * 2);
   x->o_ctx = o;  o += al(R * Dp * 2);
   x->o_a = o;    o += al(R * D * 2);
@@ -370,12 +387,29 @@ int step_impl(mavlm_ctx* x, const void* const* segs, int32_t F, void* frame_scor
 
   // ---- memory formation (MemoryController.py:132-133): K/V of the chunk for all L layers in one GEMM per video (the shape
   // does not depend on the memory rows: nothing to gain from stacking, and the videos' frames stay where they are)
-  char* kvs = ws(x, x->o_kv);
   const int ldkv = 2 * L * Dp;
-  const bool pre = B == 1 && x->pre_seg == segs[0] && x->pre_F == F && x->pre_stream == (void*)s;
-  x->pre_hits += pre ? 1 : 0;       // mavlm_project_chunk ran for exactly this chunk
-  x->pre_seg = nullptr;
-  x->pre_F = 0;
+  // Which chunk K/V buffer this step reads: the one a projection made ahead for exactly this step and chunk sits in (the step
+  // then waits for it, nothing else); otherwise buffer 0 - or buffer 1 while a projection for a LATER step owns buffer 0.  A
+  // projection made for this step but another chunk is discarded (its buffer is waited for before anything overwrites it).
+  int rb = 0;
+  bool pre = false;
+  if (B == 1) {
+    hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cst);
+    const bool capturing = cst != hipStreamCaptureStatusNone;
+    for (int b = 0; b < 2; ++b)
+      if (x->pre[b].seg && x->pre[b].step == x->steps) {
+        if (!pre && !capturing && x->pre[b].seg == segs[0] && x->pre[b].F == F) { pre = true; rb = b; }
+        x->pre[b].seg = nullptr;
+      }
+    if (!pre) rb = (x->pre[0].seg && x->pre[0].step > x->steps && x->o_kv2) ? 1 : 0;
+    if (x->pre[rb].pending && !capturing) {
+      if (x->pre[rb].stream != (void*)s || !pre) MAVLM_TRY(hipStreamWaitEvent(s, x->ev_pre[rb], 0));
+      x->pre[rb].pending = false;
+    }
+  }
+  x->pre_hits += pre ? 1 : 0;       // a projection made ahead for exactly this chunk
+  char* kvs = ws(x, rb ? x->o_kv2 : x->o_kv);
   for (int b = 0; b < B && !pre; ++b)
     MAVLM_TRY(gemm_x(x, s, segs[b], D, x->w.w_kv_seg, D, x->w.b_kv_seg, kvs + (size_t)b * S * ldkv * 2, ldkv, S, ldkv, D,
                      MAVLM_EPI_BIAS));
@@ -422,6 +456,14 @@ int step_impl(mavlm_ctx* x, const void* const* segs, int32_t F, void* frame_scor
       if (rc2) return rc2;
     }
     cur = dst;
+  }
+  if (B == 1 && x->o_kv2) {          // the chunk K/V buffer this step read is free once the stream gets here
+    hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cst);
+    if (cst == hipStreamCaptureStatusNone && x->ev_done[rb]) {
+      MAVLM_TRY(hipEventRecord(x->ev_done[rb], s));
+      x->done_rec[rb] = true;
+    }
   }
   x->steps += 1;   // append; the slot written above evicts the oldest entry once the ring is full (:152-154)
   return 0;
@@ -590,8 +632,7 @@ int mavlm_bind_weights(mavlm_ctx* x, const mavlm_weights* w) {
       return MAVLM_E_ARG;
   }
   x->w = *w;
-  x->pre_seg = nullptr;            // K/V projected with the previous weights are not this context's any more
-  x->pre_F = 0;
+  x->pre[0].seg = x->pre[1].seg = nullptr;      // K/V projected with the previous weights are not this context's any more
   x->has_w = true;
   return 0;
 }
@@ -602,8 +643,8 @@ int mavlm_bind_buffers(mavlm_ctx* x, const mavlm_buffers* b) {
   x->b = *b;
   x->has_b = true;
   x->lnx_clean = false;            // a new workspace: its exchange scratch is zero-filled at the first step
-  x->pre_seg = nullptr;            // (a prefetched projection lived in the old workspace)
-  x->pre_F = 0;
+  x->pre[0] = x->pre[1] = mavlm_ctx::pre_slot();     // (a prefetched projection lived in the old workspace)
+  x->done_rec[0] = x->done_rec[1] = false;
   return 0;
 }
 
@@ -620,8 +661,7 @@ int mavlm_ln_status_async(mavlm_ctx* x, void* host16, int32_t clear, void* strea
 int mavlm_reset(mavlm_ctx* x) {
   if (!x) return MAVLM_E_ARG;
   x->steps = 0;
-  x->pre_seg = nullptr;
-  x->pre_F = 0;
+  x->pre[0].seg = x->pre[1].seg = nullptr;      // (a projection still in flight keeps its `pending` mark: the next writer waits)
   return 0;
 }
 
@@ -655,17 +695,48 @@ int mavlm_step_batch(mavlm_ctx* x, const void* const* segs, int32_t F, void* fra
 
 int mavlm_batch(const mavlm_ctx* x) { return x ? nbatch(x->cfg) : MAVLM_E_ARG; }
 
-int mavlm_project_chunk(mavlm_ctx* x, const void* seg, int32_t F, void* stream) {
+namespace {
+// K/V projection of chunk `seg` for the step with index `for_step` (>= x->steps), enqueued on `stream`
+int project_for(mavlm_ctx* x, const void* seg, int32_t F, void* stream, int for_step) {
   if (!x || !seg) return MAVLM_E_ARG;
   if (!x->has_w || !x->has_b || nbatch(x->cfg) != 1) return MAVLM_E_STATE;
   const mavlm_config& c = x->cfg;
   if (F <= 0 || F > c.max_chunk_frames) return MAVLM_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cst);
+  if (cst != hipStreamCaptureStatusNone) return MAVLM_E_STATE;         // (events across streams: not inside a graph capture)
+  for (int i = 0; i < 2; ++i) {
+    if (!x->ev_pre[i]) MAVLM_TRY(hipEventCreateWithFlags(&x->ev_pre[i], hipEventDisableTiming));
+    if (!x->ev_done[i]) MAVLM_TRY(hipEventCreateWithFlags(&x->ev_done[i], hipEventDisableTiming));
+  }
+  // The buffer.  For the upcoming step (index n = x->steps): buffer 0, or 1 while buffer 0 holds a projection for a later step.
+  // For the step after it: buffer 1 - the upcoming step reads (or projects inline into) buffer 0 - unless buffer 1 holds the
+  // projection the upcoming step is going to read, then 0.
+  int tb = 0;
+  if (x->o_kv2) {
+    const int n = x->steps;
+    if (for_step == n) tb = (x->pre[0].seg && x->pre[0].step > n) ? 1 : 0;
+    else tb = (x->pre[1].seg && x->pre[1].step == n) ? 0 : 1;
+  }
+  if (x->pre[tb].pending && x->pre[tb].stream != stream) MAVLM_TRY(hipStreamWaitEvent(s, x->ev_pre[tb], 0));   // an older projection
+  if (x->done_rec[tb]) MAVLM_TRY(hipStreamWaitEvent(s, x->ev_done[tb], 0));     // the last step that read this buffer has finished
   const int D = c.hidden, Dp = padded_width(c), ldkv = 2 * c.depth * Dp, S = F * c.patches;
-  MAVLM_TRY(gemm_x(x, (hipStream_t)stream, seg, D, x->w.w_kv_seg, D, x->w.b_kv_seg, ws(x, x->o_kv), ldkv, S, ldkv, D, MAVLM_EPI_BIAS));
-  x->pre_seg = seg;
-  x->pre_F = F;
-  x->pre_stream = stream;
+  MAVLM_TRY(gemm_x(x, s, seg, D, x->w.w_kv_seg, D, x->w.b_kv_seg, ws(x, tb ? x->o_kv2 : x->o_kv), ldkv, S, ldkv, D, MAVLM_EPI_BIAS));
+  MAVLM_TRY(hipEventRecord(x->ev_pre[tb], s));
+  x->pre[tb].seg = seg;
+  x->pre[tb].F = F;
+  x->pre[tb].step = for_step;
+  x->pre[tb].stream = stream;
+  x->pre[tb].pending = true;
   return 0;
+}
+}  // namespace
+
+int mavlm_project_chunk(mavlm_ctx* x, const void* seg, int32_t F, void* stream) { return project_for(x, seg, F, stream, x ? x->steps : 0); }
+int mavlm_project_chunk_ahead(mavlm_ctx* x, const void* seg, int32_t F, void* stream) {
+  if (x && !x->o_kv2) return MAVLM_E_STATE;
+  return project_for(x, seg, F, stream, x ? x->steps + 1 : 0);
 }
 
 namespace {

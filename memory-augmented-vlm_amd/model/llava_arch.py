@@ -137,6 +137,9 @@ def video_token_rows(num_frames: int, mem_tokens: int, patches: int = 196, with_
     return rows
 
 
+PROJECT_AHEAD = None      # None: automatic (TransformerProjector.ahead_ok), True: wherever the memory rows are few, False: never
+
+
 def video_memory_tokens(model, image: torch.Tensor, frame_idx_cpu: torch.Tensor, memory_prompt_embeds: torch.Tensor,
                         frame_prompt_embeds: torch.Tensor, image_newline: torch.Tensor, with_frames: bool = True,
                         chunk: int = 32, fine_frames: int = 32, out: Optional[torch.Tensor] = None):
@@ -156,7 +159,13 @@ def video_memory_tokens(model, image: torch.Tensor, frame_idx_cpu: torch.Tensor,
     fine_cpu = fine_frame_indices(T, fine_frames)                                         # :513-522
     bounds = uniform_segment_variant(T, chunk)                                            # :528
     rm.memory_cache = []                                                                  # :532
+    # (few memory tokens: the next chunk's K/V projection - the largest GEMM of a step there - runs on a side stream beside this
+    #  chunk's small-grid kernels, TransformerProjector.project_ahead; PROJECT_AHEAD = False switches it off)
+    ahead = PROJECT_AHEAD is not False and len(bounds) > 2 and rm.ahead_ok(force=PROJECT_AHEAD is True) and \
+        max(bounds[i + 1] - bounds[i] for i in range(len(bounds) - 1)) <= int(getattr(rm.config, "max_chunk_frames", 32))
     for i in range(len(bounds) - 1):                                                      # :534-537
+        if ahead and i + 2 < len(bounds):
+            rm.project_ahead(x[bounds[i + 1]:bounds[i + 2]])
         rm(x[bounds[i]:bounds[i + 1]])
     if rm._cache_mode == "autograd" or _tail_wants_grad(model, memory_prompt_embeds, frame_prompt_embeds, image_newline):
         # training.  With `recurrent_memory_transformer` frozen but a trainable fuser / token-type embedding / newline /

@@ -500,6 +500,36 @@ class TransformerProjector(nn.Module):
         r._fused_ln_never = bool(fused_ln_never)
         return r
 
+    # -- the next chunk's K/V projection beside this chunk's step (round 4) ----------------------------------
+    _ahead_stream = None
+
+    def ahead_ok(self, force: bool = False) -> bool:
+        """Is it worth projecting the NEXT chunk's K/V on a side stream while this chunk's step runs?  Only where the step's own
+        kernels leave most of the chip idle - few memory rows (fewer than 128 tiles of 256 x 256 in a D-wide GEMM over them) - AND
+        the projection is long enough to matter: measured (`tools/diag_ahead_ab.py`, same process) +1.3 % at the OneVision-7B width
+        with 8 memory tokens (20.31 against 20.57 ms per 256-frame video), +-0.4 % at D = 1024 (off there; two streams of single
+        videos: -1.8 %).  Inference path only, not inside a graph capture.  `llava_arch.PROJECT_AHEAD = True` forces it on."""
+        if self._cache_mode == "autograd" or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            return False
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        rows = self.num_memory_tokens * self.patch_size
+        return -(-rows // 256) * -(-self.hidden_size // 256) < 128 and (force or self.hidden_size >= 2048)
+
+    def project_ahead(self, next_segment: torch.Tensor):
+        """`mavlm_project_chunk_ahead`: call BEFORE `self(segment_t)` with segment t + 1 (the tensor the next call will be given).
+        The library orders the two streams with events; results do not change."""
+        F = next_segment.shape[0]
+        eng = self.engine(next_segment.device, next_segment.dtype, F)
+        x = next_segment.contiguous()
+        cur = torch.cuda.current_stream()
+        if self._ahead_stream is None or self._ahead_stream.device != x.device:
+            self._ahead_stream = torch.cuda.Stream(device=x.device)
+        side = self._ahead_stream
+        side.wait_stream(cur)                      # (the producer of the frames; also everything of the steps before this one)
+        capi.check(capi.lib().mavlm_project_chunk_ahead(eng.ctx, x.data_ptr(), F, side.cuda_stream), "mavlm_project_chunk_ahead")
+        x.record_stream(side)
+
     # -- forward -----------------------------------------------------------------------------------------
     def forward(self, image_features: torch.Tensor):
         if image_features.dim() != 3:

@@ -94,6 +94,79 @@ def test_row_batch_bit_identical_when_the_schedules_coincide(mode):
         assert torch.equal(toks2[b], singles[B - 1 - b][:b_ + 1])
 
 
+def test_next_chunk_projection_on_a_side_stream_changes_nothing():
+    """Round 4: at few memory tokens `video_memory_tokens` enqueues the NEXT chunk's K/V projection on a side stream before each step
+    (`mavlm_project_chunk_ahead`: two chunk K/V buffers, event-ordered).  Same bits as the plain loop (`PROJECT_AHEAD = False`), every
+    step but the first finds its projection (mavlm_prefetch_hits), a ragged last chunk and back-to-back videos included; a chunk that
+    is NOT the announced one discards the projection and still gives the right result."""
+    cfg = O.PathConfig(hidden=1024, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=62)
+    model = _host(cfg, w, "bf16")
+    rm = model.recurrent_memory_transformer
+    T = 100                                                    # 32 + 32 + 32 + 4 frames
+    vids = [to_dev(O.bf16_round(O.hash_normal_like((T, 196, 1024), 6200 + b)), "bf16") for b in range(2)]
+    idx = torch.arange(T)
+    mp, fp = _prompts(1024)
+    lib = capi.lib()
+    assert rm.ahead_ok(force=True) and not rm.ahead_ok()       # (automatic only at hidden >= 2048: no gain at D = 1024)
+    prev = arch.PROJECT_AHEAD
+    try:
+        arch.PROJECT_AHEAD = False
+        plain = [arch.video_memory_tokens(model, v, idx, mp, fp, model.image_newline)[0].clone() for v in vids]
+        pscores = [s.clone() for s in rm.frame_attn_scores[-4:]]
+        arch.PROJECT_AHEAD = True
+        eng = rm.engine(vids[0].device, vids[0].dtype)
+        h0 = lib.mavlm_prefetch_hits(eng.ctx)
+        ahead = [arch.video_memory_tokens(model, v, idx, mp, fp, model.image_newline)[0].clone() for v in vids]
+        torch.cuda.synchronize()
+        assert lib.mavlm_prefetch_hits(eng.ctx) - h0 == 2 * 3
+        for a, b in zip(ahead, plain):
+            assert torch.equal(a, b)
+        for a, b in zip(rm.frame_attn_scores[-4:], pscores):
+            assert torch.equal(a, b)
+        # an announced chunk that does not come: the step projects its own chunk
+        x = vids[0]
+        rm.memory_cache = []
+        rm(x[:32])
+        ref1 = rm(x[32:64])[0][-1].clone()
+        rm.memory_cache = []
+        rm.project_ahead(x[64:96])                              # announces the wrong chunk for step 1
+        rm(x[:32])
+        got1 = rm(x[32:64])[0][-1].clone()
+        torch.cuda.synchronize()
+        assert torch.equal(got1, ref1)
+    finally:
+        arch.PROJECT_AHEAD = prev
+
+
+def test_next_chunk_projection_is_automatic_at_the_ov7b_width():
+    """... and at hidden 3584 with 8 memory tokens it is what `video_memory_tokens` does by itself (measured +1.3 %): same tokens as
+    with `PROJECT_AHEAD = False`, two of three steps find their projection."""
+    cfg = O.PathConfig(hidden=3584, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=63)
+    model = _host(cfg, w, "bf16")
+    rm = model.recurrent_memory_transformer
+    assert rm.ahead_ok()
+    T = 11
+    vid = to_dev(O.bf16_round(O.hash_normal_like((T, 196, 3584), 6300)), "bf16")
+    idx = torch.arange(T)
+    mp, fp = _prompts(3584)
+    lib = capi.lib()
+    prev = arch.PROJECT_AHEAD
+    try:
+        arch.PROJECT_AHEAD = False
+        plain = arch.video_memory_tokens(model, vid, idx, mp, fp, model.image_newline, chunk=4)[0].clone()
+        arch.PROJECT_AHEAD = None
+        eng = rm.engine(vid.device, vid.dtype)
+        h0 = lib.mavlm_prefetch_hits(eng.ctx)
+        auto = arch.video_memory_tokens(model, vid, idx, mp, fp, model.image_newline, chunk=4)[0].clone()
+        torch.cuda.synchronize()
+        assert lib.mavlm_prefetch_hits(eng.ctx) - h0 == 2
+        assert torch.equal(auto, plain)
+    finally:
+        arch.PROJECT_AHEAD = prev
+
+
 def test_row_batch_checkpoint_shape_vs_oracle():
     """The reference-default shape (8 memory tokens, D = 1024, 8 heads), five videos in one row batch, 2 chunks of 32 frames:
     40 (video, head) pairs x 7 query blocks = 280 eight-wave units on 256 workgroups - the levelled stream-K schedule with
