@@ -1,6 +1,6 @@
 // Backward of the fused multi-head cross-attention for WIDE heads (head_dim 448: LLaVA-OneVision-7B, hidden 3584 / 8 heads) -
 // flash style: the probabilities are recomputed per tile from the saved log-sum-exp, nothing of size [R, S] touches memory.
-// (Rounds 2-4 trained this width through a GEMM-composed backward: one head's [R, S] scores materialised in fp32, five GEMMs,
+// (Rounds 2-3, and round 4 until this kernel, trained this width through a GEMM-composed backward: one head's [R, S] scores materialised in fp32, five GEMMs,
 // five transposes and two elementwise passes per head - 30 launches per head, 240 per attention.)
 //
 //   P  = exp2(S*c - lse2[q])                 S = Q.K^T (raw), c = scale*log2(e), lse2 from the forward
@@ -48,6 +48,7 @@ __device__ __forceinline__ int wimg_x(int row) { return ((row & 3) << 2) | ((row
 
 template <int N>
 __device__ __forceinline__ void wait_lgkm() {
+  static_assert(N == 0 || N == 1 || N == 2 || N == 3 || N == 4 || N == 6 || N == 8, "add the count to the table");
   if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   else if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
