@@ -488,6 +488,8 @@ def run_replica(args, rank, world, local, device, dist_info):
     extras = {}
     if args.m8_extra or (world == 1 and os.environ.get("MAVLM_BENCH_M8", "1") != "0"):
         extras["m8_checkpoint_shape"] = run_m8_extra(args, device, arch)
+    if world == 1 and not args.no_latency and os.environ.get("MAVLM_BENCH_OV7B", "1") != "0":
+        extras["ov7b_width_configs2"] = run_ov7b_extra(args, device)
 
     if rank != 0:
         return None
@@ -615,6 +617,48 @@ def run_m8_extra(args, device, arch):
             "frames_per_s": round(args.steps * B * FRAMES / med, 1), "ms_per_step": round(med / args.steps * 1e3, 4),
             "videos_per_step": B, "streams": NS, "row_batch": NB, "mem_tokens": 8, "alg_tflop_per_video": round(fl / 1e12, 4),
             "path_mfma_frac": round(B * fl / (med / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4), "this_rank_only": True}
+
+
+def run_ov7b_extra(args, device):
+    """Extras: BASELINE.json configs[2] - the LLaVA-OneVision-7B width (hidden 3584, heads of 448), 8 memory tokens, 256-frame
+    videos (8 recurrent chunks): one video on one stream (what the reference's own entry point gets) and 2 streams x a row batch
+    of 4.  Bounded: 2 warm-up + 3 timed passes each."""
+    import torch
+    hidden, frames, M = 3584, 256, 8
+    model, arch = build_model(device, hidden=hidden, mem_tokens=M, seed=2468)
+    g = torch.Generator(device="cpu").manual_seed(56)
+    x0 = torch.randn((frames, PATCHES, hidden), generator=g).to(device).to(torch.bfloat16)
+    xs = [x0] + [x0.roll(b, 0) for b in range(1, 8)]
+    idx_cpu = torch.arange(frames)
+    mem_ids = torch.tensor(arch.MEMORY_PROMPT_IDS, device=device)
+    frame_ids = torch.tensor(arch.FRAME_PROMPT_IDS, device=device)
+    fl = algorithmic_flops(M=M, frames=frames, D=hidden)
+    out = {"hidden": hidden, "frames": frames, "mem_tokens": M, "alg_tflop_per_video": round(fl / 1e12, 3), "this_rank_only": True}
+    for name, (ns, nb) in (("single_video", (1, 1)), ("streams2_batch4", (2, 4))):
+        pool = arch.MemoryPathPool(model, ns, batch=nb)
+        vids = xs[:ns * nb]
+
+        def step():
+            mp = torch.nn.functional.embedding(mem_ids, model.embed_tokens.weight)
+            fp = torch.nn.functional.embedding(frame_ids, model.embed_tokens.weight)
+            return pool.run([(xi, idx_cpu) for xi in vids], mp, fp, model.image_newline)[0]
+        with torch.no_grad():
+            for _ in range(2):
+                step()
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                step()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+        ts.sort()
+        med = ts[1]
+        out[name] = {"ms_per_step": round(med * 1e3, 3), "videos_per_step": ns * nb,
+                     "frames_per_s": round(ns * nb * frames / med, 1),
+                     "path_mfma_frac": round(ns * nb * fl / med / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+        del pool
+    return out
 
 
 def run_shard_video(args, rank, world, local, device, dist_info):
