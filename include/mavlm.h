@@ -162,7 +162,9 @@ int mavlm_step_batch(mavlm_ctx* ctx, const void* const* segs, int32_t F, void* f
 int mavlm_batch(const mavlm_ctx* ctx);      /* B = max(config.batch, 1) */
 /* K/V projection of a chunk ahead of its mavlm_step (the one GEMM of a step that does not read the memory): lets a host
  * overlap it with an exchange the step has to wait for - the all-gather of the previous memory's rows in the row-sharded
- * mode.  The next mavlm_step with the same (seg, F) skips the projection; any other call discards it. */
+ * mode.  The next mavlm_step with the same (seg, F) skips the projection (and waits for it by an event when it runs on another
+ * stream); a step with another chunk, mavlm_reset, mavlm_bind_weights and mavlm_bind_buffers discard it.  Single videos only
+ * (MAVLM_E_STATE for a row batch); not inside a graph capture. */
 int mavlm_project_chunk(mavlm_ctx* ctx, const void* seg, int32_t F, void* stream);
 /* The same for the step AFTER the next one, on ANOTHER stream: call it before mavlm_step(chunk t) with chunk t + 1 and a side
  * stream, and the projection of chunk t + 1 - the largest GEMM of a step at few memory tokens - runs beside step t's small-grid
