@@ -12,7 +12,7 @@ from memory_augmented_vlm_amd import _capi as capi  # noqa: E402
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 lib = capi.lib()
-for (M, st, b, modes) in ((8, 1, 1, (1, 0)), (8, 2, 1, (1, 0)), (64, 2, 2, (1, 2)), (64, 1, 1, (1, 2))):
+for (M, st, b, modes) in ((8, 1, 1, (1, 0)), (8, 2, 1, (1, 0)), (64, 2, 2, (1, 2)), (64, 1, 1, (1, 2)), (8, 2, 8, (1, 2)), (8, 1, 8, (1, 2))):
     model, arch = bench.build_model(dev, hidden=1024, mem_tokens=M, seed=4321 if M == 8 else 1234)
     idx = torch.arange(bench.FRAMES)
     g = torch.Generator(device="cpu").manual_seed(100)
