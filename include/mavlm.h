@@ -414,6 +414,10 @@ int mavlm_set_attention_wide_groups(int32_t groups);
  * writer per entry), take the tile-entry form as well (64-key tiles; round 4); 2 = diagnostics: the tile-entry form wherever it is
  * supported.  Same values up to fp32 summation order; the memory never depends on the mode. */
 int mavlm_set_frame_score_mode(int32_t mode);
+/* dense + bias + residual + LayerNorm where the GEMM splits its contraction (small grids, K >= 2048 - the 4D -> D projection at few
+ * memory tokens): 1 (default) = the fp32 planes go straight into ONE reduce + LayerNorm kernel (round 4), 0 = reduction pass, fp32
+ * dense output, LayerNorm kernel.  Same arithmetic in the same order: same bits. */
+int mavlm_set_splitk_layernorm(int32_t on);
 /* 1 if mavlm_step (single video) takes the fused form for a last-layer attention of R memory rows over S = F * patches keys
  * with heads of <= 128 columns in its per-(row, frame) form - patches % 4 == 0, patches >= 64, <= 64 frames, and not one of the
  * small grids that split their keys (mavlm_attention_ws_floats), which take the tile-entry form (mavlm_set_frame_score_mode).  The fused launch runs the SAME schedule as the

@@ -65,11 +65,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 // D % 8 == 0: a lane owns chunks of 8 consecutive elements (two float4 in, ONE 16-byte residual load and ONE 16-byte
 // store per chunk - the 4-element form above moves the 16-bit data 8 bytes per lane)
-template <typename T, int NC>
+// SK: x = `splits` fp32 planes of a split-K GEMM ([splits][rows][D]) + bias, added in the order of splitk_reduce_kernel (planes in
+// order, then the bias): the reduction pass and the LayerNorm in one kernel, same bits as the two
+template <typename T, int NC, bool SK = false>
 __global__ __launch_bounds__(256) void layernorm8_kernel(const float* __restrict__ x, const uint16_t* __restrict__ res,
                                                          int ldr, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, uint16_t* __restrict__ out,
-                                                         int rows, int D, float eps) {
+                                                         int rows, int D, float eps, int splits = 1,
+                                                         const float* __restrict__ bias = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -83,6 +86,19 @@ __global__ __launch_bounds__(256) void layernorm8_kernel(const float* __restrict
     if (j < nch) {
       v[i][0] = xr[2 * j];
       v[i][1] = xr[2 * j + 1];
+      if constexpr (SK) {
+        const size_t plane4 = (size_t)rows * D / 4;
+        for (int k = 1; k < splits; ++k) {
+          const f32x4 a = xr[(size_t)k * plane4 + 2 * j], b = xr[(size_t)k * plane4 + 2 * j + 1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[i][0][e] += a[e]; v[i][1][e] += b[e]; }
+        }
+        if (bias != nullptr) {
+          const f32x4 a = ((const f32x4*)bias)[2 * j], b = ((const f32x4*)bias)[2 * j + 1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[i][0][e] += a[e]; v[i][1][e] += b[e]; }
+        }
+      }
       if (res != nullptr) rv[i] = *(const u32x4*)(res + (size_t)row * ldr + 8 * j);
     } else {
       v[i][0] = v[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -141,11 +157,12 @@ __global__ __launch_bounds__(256) void layernorm8_kernel(const float* __restrict
 // lane holds 7-8 chunks (~110 VGPRs, 4 waves per SIMD) and 6 272 rows are 1.5 rounds of the chip's wave slots: 2.4 TB/s
 // algorithmic.  Four waves per row hold <= 2 chunks per lane (~40 VGPRs); the two row reductions go through LDS (fixed order:
 // lanes by butterfly, then the four waves in order).
-template <typename T, int NC>
+template <typename T, int NC, bool SK = false>
 __global__ __launch_bounds__(256) void layernorm8_block_kernel(const float* __restrict__ x, const uint16_t* __restrict__ res,
                                                                int ldr, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, uint16_t* __restrict__ out,
-                                                               int rows, int D, float eps) {
+                                                               int rows, int D, float eps, int splits = 1,
+                                                               const float* __restrict__ bias = nullptr) {
   __shared__ float red[2][4];
   const int tid = threadIdx.x, wave = tid >> 6;
   const int row = blockIdx.x;
@@ -159,6 +176,19 @@ __global__ __launch_bounds__(256) void layernorm8_block_kernel(const float* __re
     if (j < nch) {
       v[i][0] = xr[2 * j];
       v[i][1] = xr[2 * j + 1];
+      if constexpr (SK) {
+        const size_t plane4 = (size_t)rows * D / 4;
+        for (int k = 1; k < splits; ++k) {
+          const f32x4 a = xr[(size_t)k * plane4 + 2 * j], b = xr[(size_t)k * plane4 + 2 * j + 1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[i][0][e] += a[e]; v[i][1][e] += b[e]; }
+        }
+        if (bias != nullptr) {
+          const f32x4 a = ((const f32x4*)bias)[2 * j], b = ((const f32x4*)bias)[2 * j + 1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[i][0][e] += a[e]; v[i][1][e] += b[e]; }
+        }
+      }
       if (res != nullptr) rv[i] = *(const u32x4*)(res + (size_t)row * ldr + 8 * j);
     } else {
       v[i][0] = v[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -372,6 +402,25 @@ hipError_t mavlm_launch_layernorm(const float* x, const void* res, int ldr, cons
   mavlm_prof_scope prof(MAVLM_K_LN, 0.0, (res ? 8.0 : 6.0) * rows * (double)D, s);
   return dtype == MAVLM_F16 ? ln_dispatch<F16>(x, res, ldr, gamma, beta, out, rows, D, eps, s)
                             : ln_dispatch<BF16>(x, res, ldr, gamma, beta, out, rows, D, eps, s);
+}
+
+hipError_t mavlm_launch_layernorm_planes(const float* planes, int splits, const float* bias, const void* res, int ldr,
+                                         const float* gamma, const float* beta, void* out, int rows, int D, float eps, int dtype,
+                                         hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (!planes || !gamma || !beta || !out || splits < 1 || D <= 0 || (D & 7) || D > 4096 || (res && (ldr & 7))) return hipErrorInvalidValue;
+  mavlm_prof_scope prof(MAVLM_K_LN, 0.0, (res ? 4.0 : 2.0) * rows * (double)D + 4.0 * splits * rows * (double)D, s);
+  const int nc = (D / 8 + 63) / 64;
+#define LNP(TT)                                                                                                              \
+  do {                                                                                                                       \
+    if (nc <= 1) hipLaunchKernelGGL((layernorm8_kernel<TT, 1, true>), dim3((rows + 3) / 4), dim3(256), 0, s, planes, (const uint16_t*)res, ldr, gamma, beta, (uint16_t*)out, rows, D, eps, splits, bias); \
+    else if (nc <= 2) hipLaunchKernelGGL((layernorm8_kernel<TT, 2, true>), dim3((rows + 3) / 4), dim3(256), 0, s, planes, (const uint16_t*)res, ldr, gamma, beta, (uint16_t*)out, rows, D, eps, splits, bias); \
+    else if (nc <= 4) hipLaunchKernelGGL((layernorm8_kernel<TT, 4, true>), dim3((rows + 3) / 4), dim3(256), 0, s, planes, (const uint16_t*)res, ldr, gamma, beta, (uint16_t*)out, rows, D, eps, splits, bias); \
+    else hipLaunchKernelGGL((layernorm8_block_kernel<TT, 2, true>), dim3(rows), dim3(256), 0, s, planes, (const uint16_t*)res, ldr, gamma, beta, (uint16_t*)out, rows, D, eps, splits, bias); \
+  } while (0)
+  if (dtype == MAVLM_F16) LNP(F16); else LNP(BF16);
+#undef LNP
+  return hipGetLastError();
 }
 
 hipError_t mavlm_launch_row_add(const void* x, const int64_t* src, const void* table, const int64_t* idx, void* out,

@@ -314,6 +314,7 @@ size_t mavlm_gemm_split_ws_floats(int M, int N, int K, int epilogue, int ldc) {
 }
 
 hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s) {
+  if (g.planes_out) *g.planes_out = 0;
   if (g.M <= 0) return hipSuccess;
   if (g.epilogue == MAVLM_EPI_LN) {
     // dense + residual + LayerNorm in one kernel: the non-persistent 256-column-tile kernel only (its row-block exchange
@@ -358,6 +359,8 @@ hipError_t mavlm_launch_gemm(const mavlm_gemm_args& g, int dtype, hipStream_t s)
       hipError_t e = splits_on_256(g.M, g.N, g.K) ? mavlm_launch_gemm256_splitk(p, splits, ksplit, dtype, s)
                      : (dtype == MAVLM_F16 ? launch_splitk<F16>(p, splits, ksplit, s) : launch_splitk<BF16>(p, splits, ksplit, s));
       if (e != hipSuccess) return e;
+      if (g.planes_out) *g.planes_out = splits;
+      if (g.planes_only) return hipSuccess;                 // (the caller reduces: dense_ln's reduce + LayerNorm kernel)
       // the planes are pure partial products (the kernel skips its bias when ksplit > 0); bias + epilogue once, here
       return mavlm_launch_splitk_reduce(g.splitk_ws, splits, (size_t)g.M * g.N, g.C, dtype, s, g.bias, g.N, g.epilogue);
     }

@@ -46,6 +46,7 @@ struct mavlm_ctx {
 };
 
 int g_mavlm_fused_ln = 1;   // process-wide hook (mavlm_set_fused_layernorm); contexts snapshot it at mavlm_create
+int g_mavlm_splitk_ln = 1;  // dense + LayerNorm over a split contraction: planes -> reduce + LayerNorm in one kernel (mavlm_set_splitk_layernorm)
 
 namespace {
 
@@ -264,6 +265,26 @@ int dense_ln(mavlm_ctx* x, hipStream_t s, const void* A, int lda, const void* W,
     g.ln.ctl = (unsigned*)ws(x, x->o_lnx);
     g.ln.gran = (unsigned long long*)(ws(x, x->o_lnx) + 64);
     MAVLM_TRY(mavlm_launch_gemm(g, c.dtype, s));
+    return 0;
+  }
+  // small grids whose contraction is split (the 4D -> D projection at few memory tokens): the fp32 planes go straight into a
+  // reduce + bias + residual + LayerNorm kernel - no reduction pass, no fp32 round trip of the dense output (same bits)
+  if (g_mavlm_splitk_ln && x->gsplit_floats && (N & 7) == 0 && N <= 4096 &&
+      mavlm_gemm_split_ws_floats(rows, N, K, MAVLM_EPI_F32, N) != 0 &&
+      mavlm_gemm_split_ws_floats(rows, N, K, MAVLM_EPI_F32, N) <= x->gsplit_floats) {
+    mavlm_gemm_args g;
+    int planes = 0;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.res = nullptr; g.ldr = 0; g.C = ws(x, x->o_pre); g.ldc = N;
+    g.M = rows; g.N = N; g.K = K; g.epilogue = MAVLM_EPI_F32;
+    g.splitk_ws = (float*)ws(x, x->o_gsplit); g.planes_only = 1; g.planes_out = &planes;
+    MAVLM_TRY(mavlm_launch_gemm(g, c.dtype, s));
+    if (planes > 0) {
+      MAVLM_TRY(mavlm_launch_layernorm_planes((const float*)ws(x, x->o_gsplit), planes, bias, res, N, gamma, beta, out, rows, N,
+                                              c.eps, c.dtype, s));
+      return 0;
+    }
+    // (the launch did not split after all - a tuning hook: it wrote the dense output to `pre`)
+    MAVLM_TRY(mavlm_launch_layernorm((const float*)ws(x, x->o_pre), res, N, gamma, beta, out, rows, N, c.eps, c.dtype, s));
     return 0;
   }
   MAVLM_TRY(gemm_x(x, s, A, lda, W, ldw, bias, ws(x, x->o_pre), N, rows, N, K, MAVLM_EPI_F32));
@@ -533,6 +554,12 @@ int mavlm_set_attention_wide_groups(int32_t groups) {
 int mavlm_set_frame_score_mode(int32_t mode) {
   if (mode < 0 || mode > 2) return MAVLM_E_ARG;       // (2: diagnostics - the tile-entry form wherever it is supported)
   g_mavlm_frame_score_mode = mode;
+  return 0;
+}
+
+int mavlm_set_splitk_layernorm(int32_t on) {
+  if (on != 0 && on != 1) return MAVLM_E_ARG;
+  g_mavlm_splitk_ln = on;
   return 0;
 }
 

@@ -27,6 +27,9 @@ struct mavlm_gemm_args {
   int M, N, K;
   int epilogue;
   float* splitk_ws = nullptr;    // mavlm_gemm_split_ws_floats(M,N,K) floats, or null = never split the contraction
+  int planes_only = 0;           // split-K: leave the fp32 planes in splitk_ws, no reduction (the caller reduces: dense + LayerNorm);
+                                 // *planes_out (if set) receives the number of planes, 0 when the shape takes no split
+  int* planes_out = nullptr;
   // Row-batched output (256-column-tile kernels only; 0 = plain [M, ldc] output): the M rows are blocks of c_rpb rows; block
   // q goes to batch element b = q % c_nb as its (q / c_nb)-th block, i.e. row m lands at
   // C + b * c_bstride + ((q / c_nb) * c_rpb + m % c_rpb) * ldc (elements).  Used where the stacked rows of several videos
@@ -203,6 +206,12 @@ hipError_t mavlm_launch_frame_scores(const float* part, int planes, int H, int S
 // biased variance; rsqrt(var+eps))
 hipError_t mavlm_launch_layernorm(const float* x, const void* res, int ldr, const float* gamma, const float* beta,
                                   void* out, int rows, int D, float eps, int dtype, hipStream_t s);
+// the same with x given as `splits` fp32 planes of a split-K GEMM ([splits][rows][D], summed in order) + bias [D]: the reduction pass
+// and the LayerNorm in one kernel (same arithmetic as mavlm_launch_splitk_reduce followed by mavlm_launch_layernorm: same bits).
+// D % 8 == 0, D <= 4096, ldr % 8 == 0
+hipError_t mavlm_launch_layernorm_planes(const float* planes, int splits, const float* bias, const void* res, int ldr,
+                                         const float* gamma, const float* beta, void* out, int rows, int D, float eps, int dtype,
+                                         hipStream_t s);
 
 // out[t,p,:] = x[src[t],p,:] + table[idx[t],:]   (src null = identity, idx null = row 0)
 hipError_t mavlm_launch_row_add(const void* x, const int64_t* src, const void* table, const int64_t* idx, void* out,

@@ -109,6 +109,10 @@ def test_step_stagewise_teacher_forced(score_mode, request):
     the column-sum pass (its [H, S] result is checked as a stage of its own)."""
     capi.check(capi.lib().mavlm_set_frame_score_mode(score_mode), "frame score mode")
     request.addfinalizer(lambda: capi.lib().mavlm_set_frame_score_mode(1))
+    # (the fp32 dense output `pre` is a stage of its own here: keep the split-K reduction and the LayerNorm two kernels - the default
+    #  one-kernel form never writes it; test_splitk_reduction_inside_the_layernorm_kernel_same_bits compares the two forms)
+    capi.check(capi.lib().mavlm_set_splitk_layernorm(0), "splitk layernorm")
+    request.addfinalizer(lambda: capi.lib().mavlm_set_splitk_layernorm(1))
     H, M, mode = 8, 8, "bf16"
     cfg = O.PathConfig(hidden=1024, heads=H, mem_tokens=M, depth=2)
     D, R = cfg.hidden, cfg.mem_rows
@@ -410,6 +414,33 @@ def test_frame_scores_from_tile_entries_on_small_grids(M, frames):
         for (m2, s2), (m0, s0) in zip(a, b):
             assert torch.equal(m2, m0)
             assert O.rel_l2(to_np(s2), to_np(s0)) < 5e-3
+
+
+@pytest.mark.parametrize("hidden,hd", [(1024, 128), (3584, 448)])
+def test_splitk_reduction_inside_the_layernorm_kernel_same_bits(hidden, hd):
+    """Round 4: where the 4D -> D projection splits its contraction (few memory tokens), the fp32 planes go straight into one reduce
+    + bias + residual + LayerNorm kernel (`mavlm_launch_layernorm_planes`) instead of a reduction pass, an fp32 dense output and the
+    LayerNorm kernel (`mavlm_set_splitk_layernorm(0)`): the same additions in the same order - memories and scores bit for bit."""
+    cfg = O.PathConfig(hidden=hidden, heads=8, mem_tokens=8, depth=2)
+    w = O.make_weights(cfg, seed=79)
+    proj = make_projector(cfg, w)
+    segs = [to_dev(O.bf16_round(O.hash_normal_like((F, 196, hidden), 7900 + t))) for t, F in enumerate((32, 7, 2))]
+    lib = capi.lib()
+
+    def run(on):
+        capi.check(lib.mavlm_set_splitk_layernorm(on), "splitk layernorm")
+        try:
+            proj.memory_cache = []
+            out = []
+            with torch.no_grad():
+                for seg in segs:
+                    cache, scores = proj(seg)
+                    out.append((cache[-1].clone(), scores[-1].clone()))
+            return out
+        finally:
+            lib.mavlm_set_splitk_layernorm(1)
+    for (m1, s1), (m0, s0) in zip(run(1), run(0)):
+        assert torch.equal(m1, m0) and torch.equal(s1, s0)
 
 
 def test_golden_g7_fifo_wrap_fullsize():
