@@ -418,6 +418,9 @@ int mavlm_set_frame_score_mode(int32_t mode);
  * memory tokens): 1 (default) = the fp32 planes go straight into ONE reduce + LayerNorm kernel (round 4), 0 = reduction pass, fp32
  * dense output, LayerNorm kernel.  Same arithmetic in the same order: same bits. */
 int mavlm_set_splitk_layernorm(int32_t on);
+/* K ranges of the fp32 dense output (Residual block) on small grids with 1024 <= K < 2048 (round 4; default 2, 1 = no split).  Part of
+ * the rounding plan of those shapes; set it BEFORE mavlm_create (the workspace is sized for the plan). */
+int mavlm_set_gemm_short_splits(int32_t splits);
 /* 1 if mavlm_step (single video) takes the fused form for a last-layer attention of R memory rows over S = F * patches keys
  * with heads of <= 128 columns in its per-(row, frame) form - patches % 4 == 0, patches >= 64, <= 64 frames, and not one of the
  * small grids that split their keys (mavlm_attention_ws_floats), which take the tile-entry form (mavlm_set_frame_score_mode).  The fused launch runs the SAME schedule as the

@@ -122,6 +122,7 @@ SIGNATURES = {
     "mavlm_set_attention_wide_groups": (C.c_int, [i32]),
     "mavlm_set_frame_score_mode": (C.c_int, [i32]),
     "mavlm_set_splitk_layernorm": (C.c_int, [i32]),
+    "mavlm_set_gemm_short_splits": (C.c_int, [i32]),
     "mavlm_frame_scores_fused": (C.c_int, [i32, i32, i32, i32]),
     "mavlm_attention_frames_ws_floats": (C.c_int64, [i32, i32, i32, i32]),
     "mavlm_attention_frames": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.c_float, i32, vp, C.c_int64,

@@ -280,12 +280,18 @@ static bool use_128x256(const mavlm_gemm_args& g) {
   return t256 < 192 && t128 >= 192;
 }
 
+int g_mavlm_gemm_f32_short_splits = 2;    // (tuning hook: mavlm_set_gemm_short_splits; 1 = off; measured 1.0575 / 1.0401 / 1.0510 ms per M = 8 video for 1 / 2 / 4)
 int mavlm_gemm_splits(int M, int N, int K, int epilogue, int ldc) {
   if (M <= 0 || N % BN || K % BK || ldc != N || epilogue == MAVLM_EPI_RES_F32) return 1;
   const long tiles = (long)((M + BM - 1) / BM) * (N / BN);
   // at most one 128^2 tile per two CUs and a long contraction.  (Measured: extending this to grids of up to 448 tiles,
   // e.g. the 364-tile GEMMs of R = 1568 at the OneVision-7B width, LOSES 4 % end to end - the partial planes cost more
   // than the idle CUs.)
+  // Round 4: the fp32 dense output of a Residual block (EPI_F32) on a small grid with a SHORT contraction (the attention output
+  // projection at few memory tokens: 1568 x 1024 x 1024 = 104 tiles x 16 K-tiles, 21 us of per-tile latency): its planes are
+  // reduced inside the LayerNorm kernel for free (mavlm_launch_layernorm_planes), so the split pays from K = 1024.
+  if (epilogue == MAVLM_EPI_F32 && tiles <= 128 && K >= 1024 && K < 2048 && g_mavlm_gemm_f32_short_splits > 1)
+    return g_mavlm_gemm_f32_short_splits;
   if (tiles > 128 || K < 2048) {
     // Round 4: a LONG contraction over a grid that fills 1/4 - 1/2 of the chip with 256-row tiles (the 4D -> D projection of
     // a single video at the OneVision-7B width: 1568 x 3584 x 14336 = 98 tiles x 224 K-tiles): two (up to four) K ranges on
@@ -305,7 +311,8 @@ int mavlm_gemm_splits(int M, int N, int K, int epilogue, int ldc) {
 // which kernel runs the split planes of mavlm_gemm_splits: the 256-row one for the round-4 rule, else the 128^2 one
 static bool splits_on_256(int M, int N, int K) {
   const long tiles = (long)((M + BM - 1) / BM) * (N / BN);
-  return tiles > 128 || K < 2048;
+  (void)K;
+  return tiles > 128;
 }
 
 size_t mavlm_gemm_split_ws_floats(int M, int N, int K, int epilogue, int ldc) {

@@ -557,6 +557,13 @@ int mavlm_set_frame_score_mode(int32_t mode) {
   return 0;
 }
 
+extern int g_mavlm_gemm_f32_short_splits;
+int mavlm_set_gemm_short_splits(int32_t splits) {
+  if (splits < 1 || splits > 8) return MAVLM_E_ARG;
+  g_mavlm_gemm_f32_short_splits = splits;
+  return 0;
+}
+
 int mavlm_set_splitk_layernorm(int32_t on) {
   if (on != 0 && on != 1) return MAVLM_E_ARG;
   g_mavlm_splitk_ln = on;
