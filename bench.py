@@ -489,7 +489,10 @@ def run_replica(args, rank, world, local, device, dist_info):
     if args.m8_extra or (world == 1 and os.environ.get("MAVLM_BENCH_M8", "1") != "0"):
         extras["m8_checkpoint_shape"] = run_m8_extra(args, device, arch)
     if world == 1 and not args.no_latency and os.environ.get("MAVLM_BENCH_OV7B", "1") != "0":
-        extras["ov7b_width_configs2"] = run_ov7b_extra(args, device)
+        try:
+            extras["ov7b_width_configs2"] = run_ov7b_extra(args, device)
+        except Exception as e:                # an extra never costs the line (e.g. a box short of memory)
+            extras["ov7b_width_configs2"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank != 0:
         return None
