@@ -1,3 +1,5 @@
+"""Diagnostic (GPU box): 30 single videos at the checkpoint shape (M = 8, D = 1024, 64 frames), one stream - run it under
+`rocprofv3 --kernel-trace --stats` to see the kernel sequence of ONE video (HISTORY R4.9).  usage: rocprofv3 ... -- python3 tools/diag_m8_single_trace.py"""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import bench
